@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's assembler interface for the hot path.
+
+``Assembler`` plays the role of the slice of ``FracturePhaseFieldProblem<dim>`` that
+owns ``assemble_system(bool residual_only)`` / ``assemble_nl_residual()``
+(cracks.cc:2129-2512): same member names (``solution``, ``old_solution``,
+``old_old_solution``, ``system_pde_matrix``, ``system_pde_residual``,
+``system_total_residual``), same call shapes, same error behaviour (exceptions where the
+reference throws / aborts).  All arithmetic happens in the HIP library behind the C ABI
+(``include/pfm_assemble.h``); PyTorch only provides device memory, streams and — in
+``cracks_amd.halo`` — ``torch.distributed`` (RCCL).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import PfmError, PfmParams
+
+
+def node_flags_from_dof_flags(layout, update_flag: np.ndarray, hanging_flag: Optional[np.ndarray] = None) -> np.ndarray:
+    """One byte per node, bit c = dof (node, c) carries a homogeneous line of
+    ``constraints_update`` that is not a hanging-node line (those travel in the mesh
+    description)."""
+    n = np.arange(layout.n_nodes)
+    flags = np.zeros(layout.n_nodes, np.uint8)
+    for c in range(layout.nc):
+        d = layout.dof(n, c)
+        f = update_flag[d].astype(bool)
+        if hanging_flag is not None:
+            f &= ~hanging_flag[d].astype(bool)
+        flags |= (f.astype(np.uint8) << c).astype(np.uint8)
+    return flags
+
+
+class Context:
+    """RAII wrapper of ``pfm_ctx``."""
+
+    def __init__(self, mesh, blocked: bool, device: int = 0, n_owned_nodes: Optional[int] = None,
+                 cell_lambda: Optional[np.ndarray] = None, cell_mu: Optional[np.ndarray] = None):
+        self.lib = capi.load()
+        self.dim = mesh.dim
+        self.blocked = bool(blocked)
+        self.n_nodes = mesh.n_nodes
+        self.n_owned = mesh.n_nodes if n_owned_nodes is None else int(n_owned_nodes)
+        self.n_blocks = 4 if blocked else 1
+        d = capi.PfmMeshDesc()
+        d.dim = mesh.dim
+        d.layout = capi.LAYOUT_BLOCKED if blocked else capi.LAYOUT_INTERLEAVED
+        d.n_nodes = mesh.n_nodes
+        d.n_owned_nodes = self.n_owned
+        d.n_cells = mesh.n_cells
+        keep = []
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        d.cell_nodes = arr(mesh.cells, np.int32)
+        d.coords = arr(mesh.coords, np.float64)
+        if cell_lambda is not None:
+            d.cell_lambda = arr(cell_lambda, np.float64)
+            d.cell_mu = arr(cell_mu, np.float64)
+        d.n_hanging = int(mesh.hn_nodes.size)
+        if d.n_hanging:
+            d.hn_nodes = arr(mesh.hn_nodes, np.int32)
+            d.hn_ptr = arr(mesh.hn_ptr, np.int64)
+            d.hn_parents = arr(mesh.hn_parents, np.int32)
+            d.hn_weights = arr(mesh.hn_weights, np.float64)
+        if getattr(mesh, "box_shape", None):
+            for k, v in enumerate(mesh.box_shape):
+                d.box_cells[k] = int(v)
+        self._h = C.c_void_p()
+        rc = self.lib.pfm_ctx_create(C.byref(self._h), C.byref(d), int(device))
+        if rc != capi.PFM_OK:
+            msg = self.lib.pfm_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self.lib.pfm_ctx_destroy(self._h)
+                self._h = C.c_void_p()
+            raise PfmError(rc, "pfm_ctx_create", msg)
+        self.n_owned_dofs = self.n_owned * (self.dim + 1)
+
+    # -- helpers ---------------------------------------------------------------------
+    def _check(self, rc: int, where: str):
+        if rc != capi.PFM_OK:
+            raise PfmError(rc, where, self.lib.pfm_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pfm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- C ABI -----------------------------------------------------------------------
+    def set_stream(self, stream_handle: int):
+        self._check(self.lib.pfm_ctx_set_stream(self._h, C.c_void_p(stream_handle)), "pfm_ctx_set_stream")
+
+    def set_params(self, prm):
+        p = prm if isinstance(prm, PfmParams) else PfmParams.from_any(prm)
+        self._check(self.lib.pfm_set_params(self._h, C.byref(p)), "pfm_set_params")
+
+    def set_constraints(self, node_flags: np.ndarray):
+        f = np.ascontiguousarray(node_flags, np.uint8)
+        assert f.size == self.n_nodes
+        self._check(self.lib.pfm_set_constraints(self._h, capi.np_ptr(f, np.uint8)), "pfm_set_constraints")
+
+    def pattern_size(self, block: int):
+        r, z = C.c_int64(), C.c_int64()
+        self._check(self.lib.pfm_pattern_size(self._h, block, C.byref(r), C.byref(z)), "pfm_pattern_size")
+        return r.value, z.value
+
+    def pattern(self, block: int):
+        rows, nnz = self.pattern_size(block)
+        rowptr = np.zeros(rows + 1, np.int64)
+        colind = np.zeros(nnz, np.int32)
+        self._check(self.lib.pfm_pattern_get(self._h, block, capi.np_ptr(rowptr, np.int64),
+                                             capi.np_ptr(colind, np.int32)), "pfm_pattern_get")
+        return rowptr, colind
+
+    def state_set_device(self, sol_ptr: int, old_ptr: int, oldold_ptr: int):
+        self._check(self.lib.pfm_state_set(self._h, C.c_void_p(sol_ptr), C.c_void_p(old_ptr),
+                                           C.c_void_p(oldold_ptr), 1), "pfm_state_set")
+
+    def halo_register(self, send_ptr, send_nodes, recv_ptr, recv_nodes):
+        sp = np.ascontiguousarray(send_ptr, np.int64)
+        sn = np.ascontiguousarray(send_nodes, np.int32)
+        rp = np.ascontiguousarray(recv_ptr, np.int64)
+        rn = np.ascontiguousarray(recv_nodes, np.int32)
+        self._check(self.lib.pfm_halo_register(self._h, sp.size - 1, capi.np_ptr(sp, np.int64),
+                                               capi.np_ptr(sn, np.int32), capi.np_ptr(rp, np.int64),
+                                               capi.np_ptr(rn, np.int32)), "pfm_halo_register")
+
+    def halo_pack(self, peer: int, buf_ptr: int):
+        self._check(self.lib.pfm_halo_pack(self._h, peer, C.c_void_p(buf_ptr)), "pfm_halo_pack")
+
+    def halo_unpack(self, peer: int, buf_ptr: int):
+        self._check(self.lib.pfm_halo_unpack(self._h, peer, C.c_void_p(buf_ptr)), "pfm_halo_unpack")
+
+    def assemble_device(self, residual_only: bool, value_ptrs: Sequence[int], res_pde_ptr: int, res_tot_ptr: int):
+        arr = (C.c_void_p * 4)(*[C.c_void_p(p) for p in list(value_ptrs) + [0] * (4 - len(value_ptrs))])
+        self._check(self.lib.pfm_assemble_device(self._h, 1 if residual_only else 0, arr,
+                                                 C.c_void_p(res_pde_ptr), C.c_void_p(res_tot_ptr)),
+                    "pfm_assemble_device")
+
+    def sync_status(self):
+        self._check(self.lib.pfm_sync_status(self._h), "pfm_sync_status")
+
+    def assemble_host(self, sol, old, oldold, residual_only: bool):
+        """``pfm_assemble``: synchronous, host numpy in / host numpy out (single rank)."""
+        sol = np.ascontiguousarray(sol, np.float64)
+        old = np.ascontiguousarray(old, np.float64)
+        oldold = np.ascontiguousarray(oldold, np.float64)
+        n = self.n_owned_dofs
+        assert sol.size == old.size == oldold.size == n
+        res_pde = np.zeros(n)
+        res_tot = np.zeros(n) if residual_only else None
+        values: List[np.ndarray] = []
+        ptrs = (C.c_void_p * 4)()
+        if not residual_only:
+            for b in range(self.n_blocks):
+                values.append(np.zeros(self.pattern_size(b)[1]))
+                ptrs[b] = values[b].ctypes.data
+        rc = self.lib.pfm_assemble(self._h, capi.np_ptr(sol, np.float64), capi.np_ptr(old, np.float64),
+                                   capi.np_ptr(oldold, np.float64), 1 if residual_only else 0,
+                                   None if residual_only else ptrs, capi.np_ptr(res_pde, np.float64),
+                                   capi.np_ptr(res_tot, np.float64) if residual_only else None)
+        self._check(rc, "pfm_assemble")
+        return values, res_pde, res_tot
+
+    @property
+    def kernel_path(self) -> int:
+        return self.lib.pfm_ctx_kernel_path(self._h)
+
+    def force_path(self, path: int):
+        self._check(self.lib.pfm_ctx_force_path(self._h, path), "pfm_ctx_force_path")
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.pfm_ctx_device_bytes(self._h))
+
+
+class Assembler:
+    """Device-resident counterpart of the reference's assembly members.
+
+    ``solution`` / ``old_solution`` / ``old_old_solution`` are torch device vectors over
+    the owned dofs; ``assemble_system`` / ``assemble_nl_residual`` fill
+    ``system_pde_matrix`` (list of CSR value vectors, one per block),
+    ``system_pde_residual`` and ``system_total_residual`` on the device, asynchronously
+    on torch's current stream."""
+
+    def __init__(self, mesh, blocked: bool, device: int = 0, n_owned_nodes: Optional[int] = None,
+                 cell_lambda=None, cell_mu=None, halo=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("cracks_amd.Assembler needs a ROCm GPU (there is no CPU fallback)")
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.ctx = Context(mesh, blocked, device, n_owned_nodes, cell_lambda, cell_mu)
+        self.ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        n = self.ctx.n_owned_dofs
+        z = lambda: torch.zeros(n, dtype=torch.float64, device=self.dev)
+        self.solution, self.old_solution, self.old_old_solution = z(), z(), z()
+        self.system_pde_residual, self.system_total_residual = z(), z()
+        self.system_pde_matrix: List = []
+        self.halo = halo
+
+    def allocate_matrix(self):
+        if not self.system_pde_matrix:
+            t = self.torch
+            self.system_pde_matrix = [t.empty(self.ctx.pattern_size(b)[1], dtype=t.float64, device=self.dev)
+                                      for b in range(self.ctx.n_blocks)]
+
+    def set_params(self, prm):
+        self.ctx.set_params(prm)
+
+    def set_constraints(self, node_flags: np.ndarray):
+        self.ctx.set_constraints(node_flags)
+
+    def set_vectors(self, sol: np.ndarray, old: np.ndarray, oldold: np.ndarray):
+        t = self.torch
+        self.solution.copy_(t.from_numpy(np.ascontiguousarray(sol)))
+        self.old_solution.copy_(t.from_numpy(np.ascontiguousarray(old)))
+        self.old_old_solution.copy_(t.from_numpy(np.ascontiguousarray(oldold)))
+
+    def assemble_system(self, residual_only: bool = False):
+        """cracks.cc:2129-2475 (without the AMG set-up that follows it)."""
+        self.ctx.set_stream(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        self.ctx.state_set_device(self.solution.data_ptr(), self.old_solution.data_ptr(),
+                                  self.old_old_solution.data_ptr())
+        if self.halo is not None:
+            self.halo.exchange(self.ctx)
+        if not residual_only:
+            self.allocate_matrix()
+        self.ctx.assemble_device(residual_only, [m.data_ptr() for m in self.system_pde_matrix] if not residual_only else [],
+                                 self.system_pde_residual.data_ptr(), self.system_total_residual.data_ptr())
+
+    def assemble_nl_residual(self):
+        """cracks.cc:2507-2512."""
+        self.assemble_system(True)
+
+    def synchronize(self):
+        """Wait for the stream and raise what the reference would have thrown/aborted on."""
+        self.ctx.sync_status()

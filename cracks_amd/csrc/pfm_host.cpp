@@ -1,0 +1,585 @@
+// pfm_host.cpp — host side of the C ABI (include/pfm_assemble.h): context build
+// (node graph, CSR addressing tables, device mirrors), pattern queries, state upload,
+// halo registration and the synchronous host-pointer entry point.
+//
+// What the reference does with deal.II objects before/after the cell loop
+// (cracks.cc:2133-2160, 2439-2475) becomes table look-ups prepared here once per
+// setup_system() (cracks.cc:1579-1680):
+//   * the sparsity pattern of make_sparsity_pattern (cracks.cc:1644-1654) is the node
+//     graph of the constraint-resolved mesh (x) full component coupling; its CSR offsets
+//     are arithmetic in (node-graph offset, component), so no column search is needed
+//     at assembly time;
+//   * cell->get_dof_indices + the Trilinos column search (cracks.cc:2439-2463) become a
+//     one-byte-per-vertex-pair slot table.
+#include "pfm_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace pfm;
+
+namespace
+{
+  struct HipFail
+  {
+    hipError_t e;
+    const char *what;
+  };
+
+  template <class T>
+  T *dev_alloc(pfm_ctx *c, size_t n)
+  {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+      throw HipFail{e, "hipMalloc"};
+    c->allocs.push_back(p);
+    c->device_bytes += (int64_t)bytes;
+    return static_cast<T *>(p);
+  }
+
+  template <class T>
+  T *dev_upload(pfm_ctx *c, const T *h, size_t n)
+  {
+    T *d = dev_alloc<T>(c, n);
+    if (n)
+      {
+        hipError_t e = hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+          throw HipFail{e, "hipMemcpy H2D"};
+      }
+    return d;
+  }
+
+  int fail(pfm_ctx *c, int code, const std::string &msg)
+  {
+    if (c)
+      c->err = msg;
+    return code;
+  }
+
+  int hipfail(pfm_ctx *c, hipError_t e, const char *what)
+  {
+    return fail(c, PFM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+} // namespace
+
+int64_t pfm_ctx::block_rows(int b) const
+{
+  const int dim = v.dim;
+  if (v.layout == PFM_LAYOUT_INTERLEAVED)
+    return (int64_t)v.n_owned * (dim + 1);
+  return (b == 0 || b == 1) ? (int64_t)v.n_owned * dim : (int64_t)v.n_owned;
+}
+
+int64_t pfm_ctx::block_nnz(int b) const
+{
+  const int dim = v.dim;
+  const int64_t g = h_nadj_ptr.empty() ? 0 : (int64_t)h_nadj_ptr.back();
+  if (v.layout == PFM_LAYOUT_INTERLEAVED)
+    return g * (dim + 1) * (dim + 1);
+  switch (b)
+    {
+      case 0:
+        return g * dim * dim;
+      case 1:
+      case 2:
+        return g * dim;
+      default:
+        return g;
+    }
+}
+
+extern "C"
+{
+  int pfm_ctx_create(pfm_ctx **out, const pfm_mesh_desc *m, int device)
+  {
+    if (!out || !m || (m->dim != 2 && m->dim != 3) ||
+        (m->layout != PFM_LAYOUT_INTERLEAVED && m->layout != PFM_LAYOUT_BLOCKED) ||
+        m->n_nodes <= 0 || m->n_owned_nodes < 0 || m->n_owned_nodes > m->n_nodes || m->n_cells < 0 ||
+        !m->cell_nodes || !m->coords || (m->n_hanging > 0 && (!m->hn_nodes || !m->hn_ptr)))
+      return PFM_ERR_BAD_ARG;
+    pfm_ctx *c = new (std::nothrow) pfm_ctx;
+    if (!c)
+      return PFM_ERR_NOMEM;
+    *out = c;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess)
+      return hipfail(c, e, "hipSetDevice");
+
+    const int dim = m->dim, nv = 1 << dim;
+    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    const int64_t NC = m->n_cells;
+    DevView &v = c->v;
+    v.dim = dim;
+    v.layout = m->layout;
+    v.n_nodes = N;
+    v.n_owned = NO;
+    v.n_cells = NC;
+    c->n_blocks = (m->layout == PFM_LAYOUT_BLOCKED) ? 4 : 1;
+
+    for (int64_t i = 0; i < NC * nv; ++i)
+      if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
+        return fail(c, PFM_ERR_BAD_ARG, "cell_nodes out of range");
+
+    try
+      {
+        // ---- hanging table: node -> k
+        std::vector<int32_t> hn_index;
+        if (m->n_hanging > 0)
+          {
+            hn_index.assign(N, -1);
+            for (int32_t k = 0; k < m->n_hanging; ++k)
+              {
+                if (m->hn_nodes[k] < 0 || m->hn_nodes[k] >= N)
+                  return fail(c, PFM_ERR_BAD_ARG, "hn_nodes out of range");
+                hn_index[m->hn_nodes[k]] = k;
+              }
+            for (int64_t j = 0; j < m->hn_ptr[m->n_hanging]; ++j)
+              if (m->hn_parents[j] < 0 || m->hn_parents[j] >= N || hn_index[m->hn_parents[j]] >= 0)
+                return fail(c, PFM_ERR_BAD_ARG, "hanging table must be closed (parents unconstrained)");
+          }
+
+        // ---- node graph over the constraint-resolved cells, rows = owned nodes
+        // pass 1: count cells incident to each owned node (through its own vertices and
+        // through hanging vertices it is a parent of)
+        auto for_each_resolved = [&](int64_t cell, auto &&fn) {
+          for (int a = 0; a < nv; ++a)
+            {
+              const int32_t n = m->cell_nodes[cell * nv + a];
+              const int32_t k = hn_index.empty() ? -1 : hn_index[n];
+              fn(n);
+              if (k >= 0)
+                for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
+                  fn(m->hn_parents[j]);
+            }
+        };
+        std::vector<int64_t> inc_ptr((size_t)NO + 1, 0);
+        for (int64_t cell = 0; cell < NC; ++cell)
+          for_each_resolved(cell, [&](int32_t n) {
+            if (n < NO)
+              ++inc_ptr[n + 1];
+          });
+        for (int32_t n = 0; n < NO; ++n)
+          inc_ptr[n + 1] += inc_ptr[n];
+        std::vector<int64_t> inc((size_t)inc_ptr[NO]);
+        {
+          std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
+          for (int64_t cell = 0; cell < NC; ++cell)
+            for_each_resolved(cell, [&](int32_t n) {
+              if (n < NO)
+                inc[fill[n]++] = cell;
+            });
+        }
+        c->h_nadj_ptr.assign((size_t)NO + 1, 0);
+        std::vector<int32_t> &nadj = c->h_nadj;
+        nadj.clear();
+        nadj.reserve((size_t)NO * (dim == 2 ? 9 : 27));
+        std::vector<int32_t> tmp;
+        for (int32_t n = 0; n < NO; ++n)
+          {
+            tmp.clear();
+            for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; ++k)
+              for_each_resolved(inc[k], [&](int32_t q) { tmp.push_back(q); });
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            if (tmp.size() > 254)
+              return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
+            nadj.insert(nadj.end(), tmp.begin(), tmp.end());
+            c->h_nadj_ptr[n + 1] = (long long)nadj.size();
+          }
+        std::vector<int64_t>().swap(inc);
+
+        // ---- slot table: position of vertex b's node in the row of vertex a's node
+        std::vector<uint8_t> cslot((size_t)NC * nv * nv, 0xff);
+        for (int64_t cell = 0; cell < NC; ++cell)
+          for (int a = 0; a < nv; ++a)
+            {
+              const int32_t A = m->cell_nodes[cell * nv + a];
+              if (A >= NO)
+                continue;
+              const int32_t *rb = nadj.data() + c->h_nadj_ptr[A];
+              const int32_t *re = nadj.data() + c->h_nadj_ptr[A + 1];
+              for (int b = 0; b < nv; ++b)
+                {
+                  const int32_t B = m->cell_nodes[cell * nv + b];
+                  const int32_t *p = std::lower_bound(rb, re, B);
+                  cslot[(cell * nv + a) * nv + b] = (uint8_t)(p - rb);
+                }
+            }
+
+        // ---- device mirrors (SoA)
+        {
+          std::vector<int32_t> conn((size_t)NC * nv);
+          for (int64_t cell = 0; cell < NC; ++cell)
+            for (int a = 0; a < nv; ++a)
+              conn[(size_t)a * NC + cell] = m->cell_nodes[cell * nv + a];
+          v.conn = dev_upload(c, conn.data(), conn.size());
+        }
+        {
+          std::vector<double> xs((size_t)N * dim);
+          for (int32_t n = 0; n < N; ++n)
+            for (int d = 0; d < dim; ++d)
+              xs[(size_t)d * N + n] = m->coords[(size_t)n * dim + d];
+          v.coords = dev_upload(c, xs.data(), xs.size());
+        }
+        v.cell_lambda = v.cell_mu = nullptr;
+        if (m->cell_lambda && m->cell_mu)
+          {
+            v.cell_lambda = dev_upload(c, m->cell_lambda, (size_t)NC);
+            v.cell_mu = dev_upload(c, m->cell_mu, (size_t)NC);
+          }
+        v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
+        v.nadj = dev_upload(c, nadj.data(), nadj.size());
+        v.cslot = dev_upload(c, cslot.data(), cslot.size());
+        v.hn_index = nullptr;
+        v.hn_ptr = nullptr;
+        v.hn_parents = nullptr;
+        v.hn_weights = nullptr;
+        if (m->n_hanging > 0)
+          {
+            v.hn_index = dev_upload(c, hn_index.data(), hn_index.size());
+            std::vector<long long> hp(m->hn_ptr, m->hn_ptr + m->n_hanging + 1);
+            v.hn_ptr = dev_upload(c, hp.data(), hp.size());
+            v.hn_parents = dev_upload(c, m->hn_parents, (size_t)hp.back());
+            v.hn_weights = dev_upload(c, m->hn_weights, (size_t)hp.back());
+          }
+        uint8_t *flags = dev_alloc<uint8_t>(c, (size_t)N);
+        e = hipMemset(flags, 0, (size_t)N);
+        if (e != hipSuccess)
+          throw HipFail{e, "hipMemset"};
+        v.node_flags = flags;
+        for (int d = 0; d < 3; ++d)
+          v.u[d] = (d < dim) ? dev_alloc<double>(c, (size_t)N) : nullptr;
+        v.phi = dev_alloc<double>(c, (size_t)N);
+        v.phi_old = dev_alloc<double>(c, (size_t)N);
+        v.phi_oldold = dev_alloc<double>(c, (size_t)N);
+        for (int d = 0; d < dim; ++d)
+          hipMemset(v.u[d], 0, sizeof(double) * (size_t)N);
+        hipMemset(v.phi, 0, sizeof(double) * (size_t)N);
+        hipMemset(v.phi_old, 0, sizeof(double) * (size_t)N);
+        hipMemset(v.phi_oldold, 0, sizeof(double) * (size_t)N);
+        v.status = dev_alloc<int>(c, 1);
+        hipMemset(v.status, 0, sizeof(int));
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
+      }
+    catch (const std::bad_alloc &)
+      {
+        return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+      }
+    c->kernel_path = 0;
+    return PFM_OK;
+  }
+
+  int pfm_ctx_destroy(pfm_ctx *c)
+  {
+    if (!c)
+      return PFM_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void *p : c->allocs)
+      hipFree(p);
+    for (auto &p : c->peers)
+      {
+        if (p.d_send)
+          hipFree(p.d_send);
+        if (p.d_recv)
+          hipFree(p.d_recv);
+      }
+    for (double *p : c->d_stage_vec)
+      if (p)
+        hipFree(p);
+    for (double *p : c->d_stage_res)
+      if (p)
+        hipFree(p);
+    for (double *p : c->d_stage_val)
+      if (p)
+        hipFree(p);
+    delete c;
+    return PFM_OK;
+  }
+
+  const char *pfm_last_error(const pfm_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+  int pfm_ctx_set_stream(pfm_ctx *c, void *s)
+  {
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    c->stream = static_cast<hipStream_t>(s);
+    return PFM_OK;
+  }
+
+  int pfm_set_params(pfm_ctx *c, const pfm_params *p)
+  {
+    if (!c || !p)
+      return PFM_ERR_BAD_ARG;
+    if (c->v.dim == 3 && (p->decompose_stress_matrix > 0 || p->decompose_stress_rhs > 0) &&
+        p->timestep_number > 0)
+      return fail(c, PFM_ERR_UNSUPPORTED,
+                  "stress split is 2-D only in the reference (cracks.cc:1685-1690)");
+    c->prm = *p;
+    c->have_params = true;
+    return PFM_OK;
+  }
+
+  int pfm_set_constraints(pfm_ctx *c, const uint8_t *node_flags)
+  {
+    if (!c || !node_flags)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipError_t e = hipMemcpyAsync(const_cast<uint8_t *>(c->v.node_flags), node_flags,
+                                  (size_t)c->v.n_nodes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(c->stream); // node_flags is a borrowed host buffer
+    return e == hipSuccess ? PFM_OK : hipfail(c, e, "set_constraints copy");
+  }
+
+  int pfm_pattern_size(const pfm_ctx *c, int block, int64_t *n_rows, int64_t *nnz)
+  {
+    if (!c || block < 0 || block >= c->n_blocks)
+      return PFM_ERR_BAD_ARG;
+    if (n_rows)
+      *n_rows = c->block_rows(block);
+    if (nnz)
+      *nnz = c->block_nnz(block);
+    return PFM_OK;
+  }
+
+  int pfm_pattern_get(const pfm_ctx *c, int block, int64_t *rowptr, int32_t *colind)
+  {
+    if (!c || block < 0 || block >= c->n_blocks || !rowptr || !colind)
+      return PFM_ERR_BAD_ARG;
+    const int dim = c->v.dim;
+    int ncr, ncc, coff = 0; // components per node in the row / column space of this block
+    bool phi_col = false;
+    if (c->v.layout == PFM_LAYOUT_INTERLEAVED)
+      ncr = ncc = dim + 1;
+    else
+      {
+        ncr = (block == 0 || block == 1) ? dim : 1;
+        ncc = (block == 0 || block == 2) ? dim : 1;
+        phi_col = (ncc == 1);
+      }
+    (void)coff;
+    (void)phi_col;
+    int64_t pos = 0, row = 0;
+    rowptr[0] = 0;
+    for (int32_t n = 0; n < c->v.n_owned; ++n)
+      {
+        const long long b = c->h_nadj_ptr[n], e = c->h_nadj_ptr[n + 1];
+        for (int ci = 0; ci < ncr; ++ci)
+          {
+            for (long long k = b; k < e; ++k)
+              for (int d = 0; d < ncc; ++d)
+                colind[pos++] = c->h_nadj[k] * ncc + d;
+            rowptr[++row] = pos;
+          }
+      }
+    return PFM_OK;
+  }
+
+  int pfm_state_set(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
+                    int on_device)
+  {
+    if (!c || !sol || !old || !oldold)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    const double *src[3] = {sol, old, oldold};
+    const double *d[3] = {sol, old, oldold};
+    if (!on_device)
+      {
+        const size_t bytes = sizeof(double) * (size_t)c->n_owned_dofs();
+        for (int k = 0; k < 3; ++k)
+          {
+            if (!c->d_stage_vec[k])
+              {
+                hipError_t e = hipMalloc((void **)&c->d_stage_vec[k], std::max<size_t>(bytes, 8));
+                if (e != hipSuccess)
+                  return hipfail(c, e, "hipMalloc stage");
+                c->device_bytes += (int64_t)bytes;
+              }
+            hipError_t e = hipMemcpyAsync(c->d_stage_vec[k], src[k], bytes, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess)
+              return hipfail(c, e, "state H2D");
+            d[k] = c->d_stage_vec[k];
+          }
+      }
+    int rc = launch_state_set(c->v, d[0], d[1], d[2], c->stream);
+    if (rc)
+      return fail(c, rc, "state_set launch failed");
+    if (!on_device)
+      {
+        hipError_t e = hipStreamSynchronize(c->stream); // host buffers are borrowed
+        if (e != hipSuccess)
+          return hipfail(c, e, "state sync");
+      }
+    return PFM_OK;
+  }
+
+  int pfm_halo_register(pfm_ctx *c, int n_peers, const int64_t *send_ptr, const int32_t *send_nodes,
+                        const int64_t *recv_ptr, const int32_t *recv_nodes)
+  {
+    if (!c || n_peers < 0 || (n_peers > 0 && (!send_ptr || !recv_ptr)))
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    for (auto &p : c->peers)
+      {
+        if (p.d_send)
+          hipFree(p.d_send);
+        if (p.d_recv)
+          hipFree(p.d_recv);
+      }
+    c->peers.assign((size_t)n_peers, HaloPeer{});
+    for (int k = 0; k < n_peers; ++k)
+      {
+        HaloPeer &p = c->peers[k];
+        p.n_send = send_ptr[k + 1] - send_ptr[k];
+        p.n_recv = recv_ptr[k + 1] - recv_ptr[k];
+        for (int64_t j = send_ptr[k]; j < send_ptr[k + 1]; ++j)
+          if (send_nodes[j] < 0 || send_nodes[j] >= c->v.n_owned)
+            return fail(c, PFM_ERR_BAD_ARG, "halo send node is not an owned node");
+        for (int64_t j = recv_ptr[k]; j < recv_ptr[k + 1]; ++j)
+          if (recv_nodes[j] < c->v.n_owned || recv_nodes[j] >= c->v.n_nodes)
+            return fail(c, PFM_ERR_BAD_ARG, "halo recv node is not a ghost node");
+        hipError_t e = hipMalloc((void **)&p.d_send, std::max<size_t>(4, sizeof(int32_t) * p.n_send));
+        if (e == hipSuccess)
+          e = hipMalloc((void **)&p.d_recv, std::max<size_t>(4, sizeof(int32_t) * p.n_recv));
+        if (e == hipSuccess && p.n_send)
+          e = hipMemcpy(p.d_send, send_nodes + send_ptr[k], sizeof(int32_t) * p.n_send, hipMemcpyHostToDevice);
+        if (e == hipSuccess && p.n_recv)
+          e = hipMemcpy(p.d_recv, recv_nodes + recv_ptr[k], sizeof(int32_t) * p.n_recv, hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+          return hipfail(c, e, "halo_register");
+      }
+    return PFM_OK;
+  }
+
+  int pfm_halo_pack(pfm_ctx *c, int peer, double *d_buf)
+  {
+    if (!c || peer < 0 || peer >= (int)c->peers.size() || !d_buf)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    return launch_halo_pack(c->v, c->peers[peer].d_send, c->peers[peer].n_send, d_buf, c->stream);
+  }
+
+  int pfm_halo_unpack(pfm_ctx *c, int peer, const double *d_buf)
+  {
+    if (!c || peer < 0 || peer >= (int)c->peers.size() || !d_buf)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    return launch_halo_unpack(c->v, c->peers[peer].d_recv, c->peers[peer].n_recv, d_buf, c->stream);
+  }
+
+  int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values,
+                          double *d_res_pde, double *d_res_tot)
+  {
+    if (!c || !d_res_pde || (residual_only && !d_res_tot) || (!residual_only && !d_values))
+      return PFM_ERR_BAD_ARG;
+    if (!c->have_params)
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
+    hipSetDevice(c->device);
+    // zero the outputs (cracks.cc:2133-2137)
+    hipError_t e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
+    if (e == hipSuccess && residual_only)
+      e = hipMemsetAsync(d_res_tot, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
+    if (e == hipSuccess && !residual_only)
+      for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
+        {
+          if (!d_values[b])
+            return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
+          e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
+        }
+    if (e != hipSuccess)
+      return hipfail(c, e, "zero outputs");
+    int rc = launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+    if (rc)
+      return fail(c, rc, "assemble launch failed");
+    return PFM_OK;
+  }
+
+  int pfm_sync_status(pfm_ctx *c)
+  {
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    int st = 0;
+    hipError_t e = hipMemcpyAsync(&st, c->v.status, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+      return hipfail(c, e, "sync_status");
+    if (st != 0)
+      {
+        hipMemsetAsync(c->v.status, 0, sizeof(int), c->stream);
+        return fail(c, st, st == PFM_ERR_NOT_ORTHOGONAL
+                             ? "eigenvectors not orthogonal (cracks.cc:1732-1736)"
+                             : "device-side error");
+      }
+    return PFM_OK;
+  }
+
+  int pfm_assemble(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
+                   int residual_only, double *const *values, double *residual_pde,
+                   double *residual_total)
+  {
+    if (!c || !residual_pde || (residual_only && !residual_total) || (!residual_only && !values))
+      return PFM_ERR_BAD_ARG;
+    if (c->v.n_owned != c->v.n_nodes)
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_assemble is single-rank only; use the halo entry points");
+    int rc = pfm_state_set(c, sol, old, oldold, 0);
+    if (rc)
+      return rc;
+    const size_t vb = sizeof(double) * (size_t)c->n_owned_dofs();
+    for (int k = 0; k < 2; ++k)
+      if (!c->d_stage_res[k])
+        {
+          hipError_t e = hipMalloc((void **)&c->d_stage_res[k], std::max<size_t>(vb, 8));
+          if (e != hipSuccess)
+            return hipfail(c, e, "hipMalloc stage residual");
+          c->device_bytes += (int64_t)vb;
+        }
+    if (!residual_only)
+      for (int b = 0; b < c->n_blocks; ++b)
+        if (!c->d_stage_val[b])
+          {
+            const size_t bytes = sizeof(double) * (size_t)c->block_nnz(b);
+            hipError_t e = hipMalloc((void **)&c->d_stage_val[b], std::max<size_t>(bytes, 8));
+            if (e != hipSuccess)
+              return hipfail(c, e, "hipMalloc stage values");
+            c->device_bytes += (int64_t)bytes;
+          }
+    rc = pfm_assemble_device(c, residual_only, c->d_stage_val, c->d_stage_res[0], c->d_stage_res[1]);
+    if (rc)
+      return rc;
+    hipError_t e = hipMemcpyAsync(residual_pde, c->d_stage_res[0], vb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && residual_only)
+      e = hipMemcpyAsync(residual_total, c->d_stage_res[1], vb, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && !residual_only)
+      for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
+        e = hipMemcpyAsync(values[b], c->d_stage_val[b], sizeof(double) * (size_t)c->block_nnz(b),
+                           hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess)
+      return hipfail(c, e, "copy back");
+    return pfm_sync_status(c);
+  }
+
+  int pfm_ctx_kernel_path(const pfm_ctx *c) { return c ? c->kernel_path : -1; }
+
+  int pfm_ctx_force_path(pfm_ctx *c, int path)
+  {
+    if (!c || path != 0)
+      return PFM_ERR_UNSUPPORTED;
+    c->kernel_path = path;
+    return PFM_OK;
+  }
+
+  int64_t pfm_ctx_device_bytes(const pfm_ctx *c) { return c ? c->device_bytes : 0; }
+}

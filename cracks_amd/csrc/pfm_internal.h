@@ -1,0 +1,78 @@
+// pfm_internal.h — context layout shared by the host side (pfm_host.cpp) and the
+// kernel launchers (pfm_kernels.hip).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pfm_assemble.h"
+
+namespace pfm
+{
+  // Device-side view of the static mesh tables and the node state (SoA, HBM resident).
+  struct DevView
+  {
+    int dim, layout, n_nodes, n_owned;
+    long long n_cells;
+    const int32_t *conn;   // [nv][n_cells]     cell -> local node, vertex-major (coalesced per vertex)
+    const double *coords;  // [dim][n_nodes]
+    const double *cell_lambda, *cell_mu; // [n_cells] or nullptr
+    const long long *nadj_ptr; // [n_owned+1]  node graph (rows = owned nodes, sorted columns)
+    const int32_t *nadj;
+    const uint8_t *cslot;      // [n_cells][nv*nv] slot of vertex b's node in the row of vertex a's node
+    const int32_t *hn_index;   // [n_nodes] -> k (hanging table) or -1; nullptr when the mesh is conforming
+    const long long *hn_ptr;
+    const int32_t *hn_parents;
+    const double *hn_weights;
+    const uint8_t *node_flags; // [n_nodes] bit c: dof (node,c) has a homogeneous constraint line
+    // node state (cracks.cc:2147-2154 after the ghost import)
+    double *u[3];
+    double *phi, *phi_old, *phi_oldold;
+    int *status; // device error word (pfm_status)
+  };
+
+  struct HaloPeer
+  {
+    int32_t *d_send = nullptr, *d_recv = nullptr;
+    int64_t n_send = 0, n_recv = 0;
+  };
+
+  // launchers implemented in pfm_kernels.hip
+  int launch_state_set(const DevView &v, const double *d_sol, const double *d_old,
+                       const double *d_oldold, hipStream_t s);
+  int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
+  int launch_halo_unpack(const DevView &v, const int32_t *d_nodes, int64_t n, const double *d_buf,
+                         hipStream_t s);
+  int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
+                              double *const *d_values, double *d_res_pde, double *d_res_tot,
+                              hipStream_t s);
+} // namespace pfm
+
+struct pfm_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  pfm::DevView v{};
+  pfm_params prm{};
+  bool have_params = false;
+  int n_blocks = 1;
+  int kernel_path = 0;
+  // host copies needed for pattern queries
+  std::vector<long long> h_nadj_ptr;
+  std::vector<int32_t> h_nadj;
+  // owned device allocations
+  std::vector<void *> allocs;
+  int64_t device_bytes = 0;
+  // staging for host-pointer entry points
+  double *d_stage_vec[3] = {nullptr, nullptr, nullptr};
+  double *d_stage_res[2] = {nullptr, nullptr};
+  double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<pfm::HaloPeer> peers;
+  std::string err;
+
+  int64_t n_owned_dofs() const { return (int64_t)v.n_owned * (v.dim + 1); }
+  int64_t block_rows(int b) const;
+  int64_t block_nnz(int b) const;
+};

@@ -1,0 +1,871 @@
+// pfm_kernels.hip — gfx950 kernels of the assembly hot path, "general" family.
+//
+// General family = any Q1 quad/hex mesh (MappingQ1 geometry per quadrature point), any
+// constraint set (homogeneous lines + hanging nodes), optional 2-D stress split, optional
+// per-cell Lame coefficients.  It is the reference-faithful fallback; uniform Cartesian
+// meshes (all BASELINE configs) are served by the row-owner kernels in pfm_cart.hip.
+//
+// Work decomposition: one lane <-> (cell, test vertex a).  The lane integrates the
+// (dim+1) x dpc row block of the element matrix that belongs to vertex a
+// (cracks.cc:2308-2389, rows j = (a,*), all trial dofs i) and the (dim+1) residual
+// entries (cracks.cc:2393-2432), then scatters through the constraints
+// (cracks.cc:2439-2464) with hardware FP64 atomics.  A 256-thread workgroup covers
+// 256/2^dim cells; their nodal inputs are staged once in LDS (SoA over the cell index,
+// so the 2^dim lanes of a cell read one broadcast address and neighbouring cells hit
+// consecutive banks).
+#include "pfm_internal.h"
+
+#include <hip/hip_runtime.h>
+
+namespace pfm
+{
+  namespace
+  {
+    // ------------------------------------------------------------ reference element
+    // FE_Q(1) shape functions and QGauss(3) on [0,1]^dim, x fastest (cracks.cc:2156-2160).
+    struct RefTables
+    {
+      double N2[9][4], dN2[9][4][2], w2[9];
+      double N3[27][8], dN3[27][8][3], w3[27];
+    };
+    __constant__ RefTables c_ref;
+
+    RefTables make_ref_tables()
+    {
+      RefTables t{};
+      const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+      const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+      for (int dim = 2; dim <= 3; ++dim)
+        {
+          const int nq = dim == 2 ? 9 : 27, nv = 1 << dim;
+          for (int q = 0; q < nq; ++q)
+            {
+              const int qi[3] = {q % 3, (q / 3) % 3, q / 9};
+              double w = 1.0;
+              for (int d = 0; d < dim; ++d)
+                w *= gw[qi[d]];
+              for (int v = 0; v < nv; ++v)
+                {
+                  double val = 1.0, g[3] = {1.0, 1.0, 1.0};
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      const double x = gx[qi[d]];
+                      const double f = ((v >> d) & 1) ? x : 1.0 - x;
+                      const double df = ((v >> d) & 1) ? 1.0 : -1.0;
+                      val *= f;
+                      for (int e = 0; e < dim; ++e)
+                        g[e] *= (e == d) ? df : f;
+                    }
+                  if (dim == 2)
+                    {
+                      t.N2[q][v] = val;
+                      t.dN2[q][v][0] = g[0];
+                      t.dN2[q][v][1] = g[1];
+                    }
+                  else
+                    {
+                      t.N3[q][v] = val;
+                      for (int e = 0; e < 3; ++e)
+                        t.dN3[q][v][e] = g[e];
+                    }
+                }
+              if (dim == 2)
+                t.w2[q] = w;
+              else
+                t.w3[q] = w;
+            }
+        }
+      return t;
+    }
+
+    template <int dim>
+    __device__ __forceinline__ double refN(int q, int v)
+    {
+      if constexpr (dim == 2)
+        return c_ref.N2[q][v];
+      else
+        return c_ref.N3[q][v];
+    }
+    template <int dim>
+    __device__ __forceinline__ double refdN(int q, int v, int e)
+    {
+      if constexpr (dim == 2)
+        return c_ref.dN2[q][v][e];
+      else
+        return c_ref.dN3[q][v][e];
+    }
+    template <int dim>
+    __device__ __forceinline__ double refw(int q)
+    {
+      if constexpr (dim == 2)
+        return c_ref.w2[q];
+      else
+        return c_ref.w3[q];
+    }
+
+    struct Vals
+    {
+      double *b[4];
+    };
+
+    // ------------------------------------------------------------ CSR addressing
+    // Canonical pattern = node graph (x) component coupling, so the value index of
+    // (row node P, row comp c, neighbour slot s, col comp d) is arithmetic.
+    template <int dim>
+    __device__ __forceinline__ double *val_ptr(const DevView &v, const Vals &vals, int P, int c, int s, int d)
+    {
+      constexpr int nc = dim + 1;
+      const long long off = v.nadj_ptr[P];
+      const long long deg = v.nadj_ptr[P + 1] - off;
+      if (v.layout == PFM_LAYOUT_INTERLEAVED)
+        return vals.b[0] + (nc * nc * off + (long long)c * nc * deg + (long long)s * nc + d);
+      if (c < dim)
+        {
+          if (d < dim)
+            return vals.b[0] + (dim * dim * off + (long long)c * dim * deg + (long long)s * dim + d);
+          return vals.b[1] + (dim * off + (long long)c * deg + s);
+        }
+      if (d < dim)
+        return vals.b[2] + (dim * off + (long long)s * dim + d);
+      return vals.b[3] + (off + s);
+    }
+
+    template <int dim>
+    __device__ __forceinline__ long long dof_index(const DevView &v, int P, int c)
+    {
+      if (v.layout == PFM_LAYOUT_INTERLEAVED)
+        return (long long)P * (dim + 1) + c;
+      return c < dim ? (long long)P * dim + c : (long long)v.n_owned * dim + P;
+    }
+
+    __device__ __forceinline__ int find_slot(const DevView &v, int P, int Q)
+    {
+      long long lo = v.nadj_ptr[P], hi = v.nadj_ptr[P + 1];
+      const long long base = lo;
+      while (lo < hi)
+        {
+          const long long mid = (lo + hi) >> 1;
+          if (v.nadj[mid] < Q)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+      return (int)(lo - base);
+    }
+
+    __device__ __forceinline__ void atomic_add(double *p, double x)
+    {
+      unsafeAtomicAdd(p, x); // global_atomic_add_f64
+    }
+
+    // ------------------------------------------------------------ stress split (2-D)
+    // eigen_vectors_and_values (cracks.cc:1691-1737) on a symmetric 2x2 tensor.
+    // P = [v1 v2] (columns).  Returns false when the orthogonality check fails.
+    __device__ __forceinline__ bool eigen2(double m00, double m01, double m10, double m11, double &l1,
+                                           double &l2, double P[2][2])
+    {
+      double v1x, v1y, v2x, v2y;
+      if (fabs(m01) < 1e-10 * fabs(m00) || fabs(m01) < 1e-10 * fabs(m11))
+        {
+          l1 = m00;
+          v1x = 1;
+          v1y = 0;
+          l2 = m11;
+          v2x = 0;
+          v2y = 1;
+        }
+      else
+        {
+          const double sq = sqrt((m00 - m11) * (m00 - m11) + 4.0 * m01 * m10);
+          l1 = 0.5 * ((m00 + m11) + sq);
+          l2 = 0.5 * ((m00 + m11) - sq);
+          const double t1 = (l1 - m00) / m01, t2 = (l2 - m00) / m01;
+          const double s1 = sqrt(1 + t1 * (l1 - m00) / m01), s2 = sqrt(1 + t2 * (l2 - m00) / m01);
+          v1x = 1.0 / s1;
+          v1y = (l1 - m00) / (m01 * s1);
+          v2x = 1.0 / s2;
+          v2y = (l2 - m00) / (m01 * s2);
+        }
+      P[0][0] = v1x;
+      P[0][1] = v2x;
+      P[1][0] = v1y;
+      P[1][1] = v2y;
+      return !(v1x * v2x + v1y * v2y > 1.0e-6);
+    }
+
+    // decompose_stress(..., derivative=false), cracks.cc:1959-1970
+    __device__ __forceinline__ bool split_stress(const double E[2][2], double trE, double lam, double mu,
+                                                 double sp[2][2], double sm[2][2])
+    {
+      double l1, l2, P[2][2];
+      const bool ok = eigen2(E[0][0], E[0][1], E[1][0], E[1][1], l1, l2, P);
+      const double l1p = fmax(0.0, l1), l2p = fmax(0.0, l2);
+      const double trp = fmax(0.0, trE);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          {
+            // (P Lambda+ P^T)_ij
+            const double Ep = (P[i][0] * l1p) * P[j][0] + (P[i][1] * l2p) * P[j][1];
+            const double id = (i == j) ? 1.0 : 0.0;
+            sp[i][j] = lam * trp * id + 2 * mu * Ep;
+            sm[i][j] = lam * (trE - trp) * id + 2 * mu * (E[i][j] - Ep);
+          }
+      return ok;
+    }
+
+    // decompose_stress(..., derivative=true), cracks.cc:1976-2109
+    __device__ __forceinline__ bool split_stress_lin(const double E[2][2], double trE, const double EL[2][2],
+                                                     double trEL, double lam, double mu, double sp[2][2],
+                                                     double sm[2][2])
+    {
+      double l1, l2, P[2][2];
+      const bool ok = eigen2(E[0][0], E[0][1], E[1][0], E[1][1], l1, l2, P);
+      const double l1p = fmax(0.0, l1), l2p = fmax(0.0, l2);
+      const double E00 = E[0][0], E01 = E[0][1], E10 = E[1][0], E11 = E[1][1];
+
+      const double disk = sqrt(E01 * E10 + (E00 - E11) * (E00 - E11) / 4.0);
+      const double mix = EL[0][1] * E10 + E01 * EL[1][0] + (E00 - E11) * (EL[0][0] - EL[1][1]) / 2.0;
+      const double l1L = 0.5 * trEL + 1.0 / (2.0 * disk) * mix;
+      const double l2L = 0.5 * trEL - 1.0 / (2.0 * disk) * mix;
+
+      const double t1 = (l1 - E00) / E01, t2 = (l2 - E00) / E01;
+      const double q1 = 1.0 + t1 * (l1 - E00) / E01, q2 = 1.0 + t2 * (l2 - E00) / E01;
+      const double n1 = 1.0 / sqrt(q1), n2 = 1.0 / sqrt(q2);
+      // d/dU of (l - E00)/E01
+      const double dt1 = ((l1L - EL[0][0]) * E01 - (l1 - E00) * EL[0][1]) / (E01 * E01);
+      const double dt2 = ((l2L - EL[0][0]) * E01 - (l2 - E00) * EL[0][1]) / (E01 * E01);
+      const double n1L = -1.0 * (1.0 / q1 * 1.0 / (2.0 * sqrt(q1)) * (2.0 * t1) * dt1);
+      const double n2L = -1.0 * (1.0 / q2 * 1.0 / (2.0 * sqrt(q2)) * (2.0 * t2) * dt2);
+
+      double PL[2][2];
+      PL[0][0] = n1 * 0.0 + n1L * 1.0;
+      PL[1][0] = n1 * dt1 + n1L * (l1 - E00) / E01;
+      PL[0][1] = n2 * 0.0 + n2L * 1.0;
+      PL[1][1] = n2 * dt2 + n2L * (l2 - E00) / E01;
+
+      const double l1pL = (l1 < 0.0) ? 0.0 : l1L;
+      const double l2pL = (l2 < 0.0) ? 0.0 : l2L;
+      const double trpL = (trE < 0.0) ? 0.0 : trEL;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          {
+            const double a = (PL[i][0] * l1p) * P[j][0] + (PL[i][1] * l2p) * P[j][1];
+            const double b = (P[i][0] * l1pL) * P[j][0] + (P[i][1] * l2pL) * P[j][1];
+            const double c = (P[i][0] * l1p) * PL[j][0] + (P[i][1] * l2p) * PL[j][1];
+            const double EpL = a + b + c;
+            const double id = (i == j) ? 1.0 : 0.0;
+            sp[i][j] = lam * trpL * id + 2 * mu * EpL;
+            sm[i][j] = lam * (trEL - trpL) * id + 2 * mu * (EL[i][j] - EpL);
+          }
+      return ok;
+    }
+
+    // ------------------------------------------------------------ the cell kernel
+    template <int dim, bool FULL, bool SPLIT>
+    __global__ __launch_bounds__(256) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
+                                                              double *__restrict__ res_pde,
+                                                              double *__restrict__ res_tot,
+                                                              int residual_only)
+    {
+      constexpr int nv = 1 << dim, nc = dim + 1, nq = (dim == 2 ? 9 : 27), dpc = nv * nc;
+      constexpr int CPB = 256 / nv; // cells per workgroup
+      __shared__ double s_x[dim][nv][CPB];
+      __shared__ double s_u[dim][nv][CPB];
+      __shared__ double s_p[3][nv][CPB]; // phi, phi_old, phi_oldold
+
+      const int tid = threadIdx.x;
+      const int a = tid % nv, cl = tid / nv;
+      const long long cell = (long long)blockIdx.x * CPB + cl;
+      const bool active = cell < v.n_cells;
+      int A = 0;
+      if (active)
+        {
+          A = v.conn[(long long)a * v.n_cells + cell];
+#pragma unroll
+          for (int d = 0; d < dim; ++d)
+            {
+              s_x[d][a][cl] = v.coords[(long long)d * v.n_nodes + A];
+              s_u[d][a][cl] = v.u[d][A];
+            }
+          s_p[0][a][cl] = v.phi[A];
+          s_p[1][a][cl] = v.phi_old[A];
+          s_p[2][a][cl] = v.phi_oldold[A];
+        }
+      __syncthreads();
+      if (!active)
+        return;
+
+      double lam = prm.lambda, mu = prm.mu;
+      if (v.cell_lambda)
+        {
+          lam = v.cell_lambda[cell];
+          mu = v.cell_mu[cell];
+        }
+      double gamma_penal = prm.gamma_penal;
+      if (prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC && prm.timestep_number < 1)
+        gamma_penal = 0.0; // cracks.cc:2141-2144
+      const double kappa = prm.constant_k, eps = prm.alpha_eps, Gc = prm.G_c, p = prm.pressure;
+      const double aB1 = prm.alpha_biot - 1.0;
+      const double d_rhs = prm.decompose_stress_rhs, d_mat = prm.decompose_stress_matrix;
+      const bool monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
+      // time extrapolation factor of pf_extra, cracks.cc:2268-2269
+      const double tfac = (prm.time - (prm.time - prm.old_timestep - prm.old_old_timestep)) /
+                          (prm.time - prm.old_timestep - (prm.time - prm.old_timestep - prm.old_old_timestep));
+
+      // cell->diameter(): longest vertex-to-opposite-vertex diagonal (only used when gamma != 0)
+      double diam2 = 0.0;
+#pragma unroll
+      for (int vv = 0; vv < nv / 2; ++vv)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < dim; ++d)
+            {
+              const double t = s_x[d][vv][cl] - s_x[d][nv - 1 - vv][cl];
+              s += t * t;
+            }
+          diam2 = fmax(diam2, s);
+        }
+      const double penal_fac = gamma_penal / prm.timestep * 1.0 / diam2;
+
+      // accumulators: rows j = (a, c)
+      double R[nc];
+      double Kuu[FULL ? nv : 1][dim][dim]; // [b][c][d]   trial (b,d) -> row (a,c)
+      double Kpu[FULL ? nv : 1][dim];      // [b][d]      trial (b,d) -> row (a,phi)
+      double Kpp[FULL ? nv : 1];           // [b]         trial (b,phi) -> row (a,phi)
+#pragma unroll
+      for (int c = 0; c < nc; ++c)
+        R[c] = 0.0;
+      if constexpr (FULL)
+        {
+#pragma unroll
+          for (int b = 0; b < nv; ++b)
+            {
+              Kpp[b] = 0.0;
+#pragma unroll
+              for (int c = 0; c < dim; ++c)
+                {
+                  Kpu[b][c] = 0.0;
+#pragma unroll
+                  for (int d = 0; d < dim; ++d)
+                    Kuu[b][c][d] = 0.0;
+                }
+            }
+        }
+      bool ortho_ok = true;
+
+      for (int q = 0; q < nq; ++q)
+        {
+          // ---- fe_values.reinit at q: J, J^-1, JxW (MappingQ1)
+          double J[dim][dim];
+#pragma unroll
+          for (int i = 0; i < dim; ++i)
+#pragma unroll
+            for (int j = 0; j < dim; ++j)
+              J[i][j] = 0.0;
+#pragma unroll
+          for (int vv = 0; vv < nv; ++vv)
+#pragma unroll
+            for (int i = 0; i < dim; ++i)
+              {
+                const double xi = s_x[i][vv][cl];
+#pragma unroll
+                for (int j = 0; j < dim; ++j)
+                  J[i][j] += xi * refdN<dim>(q, vv, j);
+              }
+          double inv[dim][dim], det;
+          if constexpr (dim == 2)
+            {
+              det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+              const double id = 1.0 / det;
+              inv[0][0] = J[1][1] * id;
+              inv[0][1] = -J[0][1] * id;
+              inv[1][0] = -J[1][0] * id;
+              inv[1][1] = J[0][0] * id;
+            }
+          else
+            {
+              const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+              const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+              const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+              det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+              const double id = 1.0 / det;
+              inv[0][0] = c00 * id;
+              inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+              inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+              inv[1][0] = c01 * id;
+              inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+              inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+              inv[2][0] = c02 * id;
+              inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+              inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+            }
+          const double JxW = det * refw<dim>(q);
+
+          // ---- shape gradients at q and the Newton state (cracks.cc:2222-2232)
+          double gN[nv][dim];
+          double gu[dim][dim], gpf[dim], pf = 0.0, pfo = 0.0, pfoo = 0.0;
+#pragma unroll
+          for (int i = 0; i < dim; ++i)
+            {
+              gpf[i] = 0.0;
+#pragma unroll
+              for (int j = 0; j < dim; ++j)
+                gu[i][j] = 0.0;
+            }
+#pragma unroll
+          for (int vv = 0; vv < nv; ++vv)
+            {
+#pragma unroll
+              for (int d = 0; d < dim; ++d)
+                {
+                  double s = 0.0;
+#pragma unroll
+                  for (int e = 0; e < dim; ++e)
+                    s += inv[e][d] * refdN<dim>(q, vv, e);
+                  gN[vv][d] = s;
+                }
+              const double Nv = refN<dim>(q, vv);
+              const double ph = s_p[0][vv][cl];
+              pf += ph * Nv;
+              pfo += s_p[1][vv][cl] * Nv;
+              pfoo += s_p[2][vv][cl] * Nv;
+#pragma unroll
+              for (int d = 0; d < dim; ++d)
+                {
+                  gpf[d] += ph * gN[vv][d];
+#pragma unroll
+                  for (int c = 0; c < dim; ++c)
+                    gu[c][d] += s_u[c][vv][cl] * gN[vv][d];
+                }
+            }
+          // this lane's test vertex
+          double gNa[dim];
+#pragma unroll
+          for (int d = 0; d < dim; ++d)
+            {
+              double s = 0.0;
+#pragma unroll
+              for (int e = 0; e < dim; ++e)
+                s += inv[e][d] * refdN<dim>(q, a, e);
+              gNa[d] = s;
+            }
+          const double Na = refN<dim>(q, a);
+
+          // ---- q-point state, cracks.cc:2248-2306
+          if (monolithic)
+            {
+              pf = fmax(0.0, pf);
+              pfo = fmax(0.0, pfo);
+              pfoo = fmax(0.0, pfoo);
+            }
+          const double pf_minus_old_plus = fmax(0.0, pf - pfo);
+          double pfx = pfoo + tfac * (pfo - pfoo);
+          if (pfx <= 0.0)
+            pfx = 0.0;
+          if (pfx >= 1.0)
+            pfx = 1.0;
+          if (prm.use_old_timestep_pf)
+            pfx = pfo;
+          const double g = (1 - kappa) * pfx * pfx + kappa;
+
+          double E[dim][dim], trE = 0.0, divu = 0.0;
+#pragma unroll
+          for (int i = 0; i < dim; ++i)
+            {
+              divu += gu[i][i];
+#pragma unroll
+              for (int j = 0; j < dim; ++j)
+                E[i][j] = 0.5 * (gu[i][j] + gu[j][i]);
+              trE += E[i][i];
+            }
+          double sp[dim][dim], sm[dim][dim];
+          if constexpr (SPLIT)
+            {
+              ortho_ok &= split_stress(E, trE, lam, mu, sp, sm);
+            }
+          else
+            {
+#pragma unroll
+              for (int i = 0; i < dim; ++i)
+#pragma unroll
+                for (int j = 0; j < dim; ++j)
+                  {
+                    sp[i][j] = lam * trE * (i == j ? 1.0 : 0.0) + 2 * mu * E[i][j];
+                    sm[i][j] = 0.0;
+                  }
+            }
+          double spE = 0.0; // scalar_product(stress_term_plus, E)
+#pragma unroll
+          for (int i = 0; i < dim; ++i)
+#pragma unroll
+            for (int j = 0; j < dim; ++j)
+              spE += sp[i][j] * E[i][j];
+
+          // ---- Jacobian rows of vertex a, cracks.cc:2308-2389
+          if constexpr (FULL)
+            {
+#pragma unroll
+              for (int b = 0; b < nv; ++b)
+                {
+                  const double Nb = refN<dim>(q, b);
+                  // trial dofs i = (b, d), displacement
+#pragma unroll
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      // E_LinU = sym(e_d (x) grad N_b)
+                      double EL[dim][dim];
+#pragma unroll
+                      for (int i = 0; i < dim; ++i)
+#pragma unroll
+                        for (int j = 0; j < dim; ++j)
+                          EL[i][j] = 0.5 * ((i == d ? gN[b][j] : 0.0) + (j == d ? gN[b][i] : 0.0));
+                      const double trEL = gN[b][d]; // == divergence_u_LinU
+                      double spL[dim][dim], smL[dim][dim];
+                      if constexpr (SPLIT)
+                        {
+                          ortho_ok &= split_stress_lin(E, trE, EL, trEL, lam, mu, spL, smL);
+                        }
+                      else
+                        {
+#pragma unroll
+                          for (int i = 0; i < dim; ++i)
+#pragma unroll
+                            for (int j = 0; j < dim; ++j)
+                              {
+                                spL[i][j] = lam * trEL * (i == j ? 1.0 : 0.0) + 2 * mu * EL[i][j];
+                                smL[i][j] = 0.0;
+                              }
+                        }
+                      // rows (a, c), c < dim: scalar_product(sigma_LinU, e_c (x) grad N_a)
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        {
+                          double t = 0.0, tm = 0.0;
+#pragma unroll
+                          for (int k = 0; k < dim; ++k)
+                            {
+                              t += g * spL[c][k] * gNa[k];
+                              tm += smL[c][k] * gNa[k];
+                            }
+                          Kuu[b][c][d] += (t + d_mat * tm) * JxW;
+                        }
+                      // row (a, phi)
+                      double spLE = 0.0, spEL = 0.0;
+#pragma unroll
+                      for (int i = 0; i < dim; ++i)
+#pragma unroll
+                        for (int j = 0; j < dim; ++j)
+                          {
+                            spLE += spL[i][j] * E[i][j];
+                            spEL += sp[i][j] * EL[i][j];
+                          }
+                      Kpu[b][d] += ((1 - kappa) * (spLE + spEL) * pf * Na - 2.0 * aB1 * p * (pf * trEL) * Na) * JxW;
+                    }
+                  // trial dof i = (b, phi): rows (a, c<dim) get exactly 0 (cracks.cc:2333-2337)
+                  {
+                    const double pen_i = ((pf - pfo) < 0.0) ? 0.0 : Nb; // shadowed variable, cracks.cc:2311-2315
+                    double gg = 0.0;
+#pragma unroll
+                    for (int k = 0; k < dim; ++k)
+                      gg += gN[b][k] * gNa[k];
+                    Kpp[b] += penal_fac * pen_i * Na * JxW;
+                    Kpp[b] += ((1 - kappa) * spE * Nb * Na + Gc / eps * Nb * Na + Gc * eps * gg -
+                               2.0 * aB1 * p * (Nb * divu) * Na) *
+                              JxW;
+                  }
+                }
+            }
+
+          // ---- residual rows of vertex a, cracks.cc:2393-2432
+#pragma unroll
+          for (int c = 0; c < dim; ++c)
+            {
+              double t = 0.0, tm = 0.0;
+#pragma unroll
+              for (int k = 0; k < dim; ++k)
+                {
+                  t += g * sp[c][k] * gNa[k];
+                  tm += sm[c][k] * gNa[k];
+                }
+              R[c] -= (t + d_rhs * tm - aB1 * p * pfx * pfx * gNa[c]) * JxW;
+            }
+          {
+            double gg = 0.0;
+#pragma unroll
+            for (int k = 0; k < dim; ++k)
+              gg += gpf[k] * gNa[k];
+            R[dim] -= penal_fac * pf_minus_old_plus * Na * JxW;
+            R[dim] -= ((1.0 - kappa) * spE * pf * Na - Gc / eps * (1.0 - pf) * Na + Gc * eps * gg -
+                       2.0 * aB1 * p * pf * divu * Na) *
+                      JxW;
+          }
+        } // q
+
+      if (!ortho_ok)
+        atomicMax(v.status, (int)PFM_ERR_NOT_ORTHOGONAL);
+
+      // =============================== scatter through the constraints (cracks.cc:2439-2464)
+      const uint8_t *cs = v.cslot + (long long)cell * nv * nv;
+      const int kA = v.hn_index ? v.hn_index[A] : -1;
+      const long long rb = kA < 0 ? 0 : v.hn_ptr[kA];
+      const long long re = kA < 0 ? 1 : v.hn_ptr[kA + 1];
+
+      // residual
+      const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
+      for (long long r = rb; r < re; ++r)
+        {
+          const int P = kA < 0 ? A : v.hn_parents[r];
+          const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
+          if (P >= v.n_owned)
+            continue;
+          const unsigned fP = v.node_flags[P];
+#pragma unroll
+          for (int c = 0; c < nc; ++c)
+            {
+              const long long di = dof_index<dim>(v, P, c);
+              const bool con = (fP >> c) & 1u;
+              if (!con)
+                atomic_add(res_pde + di, wP * R[c]);
+              if (residual_only && (!con || !total_via_update))
+                atomic_add(res_tot + di, wP * R[c]);
+            }
+        }
+
+      if constexpr (FULL)
+        {
+          const unsigned fA = v.node_flags[A];
+          double diag[nc];
+          // matrix rows of vertex a
+#pragma unroll
+          for (int b = 0; b < nv; ++b)
+            {
+              const int B = v.conn[(long long)b * v.n_cells + cell];
+              if (b == a)
+                {
+#pragma unroll
+                  for (int c = 0; c < dim; ++c)
+                    diag[c] = fabs(Kuu[b][c][c]);
+                  diag[dim] = fabs(Kpp[b]);
+                }
+              const int kB = v.hn_index ? v.hn_index[B] : -1;
+              const long long cb = kB < 0 ? 0 : v.hn_ptr[kB];
+              const long long ce = kB < 0 ? 1 : v.hn_ptr[kB + 1];
+              for (long long r = rb; r < re; ++r)
+                {
+                  const int P = kA < 0 ? A : v.hn_parents[r];
+                  const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
+                  if (P >= v.n_owned)
+                    continue;
+                  const unsigned fP = v.node_flags[P];
+                  for (long long s = cb; s < ce; ++s)
+                    {
+                      const int Q = kB < 0 ? B : v.hn_parents[s];
+                      const double w = wP * (kB < 0 ? 1.0 : v.hn_weights[s]);
+                      const unsigned fQ = v.node_flags[Q];
+                      const int slot = (kA < 0 && kB < 0) ? (int)cs[a * nv + b] : find_slot(v, P, Q);
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        {
+                          if ((fP >> c) & 1u)
+                            continue;
+#pragma unroll
+                          for (int d = 0; d < dim; ++d)
+                            if (!((fQ >> d) & 1u))
+                              atomic_add(val_ptr<dim>(v, vals, P, c, slot, d), w * Kuu[b][c][d]);
+                        }
+                      if (!((fP >> dim) & 1u))
+                        {
+#pragma unroll
+                          for (int d = 0; d < dim; ++d)
+                            if (!((fQ >> d) & 1u))
+                              atomic_add(val_ptr<dim>(v, vals, P, dim, slot, d), w * Kpu[b][d]);
+                          if (!((fQ >> dim) & 1u))
+                            atomic_add(val_ptr<dim>(v, vals, P, dim, slot, dim), w * Kpp[b]);
+                        }
+                    }
+                }
+            }
+          // diagonal of constrained rows (deal.II distribute_local_to_global): |K_ii| or,
+          // when that is zero, the mean |diagonal| of the element matrix
+          double dsum = 0.0;
+#pragma unroll
+          for (int c = 0; c < nc; ++c)
+            dsum += diag[c];
+#pragma unroll
+          for (int m = 1; m < nv; m <<= 1)
+            dsum += __shfl_xor(dsum, m, nv);
+          const double avg = dsum / (double)dpc;
+          if (A < v.n_owned && (kA >= 0 || fA))
+            {
+              const int slot = (int)cs[a * nv + a];
+#pragma unroll
+              for (int c = 0; c < nc; ++c)
+                if (kA >= 0 || ((fA >> c) & 1u))
+                  atomic_add(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ small kernels
+    template <int dim>
+    __global__ void k_state_set(DevView v, const double *__restrict__ sol, const double *__restrict__ old,
+                                const double *__restrict__ oldold)
+    {
+      const int n = blockIdx.x * blockDim.x + threadIdx.x;
+      if (n >= v.n_owned)
+        return;
+#pragma unroll
+      for (int d = 0; d < dim; ++d)
+        v.u[d][n] = sol[dof_index<dim>(v, n, d)];
+      const long long dp = dof_index<dim>(v, n, dim);
+      v.phi[n] = sol[dp];
+      v.phi_old[n] = old[dp];
+      v.phi_oldold[n] = oldold[dp];
+    }
+
+    template <int dim>
+    __global__ void k_halo_pack(DevView v, const int32_t *__restrict__ nodes, long long n, double *__restrict__ buf)
+    {
+      const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (i >= n)
+        return;
+      const int node = nodes[i];
+      // field-major so both sides stay coalesced
+#pragma unroll
+      for (int d = 0; d < dim; ++d)
+        buf[d * n + i] = v.u[d][node];
+      buf[(dim + 0) * n + i] = v.phi[node];
+      buf[(dim + 1) * n + i] = v.phi_old[node];
+      buf[(dim + 2) * n + i] = v.phi_oldold[node];
+    }
+
+    template <int dim>
+    __global__ void k_halo_unpack(DevView v, const int32_t *__restrict__ nodes, long long n,
+                                  const double *__restrict__ buf)
+    {
+      const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (i >= n)
+        return;
+      const int node = nodes[i];
+#pragma unroll
+      for (int d = 0; d < dim; ++d)
+        v.u[d][node] = buf[d * n + i];
+      v.phi[node] = buf[(dim + 0) * n + i];
+      v.phi_old[node] = buf[(dim + 1) * n + i];
+      v.phi_oldold[node] = buf[(dim + 2) * n + i];
+    }
+
+    bool g_tables_ready[16] = {};
+
+    int ensure_tables()
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16 && g_tables_ready[dev])
+        return PFM_OK;
+      const RefTables t = make_ref_tables();
+      if (hipMemcpyToSymbol(HIP_SYMBOL(c_ref), &t, sizeof(t)) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16)
+        g_tables_ready[dev] = true;
+      return PFM_OK;
+    }
+
+    inline int check_launch() { return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP; }
+  } // namespace
+
+  int launch_state_set(const DevView &v, const double *sol, const double *old, const double *oldold,
+                       hipStream_t s)
+  {
+    if (v.n_owned == 0)
+      return PFM_OK;
+    const int bs = 256, nb = (v.n_owned + bs - 1) / bs;
+    if (v.dim == 2)
+      hipLaunchKernelGGL(k_state_set<2>, dim3(nb), dim3(bs), 0, s, v, sol, old, oldold);
+    else
+      hipLaunchKernelGGL(k_state_set<3>, dim3(nb), dim3(bs), 0, s, v, sol, old, oldold);
+    return check_launch();
+  }
+
+  int launch_halo_pack(const DevView &v, const int32_t *nodes, int64_t n, double *buf, hipStream_t s)
+  {
+    if (n == 0)
+      return PFM_OK;
+    const int bs = 256;
+    const unsigned nb = (unsigned)((n + bs - 1) / bs);
+    if (v.dim == 2)
+      hipLaunchKernelGGL(k_halo_pack<2>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
+    else
+      hipLaunchKernelGGL(k_halo_pack<3>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
+    return check_launch();
+  }
+
+  int launch_halo_unpack(const DevView &v, const int32_t *nodes, int64_t n, const double *buf, hipStream_t s)
+  {
+    if (n == 0)
+      return PFM_OK;
+    const int bs = 256;
+    const unsigned nb = (unsigned)((n + bs - 1) / bs);
+    if (v.dim == 2)
+      hipLaunchKernelGGL(k_halo_unpack<2>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
+    else
+      hipLaunchKernelGGL(k_halo_unpack<3>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
+    return check_launch();
+  }
+
+  int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
+                              double *const *d_values, double *res_pde, double *res_tot, hipStream_t s)
+  {
+    int rc = ensure_tables();
+    if (rc)
+      return rc;
+    if (v.n_cells == 0)
+      return PFM_OK;
+    Vals vals{};
+    if (!residual_only)
+      for (int b = 0; b < (v.layout == PFM_LAYOUT_BLOCKED ? 4 : 1); ++b)
+        vals.b[b] = d_values[b];
+    const bool split = (p.decompose_stress_matrix > 0 && p.timestep_number > 0);
+    // The reference gates the split on decompose_stress_matrix only (cracks.cc:2294); a
+    // non-zero decompose_stress_rhs without it multiplies a zero stress_term_minus.
+    const int nv = 1 << v.dim, cpb = 256 / nv;
+    const unsigned nb = (unsigned)((v.n_cells + cpb - 1) / cpb);
+    const dim3 grid(nb), block(256);
+#define PFM_LAUNCH(DIM, FULLV, SPLITV) \
+  hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV>), grid, block, 0, s, v, p, vals, res_pde, res_tot, residual_only)
+    if (v.dim == 2)
+      {
+        if (residual_only)
+          {
+            if (split)
+              PFM_LAUNCH(2, false, true);
+            else
+              PFM_LAUNCH(2, false, false);
+          }
+        else
+          {
+            if (split)
+              PFM_LAUNCH(2, true, true);
+            else
+              PFM_LAUNCH(2, true, false);
+          }
+      }
+    else
+      {
+        if (split)
+          return PFM_ERR_UNSUPPORTED;
+        if (residual_only)
+          PFM_LAUNCH(3, false, false);
+        else
+          PFM_LAUNCH(3, true, false);
+      }
+#undef PFM_LAUNCH
+    return check_launch();
+  }
+} // namespace pfm

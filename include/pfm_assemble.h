@@ -1,0 +1,165 @@
+/* pfm_assemble.h — C ABI of the MI355X-native Newton residual/Jacobian assembly.
+ *
+ * Drop-in boundary for ONE path of tjhei/cracks:
+ *   FracturePhaseFieldProblem<dim>::assemble_system(bool residual_only)   cracks.cc:2129-2498
+ *   FracturePhaseFieldProblem<dim>::assemble_nl_residual()                cracks.cc:2507-2512
+ * The reference has no plugin/FFI interface for it (assemble_system is a private member,
+ * cracks.cc:1039-1040); this header defines the interface a deal.II glue shim binds
+ * (INTEGRATION.md).  Semantics = cracks.cc:2133-2475 minus deal.II object handling:
+ * zero the outputs, import ghost values, integrate every cell, scatter through the
+ * constraints, reduce.  The AMG set-up at cracks.cc:2477-2497 stays with the caller.
+ *
+ * Plain C, POD only.  Every entry point returns a pfm_status (0 = ok) and never
+ * aborts/exits/throws (the reference's abort() at cracks.cc:1735 becomes
+ * PFM_ERR_NOT_ORTHOGONAL).  A context is not re-entrant; different contexts are
+ * independent.  One context <-> one GPU <-> one reference MPI rank (cracks.cc:4587).
+ *
+ * Index spaces.  Nodes are numbered per rank: owned nodes [0,n_owned) first, ghost
+ * nodes [n_owned,n_nodes) after (the "locally relevant" numbering of cracks.cc:1622-1628).
+ * Local dof i of a cell <-> (vertex i/(dim+1), component i%(dim+1)); components
+ * 0..dim-1 = displacement, dim = phase field (cracks.cc:980-996).
+ *
+ * Dof vectors (solution / residual) hold OWNED dofs only, in one of the reference's two
+ * numberings (cracks.cc:1587-1590):
+ *   PFM_LAYOUT_INTERLEAVED  one block,  dof = node*(dim+1)+comp      (direct solver)
+ *   PFM_LAYOUT_BLOCKED      [u | phi],  u dof = node*dim+comp, phi dof = n_owned*dim+node
+ * Matrix values are CSR, rows = owned dofs, sorted columns in the rank-local numbering
+ * (ghost columns included), full component coupling (cracks.cc:1644-1654):
+ *   INTERLEAVED: block 0 only;   BLOCKED: 0 = (u,u), 1 = (u,phi), 2 = (phi,u), 3 = (phi,phi)
+ * The pattern is the node graph of the constraint-resolved mesh tensor the component
+ * coupling; pfm_pattern_get() returns it so the caller can check it against (or build)
+ * its Trilinos pattern.
+ */
+#ifndef PFM_ASSEMBLE_H
+#define PFM_ASSEMBLE_H
+
+#include <stdint.h>
+#include "pfm_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pfm_status
+{
+  PFM_OK = 0,
+  PFM_ERR_BAD_ARG = 1,
+  PFM_ERR_HIP = 2,            /* a HIP runtime call failed; pfm_last_error() has the text */
+  PFM_ERR_NOT_ORTHOGONAL = 3, /* eigenvector sanity check failed (reference abort(), cracks.cc:1732-1736) */
+  PFM_ERR_NONFINITE = 4,      /* non-finite value in an output (only checked on request) */
+  PFM_ERR_UNSUPPORTED = 5,    /* e.g. stress split in 3-D (reference is 2-D only, cracks.cc:1685-1690) */
+  PFM_ERR_NOMEM = 6
+} pfm_status;
+
+enum
+{
+  PFM_LAYOUT_INTERLEAVED = 0,
+  PFM_LAYOUT_BLOCKED = 1
+};
+
+/* per-dof constraint flag bits, one byte per NODE, bit c = component c */
+enum
+{
+  PFM_NODE_ALLCOMP_MASK = 0x0f
+};
+
+typedef struct pfm_ctx pfm_ctx;
+
+/* Static description of the rank-local mesh; everything is copied. Replaces the
+ * DoFHandler / FEValues / Triangulation inputs of cracks.cc:2156-2203. */
+typedef struct pfm_mesh_desc
+{
+  int32_t dim;               /* 2 or 3 */
+  int32_t layout;            /* PFM_LAYOUT_* */
+  int32_t n_nodes;           /* owned + ghost */
+  int32_t n_owned_nodes;
+  int64_t n_cells;           /* all local cells whose contributions reach an owned row:
+                                owned cells + one ghost layer ("owner computes") */
+  const int32_t *cell_nodes; /* [n_cells][2^dim], deal.II vertex order */
+  const double *coords;      /* [n_nodes][dim] */
+  const double *cell_lambda; /* [n_cells] or NULL: per-cell Lame override (cracks.cc:2207-2216) */
+  const double *cell_mu;
+  /* closed hanging-node table (constraints_hanging_nodes, cracks.cc:1630-1635), node level:
+   * node hn_nodes[k] = sum_j hn_weights[j]*parent hn_parents[j], j in [hn_ptr[k],hn_ptr[k+1]) */
+  int32_t n_hanging;
+  const int32_t *hn_nodes;
+  const int64_t *hn_ptr;
+  const int32_t *hn_parents;
+  const double *hn_weights;
+  /* structured fast path hint: cells form an nx*ny(*nz) box in lexicographic order with
+   * lexicographic node numbering (all zero = unknown; the library verifies the claim). */
+  int32_t box_cells[3];
+} pfm_mesh_desc;
+
+/* -- life cycle ---------------------------------------------------------------------- */
+/* Build a context on HIP device `device`.  Must be rebuilt after every setup_system()
+ * (cracks.cc:4148, 4174). */
+int pfm_ctx_create(pfm_ctx **out, const pfm_mesh_desc *mesh, int device);
+int pfm_ctx_destroy(pfm_ctx *ctx);
+const char *pfm_last_error(const pfm_ctx *ctx);
+/* all launches/copies go to this hipStream_t (default: the null stream) */
+int pfm_ctx_set_stream(pfm_ctx *ctx, void *hip_stream);
+
+/* -- inputs set elsewhere but consumed by assemble_system -------- */
+int pfm_set_params(pfm_ctx *ctx, const pfm_params *prm);
+/* constraints_update minus the hanging nodes: one byte per local node, bit c set <=> dof
+ * (node, c) has a homogeneous line (Dirichlet from set_newton_bc cracks.cc:2711-2714, or
+ * active set cracks.cc:2878-2879).  Call whenever constraints_update is rebuilt. */
+int pfm_set_constraints(pfm_ctx *ctx, const uint8_t *node_flags /* host, [n_nodes] */);
+
+/* -- matrix pattern ------------------------------------------------------------------- */
+int pfm_pattern_size(const pfm_ctx *ctx, int block, int64_t *n_rows, int64_t *nnz);
+/* host outputs: rowptr[n_rows+1], colind[nnz] */
+int pfm_pattern_get(const pfm_ctx *ctx, int block, int64_t *rowptr, int32_t *colind);
+
+/* -- state: the three vectors read at cracks.cc:2147-2154 ----------------------------- */
+/* Scatter the OWNED dofs of solution / old_solution / old_old_solution (dof vectors in the
+ * context's layout; host pointers if on_device == 0, device pointers otherwise) into the
+ * context's node arrays.  Only the phase-field block of old / old_old is read
+ * (cracks.cc:2229, 2232). */
+int pfm_state_set(pfm_ctx *ctx, const double *sol, const double *old, const double *oldold,
+                  int on_device);
+/* Ghost import (cracks.cc:2147-2154) as pack -> RCCL send/recv -> unpack; the exchange itself is
+ * done by the host side between the two calls.  Registration copies the lists.
+ * send_nodes: owned nodes whose values a peer needs; recv_nodes: ghost nodes a peer owns.
+ * A packed node record is PFM_HALO_DOUBLES_PER_NODE(dim) doubles: u[dim], phi, phi_old, phi_oldold. */
+#define PFM_HALO_DOUBLES_PER_NODE(dim) ((dim) + 3)
+int pfm_halo_register(pfm_ctx *ctx, int n_peers, const int64_t *send_ptr, const int32_t *send_nodes,
+                      const int64_t *recv_ptr, const int32_t *recv_nodes);
+int pfm_halo_pack(pfm_ctx *ctx, int peer, double *d_buf);         /* device buffer */
+int pfm_halo_unpack(pfm_ctx *ctx, int peer, const double *d_buf); /* device buffer */
+
+/* -- the hot path --------------------------------------------------------------------- */
+/* assemble_system(residual_only) on the current state.  Output pointers are DEVICE
+ * pointers; the call is asynchronous on the context's stream.
+ *   residual_only != 0: residual_pde (through constraints_update) and residual_total
+ *     (through constraints_hanging_nodes for the active-set solver, constraints_update
+ *     otherwise; cracks.cc:2440-2456) are zeroed and assembled; values is ignored.
+ *   residual_only == 0: values[block] and residual_pde are zeroed and assembled
+ *     (cracks.cc:2457-2464); residual_total is ignored.
+ * Rows of ghost nodes are never written: each rank computes its owned rows completely
+ * (it also integrates its ghost-layer cells), so no reverse exchange (compress(add),
+ * cracks.cc:2470-2475) is needed. */
+int pfm_assemble_device(pfm_ctx *ctx, int residual_only, double *const *d_values /* [n_blocks] */,
+                        double *d_residual_pde, double *d_residual_total);
+/* Blocks until the stream is idle and returns the deferred status of the launches since
+ * the last call (PFM_ERR_NOT_ORTHOGONAL, PFM_ERR_HIP, ...). */
+int pfm_sync_status(pfm_ctx *ctx);
+
+/* Synchronous host-pointer convenience = pfm_state_set + pfm_assemble_device + copies back
+ * + pfm_sync_status: the exact call shape of the reference (outputs complete in host memory
+ * on return, cracks.cc:2791-2794, 2918).  Single-rank only (no ghosts). */
+int pfm_assemble(pfm_ctx *ctx, const double *sol, const double *old, const double *oldold,
+                 int residual_only, double *const *values, double *residual_pde,
+                 double *residual_total);
+
+/* -- introspection -------------------------------------------------------------------- */
+/* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian */
+int pfm_ctx_kernel_path(const pfm_ctx *ctx);
+int pfm_ctx_force_path(pfm_ctx *ctx, int path);
+int64_t pfm_ctx_device_bytes(const pfm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
