@@ -73,6 +73,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         from . import build
         build.build_native()
+    # PyTorch wheels bundle their own HIP runtime (same SONAME as /opt/rocm's).  Import torch
+    # first so that exactly one runtime lives in the process and torch's device pointers /
+    # streams are valid for our launches; a pure C/C++ host just uses the system ROCm.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.pfm_ctx_create.argtypes = [C.POINTER(vp), C.POINTER(PfmMeshDesc), i32]
