@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — assembled DoFs/s of the Newton Jacobian+residual assembly (BASELINE.json metric).
+
+One "step" = one ``assemble_system()`` (cracks.cc:2133-2475: zero outputs, ghost import,
+cell integration, constrained scatter) on a synthetic uniformly refined 3-D Sneddon mesh
+(BASELINE.json configs[2]: ~1e7 hexes, Q1/Q1, full Jacobian + residual into the 2x2 block
+CSR).  Inputs are resident in HBM when the timed region starts; outputs stay on the device.
+
+  python bench.py                       # N=1, 216^3 cells
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N   # strong scaling: the same mesh cut into N sub-boxes,
+                                             # ghost values exchanged over RCCL (cracks_amd/halo.py)
+
+Prints ONE JSON line on rank 0 (contract in the task description) with the extra objects
+"roofline" (dominant kernel, HIP-event timed, algorithmic bytes of SURVEY.md §8(d)) and
+"cpu_baseline" (the CPU oracle = loop-for-loop port of the reference, timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
+    """Unique-touch model of SURVEY.md §8(d): every global datum read once, every output
+    written once, ~1 node per cell."""
+    if dim == 3:
+        return 168.0 if residual_only else 3592.0
+    return 120.0 if residual_only else 744.0
+
+
+def sneddon_params(h: float, dim: int):
+    from cracks_amd.capi import PfmParams
+
+    E, nu = 1.0, 0.2
+    mu = E / (2.0 * (1 + nu))
+    lam = (2 * nu * mu) / (1.0 - 2 * nu)
+    kappa = 1.0e-8 * h if dim == 2 else 0.0  # parameters_sneddon_2d.prm / _3d.prm
+    return PfmParams(lambda_=lam, mu=mu, G_c=1.0, alpha_eps=2.0 * h, constant_k=kappa, pressure=1.0e-3,
+                     alpha_biot=0.0, gamma_penal=0.0, timestep=1.0, time=1.0, old_timestep=1.0,
+                     old_old_timestep=1.0, decompose_stress_rhs=0.0, decompose_stress_matrix=0.0,
+                     timestep_number=0, outer_solver=0, use_old_timestep_pf=0, reserved=0)
+
+
+def synthetic_state(mesh, global_ids, h, dim, seed=1234):
+    """Interpolated InitialValuesSneddon + seeded perturbation; values are a
+    function of the global node id so that every rank count sees the same field."""
+    from cracks_amd.mesh import initial_values_sneddon
+
+    def noise(salt, lo, hi):
+        x = (global_ids.astype(np.uint64) + np.uint64(seed + 7919 * salt)) * np.uint64(0x9E3779B97F4A7C15)
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(32)
+        return lo + (hi - lo) * (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+    phi0 = initial_values_sneddon(mesh, h)
+    u = np.stack([noise(d, -1e-3, 1e-3) for d in range(dim)], axis=1)
+    on_boundary = np.zeros(mesh.n_nodes, bool)
+    for nodes in mesh.boundary_nodes.values():
+        on_boundary[nodes] = True
+    u[on_boundary] = 0.0
+    phi = np.clip(phi0 + noise(10, -0.2, 0.2), 0.0, 1.0)
+    phi_old = np.clip(phi0 + noise(11, -0.2, 0.2), 0.0, 1.0)
+    phi_oldold = np.clip(phi0 + noise(12, -0.2, 0.2), 0.0, 1.0)
+    flags = np.where(on_boundary, (1 << dim) - 1, 0).astype(np.uint8)  # u = 0 on the boundary (cracks.cc:2686-2694)
+    return u, phi, phi_old, phi_oldold, flags
+
+
+def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
+    """Time the CPU oracle (port of cracks.cc:2200-2467) on a bounded sample of the same
+    workload, one thread = one reference MPI rank (cracks.cc:4587)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    from cracks_amd import mesh as M
+
+    n = 20 if dim == 3 else 160
+    if residual_only and dim == 3:
+        n = 40
+    mesh = M.box_mesh(dim, n)
+    h = mesh.min_cell_diameter()
+    lay = M.DofLayout(mesh.n_nodes, dim, blocked=True)
+    u, phi, po, poo, flags = synthetic_state(mesh, np.arange(mesh.n_nodes), h, dim)
+    sol = lay.pack(u, phi)
+    old = lay.pack(np.zeros_like(u), po)
+    oo = lay.pack(np.zeros_like(u), poo)
+    dd = M.sneddon_dirichlet_dofs(mesh, lay)
+    cu = M.update_constraints(mesh, lay, dd)
+    ch = M.hanging_constraints(mesh, lay)
+    prm = O.PfmParams.from_buffer_copy(bytes(sneddon_params(h, dim)))
+    rowptr = colind = None
+    if not residual_only:
+        rowptr, colind = M.dof_sparsity(mesh, lay)
+    O.assemble(mesh, lay, prm, sol, old, oo, cu, ch, residual_only, rowptr, colind)  # warm
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < target_seconds and len(times) < 50):
+        t0 = time.perf_counter()
+        r = O.assemble(mesh, lay, prm, sol, old, oo, cu, ch, residual_only, rowptr, colind)
+        times.append(time.perf_counter() - t0)
+        assert r.err == 0
+    t = float(np.median(times))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": lay.n_dofs / t, "unit": "DoFs/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^{dim} cells ({lay.n_dofs} DoFs), median of {len(times)} assemblies, "
+                      f"g++ -O3 -march=native, 1 thread of {os.cpu_count()} ({model}); excludes Trilinos "
+                      f"insertion overhead the real reference pays"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--n", type=int, default=0, help="cells per direction (default 216 in 3-D, 1000 in 2-D)")
+    ap.add_argument("--residual-only", action="store_true")
+    ap.add_argument("--path", choices=["auto", "general", "cart"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare a small instance with the oracle first")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler
+    from cracks_amd.halo import HaloExchange
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dim = args.dim
+    n = args.n or (216 if dim == 3 else 1000)
+    ncell = (n,) * dim
+    p = P.factor_ranks(world, dim)
+    t0 = time.perf_counter()
+    lp = P.build_local_problem(dim, ncell, p, rank)
+    h = (20.0 / n) * np.sqrt(dim)
+    u, phi, po, poo, flags = synthetic_state(lp.mesh, lp.global_ids, h, dim)
+    if world == 1:
+        lp.mesh.box_shape = ncell
+    halo = None
+    if world > 1:
+        halo = HaloExchange(dim, lp.peers, lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes, dev)
+    asm = Assembler(lp.mesh, blocked=True, device=local_rank, n_owned_nodes=lp.n_owned, halo=halo)
+    if args.path == "general":
+        asm.ctx.force_path(0)
+    elif args.path == "cart":
+        asm.ctx.force_path(1)
+    asm.set_params(sneddon_params(h, dim))
+    asm.set_constraints(flags)
+    no = lp.n_owned
+    # owned dof vectors, blocked layout [u | phi]
+    def pack(uu, pp):
+        v = np.empty(no * (dim + 1))
+        v[:no * dim] = uu[:no].reshape(-1)
+        v[no * dim:] = pp[:no]
+        return v
+    asm.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
+    t_setup = time.perf_counter() - t0
+    residual_only = args.residual_only
+
+    def step():
+        asm.assemble_system(residual_only)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    asm.synchronize()
+    asm.ctx.timing_enable(True)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t1
+    asm.synchronize()
+    k_ms, k_n = asm.ctx.kernel_time_ms()
+    asm.ctx.timing_enable(False)
+
+    tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, k_ms = float(tt[0]), float(tt[1])
+    n_nodes_global = int(np.prod([k + 1 for k in ncell]))
+    n_cells_global = int(np.prod(ncell))
+    n_dofs = n_nodes_global * (dim + 1)
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        abytes = algorithmic_bytes_per_cell(dim, residual_only) * lp.mesh.n_cells  # this rank's launch
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "assembled DoFs/sec (residual+Jacobian) on 3D Sneddon" if (dim == 3 and not residual_only)
+            else f"assembled DoFs/sec ({'residual-only' if residual_only else 'residual+Jacobian'}) on {dim}D Sneddon",
+            "value": n_dofs / (elapsed / args.steps),
+            "unit": "DoFs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (uniform hex mesh on [-10,10]^d, interpolated Sneddon crack + seeded perturbation)",
+            "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
+                                   f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (108 nnz/row-node-comp)'}",
+                       "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
+                       "setup_s": round(t_setup, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "launches": k_n,
+                         "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dim, residual_only)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,6 +175,14 @@ class Context:
         self._check(rc, "pfm_assemble")
         return values, res_pde, res_tot
 
+    def timing_enable(self, on: bool = True):
+        self._check(self.lib.pfm_timing_enable(self._h, 1 if on else 0), "pfm_timing_enable")
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.lib.pfm_kernel_time_ms(self._h, C.byref(ms), C.byref(n)), "pfm_kernel_time_ms")
+        return ms.value, n.value
+
     @property
     def kernel_path(self) -> int:
         return self.lib.pfm_ctx_kernel_path(self._h)

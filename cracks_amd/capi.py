@@ -24,7 +24,7 @@ EXPORTS = [
     "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_state_set",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_assemble_device",
     "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path",
-    "pfm_ctx_device_bytes",
+    "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms",
 ]
 
 
@@ -100,6 +100,8 @@ def load():
     lib.pfm_assemble.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     lib.pfm_ctx_kernel_path.argtypes = [vp]
     lib.pfm_ctx_force_path.argtypes = [vp, i32]
+    lib.pfm_timing_enable.argtypes = [vp, i32]
+    lib.pfm_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.pfm_ctx_device_bytes.argtypes = [vp]
     lib.pfm_ctx_device_bytes.restype = i64
     _LIB = lib

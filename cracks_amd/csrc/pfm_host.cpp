@@ -294,6 +294,11 @@ extern "C"
         if (p.d_recv)
           hipFree(p.d_recv);
       }
+    for (auto &ev : c->ev_pool)
+      {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+      }
     for (double *p : c->d_stage_vec)
       if (p)
         hipFree(p);
@@ -499,7 +504,24 @@ extern "C"
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->timing)
+      {
+        if (c->ev_used == c->ev_pool.size())
+          {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+              return fail(c, PFM_ERR_HIP, "hipEventCreate");
+            c->ev_pool.emplace_back(a, b);
+          }
+        ev0 = c->ev_pool[c->ev_used].first;
+        ev1 = c->ev_pool[c->ev_used].second;
+        ++c->ev_used;
+        hipEventRecord(ev0, c->stream);
+      }
     int rc = launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+    if (ev1)
+      hipEventRecord(ev1, c->stream);
     if (rc)
       return fail(c, rc, "assemble launch failed");
     return PFM_OK;
@@ -569,6 +591,39 @@ extern "C"
     if (e != hipSuccess)
       return hipfail(c, e, "copy back");
     return pfm_sync_status(c);
+  }
+
+  int pfm_timing_enable(pfm_ctx *c, int on)
+  {
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    c->timing = on != 0;
+    c->ev_used = 0;
+    return PFM_OK;
+  }
+
+  int pfm_kernel_time_ms(pfm_ctx *c, double *mean_ms, int *n_launches)
+  {
+    if (!c || !mean_ms)
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+      return hipfail(c, e, "kernel_time sync");
+    double sum = 0.0;
+    for (size_t k = 0; k < c->ev_used; ++k)
+      {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second);
+        if (e != hipSuccess)
+          return hipfail(c, e, "hipEventElapsedTime");
+        sum += ms;
+      }
+    *mean_ms = c->ev_used ? sum / (double)c->ev_used : 0.0;
+    if (n_launches)
+      *n_launches = (int)c->ev_used;
+    c->ev_used = 0;
+    return PFM_OK;
   }
 
   int pfm_ctx_kernel_path(const pfm_ctx *c) { return c ? c->kernel_path : -1; }

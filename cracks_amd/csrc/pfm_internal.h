@@ -70,6 +70,10 @@ struct pfm_ctx
   double *d_stage_res[2] = {nullptr, nullptr};
   double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<pfm::HaloPeer> peers;
+  // measurement (pfm_timing_enable)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
   std::string err;
 
   int64_t n_owned_dofs() const { return (int64_t)v.n_owned * (v.dim + 1); }

@@ -1,0 +1,209 @@
+"""Owner-computes partition of a uniform box mesh over the GPUs of a node.
+
+Stand-in for the p4est partition the reference runs on (``parallel::distributed::
+Triangulation``, cracks.cc:1083; cells with ``cell->is_locally_owned()``, cracks.cc:2201):
+the global ``n[0] x n[1](x n[2])`` cell box is cut into ``p[0] x p[1](x p[2])`` sub-boxes,
+rank ``r = ix + p0*(iy + p1*iz)``.
+
+* A node belongs to the lowest rank whose sub-box touches it (deal.II's convention), i.e.
+  a rank owns the nodes of its sub-box except those on a low face it shares with a
+  lower-indexed neighbour.
+* Owner computes: a rank also integrates the one layer of cells on its high faces so that
+  every owned row is complete locally; the reverse exchange ``compress(add)``
+  (cracks.cc:2470-2475) disappears and the only communication is the ghost-value import
+  (cracks.cc:2147-2154), done as pairwise RCCL send/recv (cracks_amd/halo.py).
+* Local numbering: owned nodes first (ascending global id), then ghost nodes (ascending
+  global id).  Results are independent of the number of ranks up to the summation order
+  inside one row, which is fixed by the local cell order.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from .mesh import Mesh
+
+
+def factor_ranks(world: int, dim: int) -> Tuple[int, ...]:
+    """Near-cubic factorisation of the rank count (8 -> 2x2x2, 4 -> 2x2x1, 2 -> 2x1x1)."""
+    p = [1] * dim
+    w = world
+    d = 0
+    f = 2
+    while w > 1:
+        while w % f:
+            f += 1
+        p[d % dim] *= f
+        w //= f
+        d += 1
+    return tuple(p)
+
+
+def _split(n: int, p: int, i: int) -> Tuple[int, int]:
+    base, rem = divmod(n, p)
+    lo = i * base + min(i, rem)
+    return lo, lo + base + (1 if i < rem else 0)
+
+
+@dataclass
+class LocalBox:
+    rank: int
+    dim: int
+    n_global: Tuple[int, ...]  # global cells per axis
+    cells_lo: Tuple[int, ...]  # extended local cell box [lo, hi)
+    cells_hi: Tuple[int, ...]
+    own_lo: Tuple[int, ...]  # owned node index range [lo, hi] inclusive, global node indices
+    own_hi: Tuple[int, ...]
+    node_lo: Tuple[int, ...]  # local node box [lo, hi] inclusive
+    node_hi: Tuple[int, ...]
+
+    def node_ids(self) -> np.ndarray:
+        """Global ids (lexicographic) of the local node box, lexicographic order."""
+        npg = [k + 1 for k in self.n_global]
+        ax = [np.arange(self.node_lo[d], self.node_hi[d] + 1) for d in range(self.dim)]
+        if self.dim == 2:
+            return (ax[0][None, :] + npg[0] * ax[1][:, None]).ravel()
+        return (ax[0][None, None, :] + npg[0] * (ax[1][None, :, None] + npg[1] * ax[2][:, None, None])).ravel()
+
+    def owned_mask(self) -> np.ndarray:
+        ax = [np.arange(self.node_lo[d], self.node_hi[d] + 1) for d in range(self.dim)]
+        m = [(ax[d] >= self.own_lo[d]) & (ax[d] <= self.own_hi[d]) for d in range(self.dim)]
+        if self.dim == 2:
+            return (m[0][None, :] & m[1][:, None]).ravel()
+        return (m[0][None, None, :] & m[1][None, :, None] & m[2][:, None, None]).ravel()
+
+
+def local_box(n: Sequence[int], p: Sequence[int], rank: int) -> LocalBox:
+    dim = len(n)
+    idx = []
+    r = rank
+    for d in range(dim):
+        idx.append(r % p[d])
+        r //= p[d]
+    clo, chi, olo, ohi, nlo, nhi = [], [], [], [], [], []
+    for d in range(dim):
+        c0, c1 = _split(n[d], p[d], idx[d])
+        eh = 1 if c1 < n[d] else 0  # ghost cell layer on the high side
+        el = 1 if c0 > 0 else 0  # low plane belongs to the lower neighbour
+        clo.append(c0)
+        chi.append(c1 + eh)
+        olo.append(c0 + el)
+        ohi.append(c1)
+        nlo.append(c0)
+        nhi.append(c1 + eh)
+    return LocalBox(rank, dim, tuple(n), tuple(clo), tuple(chi), tuple(olo), tuple(ohi), tuple(nlo), tuple(nhi))
+
+
+def owner_of_nodes(n: Sequence[int], p: Sequence[int], gid: np.ndarray) -> np.ndarray:
+    """Rank owning each global node id."""
+    dim = len(n)
+    npg = [k + 1 for k in n]
+    rem = gid.copy()
+    rank = np.zeros(gid.shape, np.int64)
+    mult = 1
+    for d in range(dim):
+        i = rem % npg[d]
+        rem //= npg[d]
+        # node i belongs to the box whose (lo, hi] contains it; node 0 to box 0
+        bounds = np.array([_split(n[d], p[d], k)[1] for k in range(p[d])])
+        box = np.searchsorted(bounds, i, side="left")
+        box = np.minimum(box, p[d] - 1)
+        rank += mult * box
+        mult *= p[d]
+    return rank
+
+
+@dataclass
+class LocalProblem:
+    mesh: Mesh  # rank-local mesh, local node numbering (owned first)
+    n_owned: int
+    global_ids: np.ndarray  # [n_local_nodes] global node id of each local node
+    peers: List[int]
+    send_ptr: np.ndarray
+    send_nodes: np.ndarray  # local (owned) node indices, grouped by peer, ascending global id
+    recv_ptr: np.ndarray
+    recv_nodes: np.ndarray  # local (ghost) node indices
+    box: LocalBox
+
+
+def build_local_problem(dim: int, n: Sequence[int], p: Sequence[int], rank: int, lo=-10.0, hi=10.0) -> LocalProblem:
+    """Rank-local mesh + halo lists, built without ever forming the global mesh."""
+    n = tuple(int(k) for k in n)
+    p = tuple(int(k) for k in p)
+    world = int(np.prod(p))
+    box = local_box(n, p, rank)
+    lo = np.broadcast_to(np.asarray(lo, float), (dim,))
+    hi = np.broadcast_to(np.asarray(hi, float), (dim,))
+    gid = box.node_ids()
+    owned = box.owned_mask()
+    order = np.concatenate([np.nonzero(owned)[0], np.nonzero(~owned)[0]])  # box index -> local id order
+    local_of_box = np.empty(gid.size, np.int64)
+    local_of_box[order] = np.arange(gid.size)
+    global_ids = gid[order]
+    n_owned = int(owned.sum())
+    # coordinates
+    npg = [k + 1 for k in n]
+    rem = global_ids.copy()
+    coords = np.empty((gid.size, dim))
+    for d in range(dim):
+        i = rem % npg[d]
+        rem //= npg[d]
+        coords[:, d] = lo[d] + (hi[d] - lo[d]) * i / n[d]
+    # cells of the extended box, lexicographic, vertices in deal.II order
+    ln = [box.node_hi[d] - box.node_lo[d] + 1 for d in range(dim)]
+    lc = [box.cells_hi[d] - box.cells_lo[d] for d in range(dim)]
+    if dim == 2:
+        j, i = np.meshgrid(np.arange(lc[1]), np.arange(lc[0]), indexing="ij")
+        base = (i + ln[0] * j).ravel()
+        offs = np.array([0, 1, ln[0], ln[0] + 1])
+    else:
+        k, j, i = np.meshgrid(np.arange(lc[2]), np.arange(lc[1]), np.arange(lc[0]), indexing="ij")
+        base = (i + ln[0] * (j + ln[1] * k)).ravel()
+        sx, sy, sz = 1, ln[0], ln[0] * ln[1]
+        offs = np.array([0, sx, sy, sx + sy, sz, sz + sx, sz + sy, sz + sx + sy])
+    cells = local_of_box[base[:, None] + offs[None, :]].astype(np.int32)
+    # physical boundary nodes (colorized ids) in local numbering
+    bn = {}
+    rem = global_ids.copy()
+    for d in range(dim):
+        i = rem % npg[d]
+        rem //= npg[d]
+        bn[2 * d] = np.nonzero(i == 0)[0].astype(np.int32)
+        bn[2 * d + 1] = np.nonzero(i == n[d])[0].astype(np.int32)
+    mesh = Mesh(dim=dim, coords=coords, cells=np.ascontiguousarray(cells), boundary_nodes=bn)
+    # halo lists
+    ghost_gid = global_ids[n_owned:]
+    ghost_owner = owner_of_nodes(n, p, ghost_gid)
+    sorter = np.argsort(global_ids[:n_owned])
+    peers_set = set(int(r) for r in np.unique(ghost_owner))
+    send_lists = {}
+    for r in range(world):
+        if r == rank:
+            continue
+        ob = local_box(n, p, r)
+        # quick reject: boxes must touch
+        if any(ob.node_lo[d] > box.node_hi[d] or box.node_lo[d] > ob.node_hi[d] for d in range(dim)):
+            continue
+        og = ob.node_ids()
+        their_ghost = og[~ob.owned_mask()]
+        mine = np.intersect1d(their_ghost, global_ids[:n_owned])  # sorted ascending
+        if mine.size:
+            pos = sorter[np.searchsorted(global_ids[:n_owned], mine, sorter=sorter)]
+            send_lists[r] = pos.astype(np.int32)
+            peers_set.add(r)
+    peers = sorted(peers_set)
+    send_ptr, recv_ptr = [0], [0]
+    send_nodes, recv_nodes = [], []
+    for r in peers:
+        s = send_lists.get(r, np.zeros(0, np.int32))
+        send_nodes.append(s)
+        send_ptr.append(send_ptr[-1] + s.size)
+        sel = np.nonzero(ghost_owner == r)[0]
+        sel = sel[np.argsort(ghost_gid[sel])]
+        recv_nodes.append((n_owned + sel).astype(np.int32))
+        recv_ptr.append(recv_ptr[-1] + sel.size)
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int32)
+    return LocalProblem(mesh, n_owned, global_ids, peers, np.asarray(send_ptr, np.int64), cat(send_nodes),
+                        np.asarray(recv_ptr, np.int64), cat(recv_nodes), box)

@@ -153,6 +153,14 @@ int pfm_assemble(pfm_ctx *ctx, const double *sol, const double *old, const doubl
                  int residual_only, double *const *values, double *residual_pde,
                  double *residual_total);
 
+/* -- measurement ---------------------------------------------------------------------- */
+/* When enabled, every pfm_assemble_device() brackets its dominant kernel (the cell / row
+ * kernel, not the memsets or the state scatter) with HIP events on the context's stream;
+ * pfm_kernel_time_ms() synchronises, returns the mean duration of the launches recorded
+ * since the last call and resets the record. */
+int pfm_timing_enable(pfm_ctx *ctx, int on);
+int pfm_kernel_time_ms(pfm_ctx *ctx, double *mean_ms, int *n_launches);
+
 /* -- introspection -------------------------------------------------------------------- */
 /* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian */
 int pfm_ctx_kernel_path(const pfm_ctx *ctx);
