@@ -1,0 +1,337 @@
+// pfm_cart.hip — gfx950 kernels of the assembly hot path, "cartesian" family.
+//
+// Fast path for uniform Cartesian boxes (every BASELINE benchmark mesh: J = diag(h)).
+// MI355X-first design, not a translation of the reference's cell loop + scatter:
+//
+//   ROW OWNER.  Work is assigned by OUTPUT ROW (owned node), not by cell.  Every CSR value
+//   and every residual entry is computed completely by one lane and written exactly once:
+//   no atomics, no colouring, no zeroing pass, bitwise deterministic, and the result of a
+//   row does not depend on how the mesh is cut over GPUs.  The unique-touch traffic model
+//   of SURVEY.md §8(d) (3592 B/cell) becomes the actual traffic.
+//
+//   SUM FACTORISATION.  On a Cartesian cell dN_a/dx_c = (+-1/h_c) * prod_{k!=c} n_{a_k}(xi_k),
+//   so the element matrix (cracks.cc:2353-2387) collapses onto a handful of 1-D moment
+//   tables of the q-point weights.  The (u,u) block of one hex (576 entries, 27 648 loop
+//   bodies in the reference) is determined by 63 numbers:
+//       A^c[g_i][g_j]     = sum_q w g(q) m_{g_i}(q_i) m_{g_j}(q_j)            (3 x 9)
+//       T^{cd}[al][be][g] = sum_q w g(q) n_al(q_c) n_be(q_d) m_g(q_e)         (3 x 12)
+//   with n_0 = 1-xi, n_1 = xi, m_00 = n_0^2, m_01 = n_0 n_1, m_11 = n_1^2 at the 3 Gauss
+//   points, g(q) = (1-kappa) pf_extra^2 + kappa.  A workgroup computes these once per cell
+//   of its tile into LDS (SoA over cells: conflict-free), then its lanes, one per node,
+//   gather K[(a,c),(b,d)] = lambda G^{cd}_{ab} + mu G^{dc}_{ab} + mu delta_cd tr G_ab for all
+//   neighbour slots with compile-time LDS offsets, stage the rows in LDS and stream them out
+//   with fully coalesced stores.
+//
+// Arithmetic is the reference's (cracks.cc:2248-2432) re-associated; parity with the CPU
+// oracle is at round-off level (tests/test_gpu_parity.py, tolerance 1e-12).
+#include "pfm_internal.h"
+
+#include <hip/hip_runtime.h>
+
+namespace pfm
+{
+  namespace
+  {
+    // 1-D Gauss(3) data on [0,1]
+    struct Tab1D
+    {
+      double n[2][3]; // n_0 = 1 - xi, n_1 = xi
+      double w[3];
+    };
+    __constant__ Tab1D c_t1;
+
+    Tab1D make_tab1d()
+    {
+      Tab1D t{};
+      const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+      const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+      for (int q = 0; q < 3; ++q)
+        {
+          t.n[0][q] = 1.0 - gx[q];
+          t.n[1][q] = gx[q];
+          t.w[q] = gw[q];
+        }
+      return t;
+    }
+
+    template <int dim>
+    __device__ __forceinline__ long long dof_index_c(const DevView &v, int P, int c)
+    {
+      if (v.layout == PFM_LAYOUT_INTERLEAVED)
+        return (long long)P * (dim + 1) + c;
+      return c < dim ? (long long)P * dim + c : (long long)v.n_owned * dim + P;
+    }
+
+    struct Scal // per-launch scalars derived from pfm_params
+    {
+      double lam, mu, kappa, eps, Gc, p, aB1, gamma_fac, tfac;
+      int monolithic, use_old, total_via_update;
+    };
+
+    Scal make_scal(const pfm_params &prm, const CartView &cv, int dim)
+    {
+      Scal s{};
+      s.lam = prm.lambda;
+      s.mu = prm.mu;
+      s.kappa = prm.constant_k;
+      s.eps = prm.alpha_eps;
+      s.Gc = prm.G_c;
+      s.p = prm.pressure;
+      s.aB1 = prm.alpha_biot - 1.0;
+      double gamma = prm.gamma_penal;
+      if (prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC && prm.timestep_number < 1)
+        gamma = 0.0; // cracks.cc:2141-2144
+      double diam2 = 0.0;
+      for (int d = 0; d < dim; ++d)
+        diam2 += cv.h[d] * cv.h[d];
+      s.gamma_fac = gamma / prm.timestep * 1.0 / diam2; // cracks.cc:2370, 2419
+      s.tfac = (prm.time - (prm.time - prm.old_timestep - prm.old_old_timestep)) /
+               (prm.time - prm.old_timestep - (prm.time - prm.old_timestep - prm.old_old_timestep));
+      s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
+      s.use_old = prm.use_old_timestep_pf;
+      s.total_via_update = prm.outer_solver != PFM_SOLVER_ACTIVE_SET;
+      return s;
+    }
+
+    // =====================================================================================
+    // Residual, row owner: one lane per owned node, loop over its 2^dim cells
+    // (cracks.cc:2393-2432 gathered per test vertex).
+    // =====================================================================================
+    template <int dim>
+    __global__ __launch_bounds__(128) void k_cart_residual(DevView v, CartView cv, Scal S,
+                                                           double *__restrict__ res_pde,
+                                                           double *__restrict__ res_tot, int write_total)
+    {
+      constexpr int nv = 1 << dim, nc = dim + 1;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
+      const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (t >= v.n_owned)
+        return;
+      const int i = cv.o0[0] + (int)(t % OWX);
+      const int j = cv.o0[1] + (int)((t / OWX) % OWY);
+      const int k = dim == 3 ? cv.o0[2] + (int)(t / ((long long)OWX * OWY)) : 0;
+      const int row = cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+
+      const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = dim == 3 ? 1.0 / cv.h[2] : 0.0;
+      const double vol = cv.h[0] * cv.h[1] * (dim == 3 ? cv.h[2] : 1.0);
+      double R[nc];
+#pragma unroll
+      for (int c = 0; c < nc; ++c)
+        R[c] = 0.0;
+
+#pragma unroll
+      for (int e = 0; e < nv; ++e)
+        {
+          // cell (i+ex, j+ey, k+ez), e in {-1,0}^dim; this node is its vertex a = -e
+          const int ax = (e & 1), ay = (e >> 1) & 1, az = (e >> 2) & 1;
+          const int ci = i - ax, cj = j - ay, ck = k - az;
+          if (ci < 0 || ci >= cv.NX - 1 || cj < 0 || cj >= cv.NY - 1)
+            continue;
+          if (dim == 3 && (ck < 0 || ck >= cv.NZ - 1))
+            continue;
+          // nodal values of the cell: [field][vertex]; fields u(dim), phi, phi_old, phi_oldold
+          double U[dim + 3][nv];
+#pragma unroll
+          for (int b = 0; b < nv; ++b)
+            {
+              const long long bidx = (ci + (b & 1)) + (long long)cv.NX * ((cj + ((b >> 1) & 1)) +
+                                                                            (long long)cv.NY * (ck + ((b >> 2) & 1)));
+              const int n = cv.local_of_box[bidx];
+#pragma unroll
+              for (int d = 0; d < dim; ++d)
+                U[d][b] = v.u[d][n];
+              U[dim][b] = v.phi[n];
+              U[dim + 1][b] = v.phi_old[n];
+              U[dim + 2][b] = v.phi_oldold[n];
+            }
+          constexpr int NZQ = dim == 3 ? 3 : 1;
+          for (int qz = 0; qz < NZQ; ++qz)
+            {
+              // collapse z: plane values P[f][vy][vx] and z-derivatives Dz[f][vy][vx]
+              double Pl[dim + 3][4], Dz[dim + 1][4];
+              const double nz0 = dim == 3 ? c_t1.n[0][qz] : 1.0, nz1 = dim == 3 ? c_t1.n[1][qz] : 0.0;
+#pragma unroll
+              for (int f = 0; f < dim + 3; ++f)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                  {
+                    if constexpr (dim == 3)
+                      Pl[f][b] = nz0 * U[f][b] + nz1 * U[f][b + 4];
+                    else
+                      Pl[f][b] = U[f][b];
+                  }
+#pragma unroll
+              for (int f = 0; f < dim + 1; ++f)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                  {
+                    if constexpr (dim == 3)
+                      Dz[f][b] = (U[f][b + 4] - U[f][b]) * ihz;
+                    else
+                      Dz[f][b] = 0.0;
+                  }
+              const double naz = dim == 3 ? (az ? nz1 : nz0) : 1.0;
+              const double wz = dim == 3 ? c_t1.w[qz] : 1.0;
+              for (int qy = 0; qy < 3; ++qy)
+                {
+                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy];
+                  double L[dim + 3][2], Dy[dim + 1][2], DzL[dim + 1][2];
+#pragma unroll
+                  for (int f = 0; f < dim + 3; ++f)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                      L[f][b] = ny0 * Pl[f][b] + ny1 * Pl[f][b + 2];
+#pragma unroll
+                  for (int f = 0; f < dim + 1; ++f)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                      {
+                        Dy[f][b] = (Pl[f][b + 2] - Pl[f][b]) * ihy;
+                        DzL[f][b] = ny0 * Dz[f][b] + ny1 * Dz[f][b + 2];
+                      }
+                  const double nay = ay ? ny1 : ny0;
+                  const double wyz = c_t1.w[qy] * wz;
+                  // x-derivatives do not depend on qx
+                  double Dx[dim + 1];
+#pragma unroll
+                  for (int f = 0; f < dim + 1; ++f)
+                    Dx[f] = (L[f][1] - L[f][0]) * ihx;
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
+                      const double JxW = vol * c_t1.w[qx] * wyz;
+                      // Newton state at q (cracks.cc:2222-2232)
+                      double gu[dim][dim], gpf[dim];
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        {
+                          gu[c][0] = Dx[c];
+                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                          if constexpr (dim == 3)
+                            gu[c][2] = nx0 * DzL[c][0] + nx1 * DzL[c][1];
+                        }
+                      gpf[0] = Dx[dim];
+                      gpf[1] = nx0 * Dy[dim][0] + nx1 * Dy[dim][1];
+                      if constexpr (dim == 3)
+                        gpf[2] = nx0 * DzL[dim][0] + nx1 * DzL[dim][1];
+                      double pf = nx0 * L[dim][0] + nx1 * L[dim][1];
+                      double pfo = nx0 * L[dim + 1][0] + nx1 * L[dim + 1][1];
+                      double pfoo = nx0 * L[dim + 2][0] + nx1 * L[dim + 2][1];
+                      if (S.monolithic)
+                        {
+                          pf = fmax(0.0, pf);
+                          pfo = fmax(0.0, pfo);
+                          pfoo = fmax(0.0, pfoo);
+                        }
+                      const double pen = fmax(0.0, pf - pfo);
+                      double pfx = pfoo + S.tfac * (pfo - pfoo);
+                      if (pfx <= 0.0)
+                        pfx = 0.0;
+                      if (pfx >= 1.0)
+                        pfx = 1.0;
+                      if (S.use_old)
+                        pfx = pfo;
+                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+                      double E[dim][dim], trE = 0.0, divu = 0.0;
+#pragma unroll
+                      for (int a = 0; a < dim; ++a)
+                        {
+                          divu += gu[a][a];
+#pragma unroll
+                          for (int b = 0; b < dim; ++b)
+                            E[a][b] = 0.5 * (gu[a][b] + gu[b][a]);
+                          trE += E[a][a];
+                        }
+                      double sp[dim][dim], spE = 0.0;
+#pragma unroll
+                      for (int a = 0; a < dim; ++a)
+#pragma unroll
+                        for (int b = 0; b < dim; ++b)
+                          {
+                            sp[a][b] = S.lam * trE * (a == b ? 1.0 : 0.0) + 2 * S.mu * E[a][b];
+                            spE += sp[a][b] * E[a][b];
+                          }
+                      // test function of vertex a at q
+                      const double nax = ax ? nx1 : nx0;
+                      const double Na = nax * nay * naz;
+                      double gNa[dim];
+                      gNa[0] = (ax ? ihx : -ihx) * nay * naz;
+                      gNa[1] = (ay ? ihy : -ihy) * nax * naz;
+                      if constexpr (dim == 3)
+                        gNa[2] = (az ? ihz : -ihz) * nax * nay;
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        {
+                          double tt = 0.0;
+#pragma unroll
+                          for (int kk = 0; kk < dim; ++kk)
+                            tt += g * sp[c][kk] * gNa[kk];
+                          R[c] -= (tt - S.aB1 * S.p * pfx * pfx * gNa[c]) * JxW;
+                        }
+                      double gg = 0.0;
+#pragma unroll
+                      for (int kk = 0; kk < dim; ++kk)
+                        gg += gpf[kk] * gNa[kk];
+                      R[dim] -= S.gamma_fac * pen * Na * JxW;
+                      R[dim] -= ((1.0 - S.kappa) * spE * pf * Na - S.Gc / S.eps * (1.0 - pf) * Na + S.Gc * S.eps * gg -
+                                 2.0 * S.aB1 * S.p * pf * divu * Na) *
+                                JxW;
+                    }
+                }
+            }
+        }
+      // constrained scatter degenerates to a masked store (cracks.cc:2440-2456)
+      const unsigned fl = v.node_flags[row];
+#pragma unroll
+      for (int c = 0; c < nc; ++c)
+        {
+          const bool con = (fl >> c) & 1u;
+          const long long di = dof_index_c<dim>(v, row, c);
+          res_pde[di] = con ? 0.0 : R[c];
+          if (write_total)
+            res_tot[di] = (con && S.total_via_update) ? 0.0 : R[c];
+        }
+    }
+
+    bool g_tab_ready[16] = {};
+    int ensure_tab()
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16 && g_tab_ready[dev])
+        return PFM_OK;
+      const Tab1D t = make_tab1d();
+      if (hipMemcpyToSymbol(HIP_SYMBOL(c_t1), &t, sizeof(t)) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16)
+        g_tab_ready[dev] = true;
+      return PFM_OK;
+    }
+  } // namespace
+
+  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values,
+                         hipStream_t s);
+
+  int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
+                           double *const *d_values, double *res_pde, double *res_tot, hipStream_t s)
+  {
+    int rc = ensure_tab();
+    if (rc)
+      return rc;
+    if ((p.decompose_stress_matrix > 0 || p.decompose_stress_rhs > 0) && p.timestep_number > 0)
+      return PFM_ERR_UNSUPPORTED; // the host routes split runs to the general path
+    const Scal S = make_scal(p, cv, v.dim);
+    const int bs = 128;
+    const unsigned nb = (unsigned)((v.n_owned + bs - 1) / bs);
+    if (v.dim == 2)
+      hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+    else
+      hipLaunchKernelGGL(k_cart_residual<3>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+    if (hipGetLastError() != hipSuccess)
+      return PFM_ERR_HIP;
+    if (!residual_only)
+      return launch_cart_matrix(v, cv, p, d_values, s);
+    return PFM_OK;
+  }
+} // namespace pfm

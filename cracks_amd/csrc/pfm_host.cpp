@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -65,6 +66,126 @@ namespace
   int hipfail(pfm_ctx *c, hipError_t e, const char *what)
   {
     return fail(c, PFM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  }
+  // Detect a uniform Cartesian box and build the fast-path tables.
+  // Returns false (general path) whenever any check fails; never an error.
+  bool build_cart(pfm_ctx *c, const pfm_mesh_desc *m)
+  {
+    const int dim = m->dim, nv = 1 << dim;
+    if (m->n_hanging > 0 || m->cell_lambda || m->cell_mu)
+      return false;
+    int nc[3] = {m->box_cells[0], m->box_cells[1], dim == 3 ? m->box_cells[2] : 1};
+    if (nc[0] <= 0 || nc[1] <= 0 || nc[2] <= 0)
+      return false;
+    const int NX = nc[0] + 1, NY = nc[1] + 1, NZ = dim == 3 ? nc[2] + 1 : 1;
+    const int64_t nn = (int64_t)NX * NY * NZ;
+    if (nn != m->n_nodes || (int64_t)nc[0] * nc[1] * nc[2] != m->n_cells)
+      return false;
+    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    double x0[3] = {0, 0, 0}, x1[3] = {0, 0, 0}, h[3] = {1, 1, 1};
+    for (int d = 0; d < dim; ++d)
+      {
+        x0[d] = x1[d] = m->coords[d];
+        for (int32_t n = 1; n < N; ++n)
+          {
+            x0[d] = std::min(x0[d], m->coords[(size_t)n * dim + d]);
+            x1[d] = std::max(x1[d], m->coords[(size_t)n * dim + d]);
+          }
+        h[d] = (x1[d] - x0[d]) / nc[d];
+        if (!(h[d] > 0))
+          return false;
+      }
+    std::vector<int32_t> local_of_box((size_t)nn, -1);
+    std::vector<int32_t> box_of_local((size_t)N);
+    for (int32_t n = 0; n < N; ++n)
+      {
+        int64_t idx[3] = {0, 0, 0};
+        for (int d = 0; d < dim; ++d)
+          {
+            const double t = (m->coords[(size_t)n * dim + d] - x0[d]) / h[d];
+            idx[d] = llround(t);
+            if (std::abs(t - (double)idx[d]) > 1e-9 || idx[d] < 0 || idx[d] > nc[d])
+              return false;
+          }
+        const int64_t b = idx[0] + (int64_t)NX * (idx[1] + (int64_t)NY * idx[2]);
+        if (local_of_box[b] != -1)
+          return false; // duplicated coordinates (e.g. a slit): not a lattice
+        local_of_box[b] = n;
+        box_of_local[n] = (int32_t)b;
+      }
+    // every lattice cell must be present exactly once, vertices in deal.II order
+    std::vector<uint8_t> seen((size_t)m->n_cells, 0);
+    for (int64_t cell = 0; cell < m->n_cells; ++cell)
+      {
+        const int64_t b0 = box_of_local[m->cell_nodes[cell * nv]];
+        const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / ((int64_t)NX * NY);
+        if (i >= nc[0] || j >= nc[1] || (dim == 3 && k >= nc[2]))
+          return false;
+        for (int a = 0; a < nv; ++a)
+          {
+            const int64_t b = (i + (a & 1)) + (int64_t)NX * ((j + ((a >> 1) & 1)) + (int64_t)NY * (k + ((a >> 2) & 1)));
+            if (local_of_box[b] != m->cell_nodes[cell * nv + a])
+              return false;
+          }
+        const int64_t cid = i + (int64_t)nc[0] * (j + (int64_t)nc[1] * k);
+        if (seen[cid])
+          return false;
+        seen[cid] = 1;
+      }
+    // owned nodes must form a sub-box
+    int o0[3] = {1 << 30, 1 << 30, 1 << 30}, o1[3] = {-1, -1, -1};
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        const int64_t b = box_of_local[n];
+        const int idx[3] = {(int)(b % NX), (int)((b / NX) % NY), (int)(b / ((int64_t)NX * NY))};
+        for (int d = 0; d < 3; ++d)
+          {
+            o0[d] = std::min(o0[d], idx[d]);
+            o1[d] = std::max(o1[d], idx[d]);
+          }
+      }
+    if (NO == 0)
+      return false;
+    if ((int64_t)(o1[0] - o0[0] + 1) * (o1[1] - o0[1] + 1) * (o1[2] - o0[2] + 1) != NO)
+      return false;
+    // CSR neighbour slot -> lattice offset index (dx+1) + 3*(dy+1) + 9*(dz+1)
+    const int no = dim == 3 ? 27 : 9;
+    std::vector<uint8_t> inv((size_t)NO * no, 0xff);
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        const int64_t b = box_of_local[n];
+        const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+        const int32_t *rb = c->h_nadj.data() + c->h_nadj_ptr[n];
+        const int32_t *re = c->h_nadj.data() + c->h_nadj_ptr[n + 1];
+        int found = 0;
+        for (int o = 0; o < no; ++o)
+          {
+            const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+            if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+              continue;
+            const int32_t q = local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
+            const int32_t *p = std::lower_bound(rb, re, q);
+            if (p == re || *p != q)
+              continue; // neighbour not coupled through a local cell (cannot happen for owned rows)
+            inv[(size_t)n * no + (p - rb)] = (uint8_t)o;
+            ++found;
+          }
+        if (found != (int)(re - rb))
+          return false;
+      }
+    CartView &cv = c->cv;
+    cv.NX = NX;
+    cv.NY = NY;
+    cv.NZ = NZ;
+    for (int d = 0; d < 3; ++d)
+      {
+        cv.o0[d] = o0[d];
+        cv.o1[d] = o1[d];
+        cv.h[d] = h[d];
+      }
+    cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
+    cv.inv27 = dev_upload(c, inv.data(), inv.size());
+    return true;
   }
 } // namespace
 
@@ -275,7 +396,15 @@ extern "C"
       {
         return fail(c, PFM_ERR_NOMEM, "host allocation failed");
       }
-    c->kernel_path = 0;
+    try
+      {
+        c->cart_ok = build_cart(c, m);
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
+      }
+    c->kernel_path = c->cart_ok ? 1 : 0;
     return PFM_OK;
   }
 
@@ -491,16 +620,24 @@ extern "C"
     if (!c->have_params)
       return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
     hipSetDevice(c->device);
-    // zero the outputs (cracks.cc:2133-2137)
-    hipError_t e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
-    if (e == hipSuccess && residual_only)
+    hipError_t e = hipSuccess;
+    const bool split = (c->prm.decompose_stress_matrix > 0 || c->prm.decompose_stress_rhs > 0) &&
+                       c->prm.timestep_number > 0;
+    const bool cart = c->kernel_path == 1 && !split && (residual_only || cart_matrix_supported(c->v.dim));
+    const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
+    // zero the outputs (cracks.cc:2133-2137); the row-owner kernels of the cartesian path
+    // write every entry exactly once and need no zeroing pass
+    if (!cart)
+      e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
+    if (!cart && e == hipSuccess && residual_only)
       e = hipMemsetAsync(d_res_tot, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
     if (e == hipSuccess && !residual_only)
       for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
         {
           if (!d_values[b])
             return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
-          e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
+          if (!cart)
+            e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
@@ -519,7 +656,10 @@ extern "C"
         ++c->ev_used;
         hipEventRecord(ev0, c->stream);
       }
-    int rc = launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream)
+                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+    if (rc == PFM_OK && overlay_uu)
+      rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream);
     if (ev1)
       hipEventRecord(ev1, c->stream);
     if (rc)
@@ -630,7 +770,7 @@ extern "C"
 
   int pfm_ctx_force_path(pfm_ctx *c, int path)
   {
-    if (!c || path != 0)
+    if (!c || path < 0 || path > 2 || (path >= 1 && !c->cart_ok) || (path == 2 && c->v.dim != 3))
       return PFM_ERR_UNSUPPORTED;
     c->kernel_path = path;
     return PFM_OK;

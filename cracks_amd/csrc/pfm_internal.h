@@ -33,6 +33,17 @@ namespace pfm
     int *status; // device error word (pfm_status)
   };
 
+  // Uniform Cartesian box (fast path): lattice of (NX,NY,NZ) nodes, owned nodes form the
+  // sub-box [o0,o1] (inclusive, lattice coordinates); rows are addressed by local node id.
+  struct CartView
+  {
+    int NX, NY, NZ;
+    int o0[3], o1[3];
+    double h[3];
+    const int32_t *local_of_box; // [NX*NY*NZ] lattice index -> local node id
+    const uint8_t *inv27;        // [n_owned][3^dim] CSR neighbour slot -> lattice offset index, 0xff = none
+  };
+
   struct HaloPeer
   {
     int32_t *d_send = nullptr, *d_recv = nullptr;
@@ -45,6 +56,10 @@ namespace pfm
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
   int launch_halo_unpack(const DevView &v, const int32_t *d_nodes, int64_t n, const double *d_buf,
                          hipStream_t s);
+  int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
+                           double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s);
+  bool cart_matrix_supported(int dim);
+  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
                               hipStream_t s);
@@ -59,6 +74,8 @@ struct pfm_ctx
   bool have_params = false;
   int n_blocks = 1;
   int kernel_path = 0;
+  bool cart_ok = false;
+  pfm::CartView cv{};
   // host copies needed for pattern queries
   std::vector<long long> h_nadj_ptr;
   std::vector<int32_t> h_nadj;
