@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--n", type=int, default=0, help="cells per direction (default 216 in 3-D, 1000 in 2-D)")
     ap.add_argument("--residual-only", action="store_true")
-    ap.add_argument("--path", choices=["auto", "general", "cart"], default="auto")
+    ap.add_argument("--path", choices=["auto", "general", "cart", "overlay"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare a small instance with the oracle first")
     args = ap.parse_args()
@@ -174,6 +174,8 @@ def main():
         asm.ctx.force_path(0)
     elif args.path == "cart":
         asm.ctx.force_path(1)
+    elif args.path == "overlay":
+        asm.ctx.force_path(2)
     asm.set_params(sneddon_params(h, dim))
     asm.set_constraints(flags)
     no = lp.n_owned

@@ -1,0 +1,145 @@
+// pfm_cart_common.h — tile geometry, 1-D Gauss tables and per-launch scalars shared by the
+// row-owner Jacobian kernels (pfm_cart_matrix.hip, pfm_cart_phi.hip).  Everything lives in
+// an anonymous namespace: each translation unit owns its copy of the __constant__ table.
+#pragma once
+#include "pfm_internal.h"
+
+#include <hip/hip_runtime.h>
+
+namespace pfm
+{
+  namespace
+  {
+    constexpr int TX = 8, TY = 8, NTHREADS = 512;
+    constexpr int HX = TX + 2, HY = TY + 2;      // nodal halo (10 x 10 x 3)
+    constexpr int NH = HX * HY * 3;              // 300 halo nodes
+    constexpr int CX = TX + 1, CY = TY + 1;      // cells per layer (9 x 9)
+    constexpr int CS = CX * CY * 2;              // 162 cell slots (two layers)
+    constexpr int NNUM_UU = 64;                  // 27 A + 36 T + 1 spare
+    constexpr int STG = 81;                      // staged row width (27 slots x 3), odd => conflict-free
+
+    struct G1
+    {
+      double n[2][3], m[3][3], w[3]; // n_al(q), m_g(q) (g = 0:00, 1:01, 2:11), weights
+    };
+    __constant__ G1 c_g1;
+
+    G1 make_g1()
+    {
+      G1 t{};
+      const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+      const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+      for (int q = 0; q < 3; ++q)
+        {
+          t.n[0][q] = 1.0 - gx[q];
+          t.n[1][q] = gx[q];
+          t.m[0][q] = t.n[0][q] * t.n[0][q];
+          t.m[1][q] = t.n[0][q] * t.n[1][q];
+          t.m[2][q] = t.n[1][q] * t.n[1][q];
+          t.w[q] = gw[q];
+        }
+      return t;
+    }
+
+    struct MatScal
+    {
+      double lam, mu, kappa, eps, Gc, p, aB1, gamma_fac, tfac;
+      double ih[3], vol;
+      double cA[3][3]; // cA[c][k] = (k == c ? lam + 2 mu : mu) / h_k^2
+      double cT[3];    // 1 / (h_lo h_hi) for the pairs (0,1), (0,2), (1,2)
+      int monolithic, use_old;
+    };
+
+    // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
+    __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScal &S, int qz,
+                                                  double wg[9])
+    {
+      double a[4], b[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          a[v] = c_g1.n[0][qz] * po[v] + c_g1.n[1][qz] * po[v + 4];
+          b[v] = c_g1.n[0][qz] * poo[v] + c_g1.n[1][qz] * poo[v + 4];
+        }
+#pragma unroll
+      for (int qy = 0; qy < 3; ++qy)
+        {
+          const double a0 = c_g1.n[0][qy] * a[0] + c_g1.n[1][qy] * a[2];
+          const double a1 = c_g1.n[0][qy] * a[1] + c_g1.n[1][qy] * a[3];
+          const double b0 = c_g1.n[0][qy] * b[0] + c_g1.n[1][qy] * b[2];
+          const double b1 = c_g1.n[0][qy] * b[1] + c_g1.n[1][qy] * b[3];
+#pragma unroll
+          for (int qx = 0; qx < 3; ++qx)
+            {
+              double pfo = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
+              double pfoo = c_g1.n[0][qx] * b0 + c_g1.n[1][qx] * b1;
+              if (S.monolithic)
+                {
+                  pfo = fmax(0.0, pfo);
+                  pfoo = fmax(0.0, pfoo);
+                }
+              double pfx = pfoo + S.tfac * (pfo - pfoo);
+              if (pfx <= 0.0)
+                pfx = 0.0;
+              if (pfx >= 1.0)
+                pfx = 1.0;
+              if (S.use_old)
+                pfx = pfo;
+              const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz]) * g;
+            }
+        }
+    }
+
+    bool g_g1_ready[16] = {};
+    int ensure_g1()
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16 && g_g1_ready[dev])
+        return PFM_OK;
+      const G1 t = make_g1();
+      if (hipMemcpyToSymbol(HIP_SYMBOL(c_g1), &t, sizeof(t)) != hipSuccess)
+        return PFM_ERR_HIP;
+      if (dev < 16)
+        g_g1_ready[dev] = true;
+      return PFM_OK;
+    }
+
+    MatScal make_mat_scal(const pfm_params &prm, const CartView &cv)
+    {
+      MatScal s{};
+      s.lam = prm.lambda;
+      s.mu = prm.mu;
+      s.kappa = prm.constant_k;
+      s.eps = prm.alpha_eps;
+      s.Gc = prm.G_c;
+      s.p = prm.pressure;
+      s.aB1 = prm.alpha_biot - 1.0;
+      double gamma = prm.gamma_penal;
+      if (prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC && prm.timestep_number < 1)
+        gamma = 0.0;
+      double diam2 = 0.0;
+      s.vol = 1.0;
+      for (int d = 0; d < 3; ++d)
+        {
+          diam2 += cv.h[d] * cv.h[d];
+          s.ih[d] = 1.0 / cv.h[d];
+          s.vol *= cv.h[d];
+        }
+      s.gamma_fac = gamma / prm.timestep * 1.0 / diam2;
+      s.tfac = (prm.time - (prm.time - prm.old_timestep - prm.old_old_timestep)) /
+               (prm.time - prm.old_timestep - (prm.time - prm.old_timestep - prm.old_old_timestep));
+      for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 3; ++k)
+          s.cA[c][k] = (k == c ? prm.lambda + 2 * prm.mu : prm.mu) * s.ih[k] * s.ih[k];
+      s.cT[0] = s.ih[0] * s.ih[1];
+      s.cT[1] = s.ih[0] * s.ih[2];
+      s.cT[2] = s.ih[1] * s.ih[2];
+      s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
+      s.use_old = prm.use_old_timestep_pf;
+      return s;
+    }
+  } // namespace
+} // namespace pfm

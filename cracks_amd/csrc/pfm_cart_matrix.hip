@@ -11,54 +11,17 @@
 //            visits 8 cell contributions per row), compile-time LDS offsets, rows staged in LDS
 //   phase 3  copy-out: flat, coalesced stores of the staged rows into the CSR value array
 #include "pfm_internal.h"
+#include "pfm_cart_common.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace pfm
 {
   namespace
   {
-    constexpr int TX = 8, TY = 8, NTHREADS = 512;
-    constexpr int HX = TX + 2, HY = TY + 2;      // nodal halo (10 x 10 x 3)
-    constexpr int NH = HX * HY * 3;              // 300 halo nodes
-    constexpr int CX = TX + 1, CY = TY + 1;      // cells per layer (9 x 9)
-    constexpr int CS = CX * CY * 2;              // 162 cell slots (two layers)
-    constexpr int NNUM_UU = 64;                  // 27 A + 36 T + 1 spare
-    constexpr int STG = 81;                      // staged row width (27 slots x 3), odd => conflict-free
-
-    struct G1
-    {
-      double n[2][3], m[3][3], w[3]; // n_al(q), m_g(q) (g = 0:00, 1:01, 2:11), weights
-    };
-    __constant__ G1 c_g1;
-
-    G1 make_g1()
-    {
-      G1 t{};
-      const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
-      const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
-      for (int q = 0; q < 3; ++q)
-        {
-          t.n[0][q] = 1.0 - gx[q];
-          t.n[1][q] = gx[q];
-          t.m[0][q] = t.n[0][q] * t.n[0][q];
-          t.m[1][q] = t.n[0][q] * t.n[1][q];
-          t.m[2][q] = t.n[1][q] * t.n[1][q];
-          t.w[q] = gw[q];
-        }
-      return t;
-    }
-
-    struct MatScal
-    {
-      double lam, mu, kappa, eps, Gc, p, aB1, gamma_fac, tfac;
-      double ih[3], vol;
-      double cA[3][3]; // cA[c][k] = (k == c ? lam + 2 mu : mu) / h_k^2
-      double cT[3];    // 1 / (h_lo h_hi) for the pairs (0,1), (0,2), (1,2)
-      int monolithic, use_old;
-    };
-
     // ---- compile-time index helpers ------------------------------------------------------
     __host__ __device__ constexpr int idxA(int c, int gi, int gj) { return c * 9 + gi * 3 + gj; }
     __host__ __device__ constexpr int pair_of(int lo, int hi) { return lo == 0 ? (hi == 1 ? 0 : 1) : 2; }
@@ -240,59 +203,47 @@ namespace pfm
         }
     }
 
-    // weights w*g(q) of one cell from the nodal phi_old / phi_oldold (cracks.cc:2262-2277)
-    __device__ __forceinline__ void cell_wg(const double po[8], const double poo[8], const MatScal &S, double wg[27])
+    // node phase of one row component; MASK = the tile touches constrained dofs
+    template <int C, bool MASK>
+    __device__ __forceinline__ void uu_rows(int wave, const double *lane_base, const MatScal &S, double *stage_row,
+                                            unsigned row_flag, const unsigned char *nbf)
     {
-#pragma unroll
-      for (int qz = 0; qz < 3; ++qz)
+      if constexpr (MASK)
+        uu_dispatch<C>(wave, lane_base, S, stage_row, row_flag, nbf);
+      else
         {
-          double a[4], b[4];
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            {
-              a[v] = c_g1.n[0][qz] * po[v] + c_g1.n[1][qz] * po[v + 4];
-              b[v] = c_g1.n[0][qz] * poo[v] + c_g1.n[1][qz] * poo[v + 4];
-            }
-#pragma unroll
-          for (int qy = 0; qy < 3; ++qy)
-            {
-              const double a0 = c_g1.n[0][qy] * a[0] + c_g1.n[1][qy] * a[2];
-              const double a1 = c_g1.n[0][qy] * a[1] + c_g1.n[1][qy] * a[3];
-              const double b0 = c_g1.n[0][qy] * b[0] + c_g1.n[1][qy] * b[2];
-              const double b1 = c_g1.n[0][qy] * b[1] + c_g1.n[1][qy] * b[3];
-#pragma unroll
-              for (int qx = 0; qx < 3; ++qx)
-                {
-                  double pfo = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
-                  double pfoo = c_g1.n[0][qx] * b0 + c_g1.n[1][qx] * b1;
-                  if (S.monolithic)
-                    {
-                      pfo = fmax(0.0, pfo);
-                      pfoo = fmax(0.0, pfoo);
-                    }
-                  double pfx = pfoo + S.tfac * (pfo - pfoo);
-                  if (pfx <= 0.0)
-                    pfx = 0.0;
-                  if (pfx >= 1.0)
-                    pfx = 1.0;
-                  if (S.use_old)
-                    pfx = pfo;
-                  const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-                  wg[qx + 3 * qy + 9 * qz] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz]) * g;
-                }
-            }
+          const unsigned char zero[27] = {};
+          uu_dispatch<C>(wave, lane_base, S, stage_row, 0u, zero);
         }
     }
 
     // =====================================================================================
+    template <int NCOL /* 3 blocked, 4 interleaved */, int ABL = 0 /* ablation bits, profiling only */>
     __global__ __launch_bounds__(NTHREADS) void k_cart_uu(DevView v, CartView cv, MatScal S, double *__restrict__ vals,
-                                                          int ncol /* 3 blocked, 4 interleaved */)
+                                                          unsigned long long *__restrict__ dbg)
     {
+      // phase clock (profiling builds only, ABL & 8): wave 0 accumulates cycles per phase
+      long long tclk = 0;
+      auto stamp = [&](int phase) {
+        if constexpr ((ABL & 8) != 0)
+          {
+            const long long now = clock64();
+            if (threadIdx.x == 0 && phase >= 0)
+              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+            tclk = now;
+          }
+      };
+      stamp(-1);
       __shared__ double s_buf[NNUM_UU * CS];
-      __shared__ double s_stage[TX * TY * STG];
+      __shared__ double s_stage[TX * TY * STG]; // rows being staged; holds w*g(q) [27][CS] during the cell phase
       __shared__ double s_po[NH], s_poo[NH];
       __shared__ int s_node[NH];
       __shared__ unsigned char s_flag[NH];
+      __shared__ long long s_rowbase[TX * TY]; // first value of the node's row block, -1 = not an owned node of the tile
+      __shared__ int s_deg[TX * TY];
+      __shared__ unsigned char s_inv[TX * TY * 27];
+      __shared__ int s_info[2]; // [0] any constraint flag in the halo, [1] number of irregular nodes
+      static_assert(27 * CS <= TX * TY * STG, "w*g scratch must fit in the staging buffer");
 
       const int t = threadIdx.x;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
@@ -301,7 +252,10 @@ namespace pfm
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * TX, j0 = cv.o0[1] + tiy * TY, k = cv.o0[2] + tk;
 
-      // ---- phase 0: nodal halo
+      // ---- phase 0: nodal halo + CSR row info of the tile's nodes
+      if (t < 2)
+        s_info[t] = 0;
+      __syncthreads();
       if (t < NH)
         {
           const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
@@ -320,32 +274,49 @@ namespace pfm
           s_po[t] = a;
           s_poo[t] = b;
           s_flag[t] = f;
+          if (f & 7u)
+            atomicOr(&s_info[0], 1);
+        }
+      else if (t >= 320 && t < 320 + TX * TY)
+        {
+          const int nl = t - 320, li = nl % TX, lj = nl / TX;
+          const int gi = i0 + li, gj = j0 + lj;
+          long long base = -1;
+          int deg = 0;
+          bool regular = false;
+          if (gi <= cv.o1[0] && gj <= cv.o1[1])
+            {
+              const int r = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * k)];
+              const long long off = v.nadj_ptr[r];
+              deg = (int)(v.nadj_ptr[r + 1] - off);
+              base = (long long)NCOL * NCOL * off;
+              regular = deg == 27;
+              for (int s = 0; s < 27; ++s)
+                {
+                  const unsigned char o = cv.inv27[(long long)r * 27 + s];
+                  s_inv[nl * 27 + s] = o;
+                  regular = regular && o == s;
+                }
+            }
+          s_rowbase[nl] = base;
+          s_deg[nl] = deg;
+          if (!regular)
+            atomicAdd(&s_info[1], 1);
         }
       __syncthreads();
+      stamp(0);
 
-      // ---- phase 1: cell phase (3 threads per cell)
-      if (t < 3 * CS)
+      // ---- phase 1a: w*g at the quadrature points, one thread per (cell, z-level) -> LDS [q][cell]
+      if ((ABL & 1) == 0 && t < 3 * CS)
         {
-          const int cs = t % CS, sub = t / CS;
+          const int cs = t % CS, qz = t / CS;
           const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
           const int h000 = cx + HX * (cy + HY * l);
           const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
-          double *out = s_buf + cs;
-          if (!valid)
+          double wg[9];
+          if (valid)
             {
-              if (sub == 0)
-                for (int m = 0; m < 27; ++m)
-                  out[m * CS] = 0.0;
-              else if (sub == 1)
-                for (int m = 27; m < 51; ++m)
-                  out[m * CS] = 0.0;
-              else
-                for (int m = 51; m < 64; ++m)
-                  out[m * CS] = 0.0;
-            }
-          else
-            {
-              double po[8], poo[8], wg[27];
+              double po[8], poo[8];
 #pragma unroll
               for (int b = 0; b < 8; ++b)
                 {
@@ -353,192 +324,203 @@ namespace pfm
                   po[b] = s_po[hb];
                   poo[b] = s_poo[hb];
                 }
-              cell_wg(po, poo, S, wg);
-              if (sub == 0)
-                {
-                  // A^c[g_i][g_j]: collapse axis c, then moments over the two others
+              cell_wg_plane(po, poo, S, qz, wg);
+            }
+          else
+            {
 #pragma unroll
-                  for (int c = 0; c < 3; ++c)
+              for (int q = 0; q < 9; ++q)
+                wg[q] = 0.0; // cells outside the local box contribute nothing
+            }
+#pragma unroll
+          for (int q = 0; q < 9; ++q)
+            s_stage[(qz * 9 + q) * CS + cs] = wg[q];
+        }
+      __syncthreads();
+      stamp(1);
+
+      // ---- phase 1b: moment tables, 3 threads per cell -> LDS [number][cell]
+      if ((ABL & 1) == 0 && t < 3 * CS)
+        {
+          const int cs = t % CS, sub = t / CS;
+          double *out = s_buf + cs;
+          double wg[27];
+#pragma unroll
+          for (int q = 0; q < 27; ++q)
+            wg[q] = s_stage[q * CS + cs];
+          if (sub == 0)
+            {
+              // A^c[g_i][g_j]: collapse axis c, then moments over the two others
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                {
+                  double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+#pragma unroll
+                  for (int qj = 0; qj < 3; ++qj)
+#pragma unroll
+                    for (int qi = 0; qi < 3; ++qi)
+                      {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int qc = 0; qc < 3; ++qc)
+                          {
+                            const int q = (c == 0) ? (qc + 3 * qi + 9 * qj) : (c == 1) ? (qi + 3 * qc + 9 * qj) : (qi + 3 * qj + 9 * qc);
+                            acc += wg[q];
+                          }
+                        s9[qj][qi] = acc;
+                      }
+#pragma unroll
+                  for (int gi = 0; gi < 3; ++gi)
                     {
-                      double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+                      double tq[3];
 #pragma unroll
                       for (int qj = 0; qj < 3; ++qj)
+                        tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
 #pragma unroll
-                        for (int qi = 0; qi < 3; ++qi)
-                          {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int qc = 0; qc < 3; ++qc)
-                              {
-                                const int q = (c == 0) ? (qc + 3 * qi + 9 * qj) : (c == 1) ? (qi + 3 * qc + 9 * qj) : (qi + 3 * qj + 9 * qc);
-                                acc += wg[q];
-                              }
-                            s9[qj][qi] = acc;
-                          }
-#pragma unroll
-                      for (int gi = 0; gi < 3; ++gi)
-                        {
-                          double tq[3];
-#pragma unroll
-                          for (int qj = 0; qj < 3; ++qj)
-                            tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
-#pragma unroll
-                          for (int gj = 0; gj < 3; ++gj)
-                            out[idxA(c, gi, gj) * CS] = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
-                        }
-                    }
-                }
-              else
-                {
-                  // T^p[al][be][g] = sum wg n_al(q_lo) n_be(q_hi) m_g(q_e)
-                  auto do_pair = [&](const int lo, const int hi) {
-                    const int e = 3 - lo - hi, p = pair_of(lo, hi);
-                    const int st[3] = {1, 3, 9};
-#pragma unroll
-                    for (int al = 0; al < 2; ++al)
-                      {
-                        double t1[3][3]; // [q_e][q_hi]
-#pragma unroll
-                        for (int qe = 0; qe < 3; ++qe)
-#pragma unroll
-                          for (int qh = 0; qh < 3; ++qh)
-                            {
-                              double acc = 0.0;
-#pragma unroll
-                              for (int ql = 0; ql < 3; ++ql)
-                                acc += wg[ql * st[lo] + qh * st[hi] + qe * st[e]] * c_g1.n[al][ql];
-                              t1[qe][qh] = acc;
-                            }
-#pragma unroll
-                        for (int be = 0; be < 2; ++be)
-                          {
-                            double t2[3];
-#pragma unroll
-                            for (int qe = 0; qe < 3; ++qe)
-                              t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
-#pragma unroll
-                            for (int g = 0; g < 3; ++g)
-                              out[idxT(p, al, be, g) * CS] = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
-                          }
-                      }
-                  };
-                  if (sub == 1)
-                    {
-                      do_pair(0, 1);
-                      do_pair(0, 2);
-                    }
-                  else
-                    {
-                      do_pair(1, 2);
-                      out[63 * CS] = 0.0;
+                      for (int gj = 0; gj < 3; ++gj)
+                        out[idxA(c, gi, gj) * CS] = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
                     }
                 }
             }
+          else
+            {
+              // T^p[al][be][g] = sum wg n_al(q_lo) n_be(q_hi) m_g(q_e)
+              auto do_pair = [&](const int lo, const int hi) {
+                const int e = 3 - lo - hi, p = pair_of(lo, hi);
+                const int st[3] = {1, 3, 9};
+#pragma unroll
+                for (int al = 0; al < 2; ++al)
+                  {
+                    double t1[3][3]; // [q_e][q_hi]
+#pragma unroll
+                    for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                      for (int qh = 0; qh < 3; ++qh)
+                        {
+                          double acc = 0.0;
+#pragma unroll
+                          for (int ql = 0; ql < 3; ++ql)
+                            acc += wg[ql * st[lo] + qh * st[hi] + qe * st[e]] * c_g1.n[al][ql];
+                          t1[qe][qh] = acc;
+                        }
+#pragma unroll
+                    for (int be = 0; be < 2; ++be)
+                      {
+                        double t2[3];
+#pragma unroll
+                        for (int qe = 0; qe < 3; ++qe)
+                          t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                          out[idxT(p, al, be, g) * CS] = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
+                      }
+                  }
+              };
+              if (sub == 1)
+                {
+                  do_pair(0, 1);
+                  do_pair(0, 2);
+                }
+              else
+                do_pair(1, 2);
+            }
         }
       __syncthreads();
+      stamp(2);
 
       // ---- phases 2 + 3 per row component
       const int wave = t >> 6, lane = t & 63;
       const int ti = lane % TX, tj = lane / TX;
       const int hc = (ti + 1) + HX * ((tj + 1) + HY * 1); // halo index of this lane's node
-      const int ni = i0 + ti, nj = j0 + tj;
-      const bool owned = ni <= cv.o1[0] && nj <= cv.o1[1];
-      const unsigned row_flag = s_flag[hc];
+      const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
+      const bool masked = s_info[0] != 0;
+      const bool regular_tile = (NCOL == 3) && s_info[1] == 0;
+      unsigned row_flag = 0;
       unsigned char nbf[27];
+      if (masked)
+        {
+          row_flag = s_flag[hc];
 #pragma unroll
-      for (int o = 0; o < 27; ++o)
-        nbf[o] = s_flag[hc + (o % 3 - 1) + HX * ((o / 3) % 3 - 1) + HX * HY * (o / 9 - 1)];
+          for (int o = 0; o < 27; ++o)
+            nbf[o] = s_flag[hc + (o % 3 - 1) + HX * ((o / 3) % 3 - 1) + HX * HY * (o / 9 - 1)];
+        }
       const double *lane_base = s_buf + (CX * CY) + (tj + 1) * CX + (ti + 1);
       double *stage_row = s_stage + lane * STG;
+      // fast copy-out of regular tiles: flat element f = nl*81 + e  ->  rowbase[nl] + c*81 + e
+      constexpr int NIT = (TX * TY * STG + NTHREADS - 1) / NTHREADS;
+      long long dst0[NIT];
+      if (regular_tile)
+        {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it)
+            {
+              const int f = t + it * NTHREADS;
+              const int nl = f / STG;
+              dst0[it] = (f < TX * TY * STG) ? s_rowbase[nl] + (f - nl * STG) : -1;
+            }
+        }
 
 #pragma unroll 1
       for (int c = 0; c < 3; ++c)
         {
-          if (owned)
+          if ((ABL & 2) == 0 && owned)
             {
-              if (c == 0)
-                uu_dispatch<0>(wave, lane_base, S, stage_row, row_flag, nbf);
-              else if (c == 1)
-                uu_dispatch<1>(wave, lane_base, S, stage_row, row_flag, nbf);
+              if (masked)
+                {
+                  if (c == 0)
+                    uu_rows<0, true>(wave, lane_base, S, stage_row, row_flag, nbf);
+                  else if (c == 1)
+                    uu_rows<1, true>(wave, lane_base, S, stage_row, row_flag, nbf);
+                  else
+                    uu_rows<2, true>(wave, lane_base, S, stage_row, row_flag, nbf);
+                }
               else
-                uu_dispatch<2>(wave, lane_base, S, stage_row, row_flag, nbf);
+                {
+                  if (c == 0)
+                    uu_rows<0, false>(wave, lane_base, S, stage_row, row_flag, nbf);
+                  else if (c == 1)
+                    uu_rows<1, false>(wave, lane_base, S, stage_row, row_flag, nbf);
+                  else
+                    uu_rows<2, false>(wave, lane_base, S, stage_row, row_flag, nbf);
+                }
             }
+          stamp(3);
           __syncthreads();
-          // copy-out: element f of the tile's row-c data, flat over (node, slot, column comp)
-          const int rowlen = 27 * ncol;
-          for (int f = t; f < TX * TY * rowlen; f += NTHREADS)
+          stamp(4);
+          if ((ABL & 4) == 0)
             {
-              const int nl = f / rowlen, e = f - nl * rowlen;
-              const int s = e / ncol, d = e - s * ncol;
-              const int li = nl % TX, lj = nl / TX;
-              if (i0 + li > cv.o1[0] || j0 + lj > cv.o1[1])
-                continue;
-              const int r = s_node[(li + 1) + HX * ((lj + 1) + HY)];
-              const long long off = v.nadj_ptr[r];
-              const int deg = (int)(v.nadj_ptr[r + 1] - off);
-              if (s >= deg)
-                continue;
-              const int o = cv.inv27[(long long)r * 27 + s];
-              const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
-              vals[(long long)ncol * ncol * off + (long long)c * ncol * deg + (long long)s * ncol + d] = val;
+              if (regular_tile)
+                {
+#pragma unroll
+                  for (int it = 0; it < NIT; ++it)
+                    if (dst0[it] >= 0)
+                      vals[dst0[it] + c * STG] = s_stage[t + it * NTHREADS];
+                }
+              else
+                {
+                  // general copy-out: element f of the tile's row-c data, flat over (node, slot, column comp)
+                  constexpr int rowlen = 27 * NCOL;
+                  for (int f = t; f < TX * TY * rowlen; f += NTHREADS)
+                    {
+                      const int nl = f / rowlen, e = f - nl * rowlen;
+                      const int s = e / NCOL, d = e - s * NCOL;
+                      const long long base = s_rowbase[nl];
+                      const int deg = s_deg[nl];
+                      if (base < 0 || s >= deg)
+                        continue;
+                      const int o = s_inv[nl * 27 + s];
+                      const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
+                      vals[base + (long long)c * NCOL * deg + s * NCOL + d] = val;
+                    }
+                }
             }
+          stamp(5);
           __syncthreads();
+          stamp(6);
         }
     }
 
-    bool g_g1_ready[16] = {};
-    int ensure_g1()
-    {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess)
-        return PFM_ERR_HIP;
-      if (dev < 16 && g_g1_ready[dev])
-        return PFM_OK;
-      const G1 t = make_g1();
-      if (hipMemcpyToSymbol(HIP_SYMBOL(c_g1), &t, sizeof(t)) != hipSuccess)
-        return PFM_ERR_HIP;
-      if (dev < 16)
-        g_g1_ready[dev] = true;
-      return PFM_OK;
-    }
-
-    MatScal make_mat_scal(const pfm_params &prm, const CartView &cv)
-    {
-      MatScal s{};
-      s.lam = prm.lambda;
-      s.mu = prm.mu;
-      s.kappa = prm.constant_k;
-      s.eps = prm.alpha_eps;
-      s.Gc = prm.G_c;
-      s.p = prm.pressure;
-      s.aB1 = prm.alpha_biot - 1.0;
-      double gamma = prm.gamma_penal;
-      if (prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC && prm.timestep_number < 1)
-        gamma = 0.0;
-      double diam2 = 0.0;
-      s.vol = 1.0;
-      for (int d = 0; d < 3; ++d)
-        {
-          diam2 += cv.h[d] * cv.h[d];
-          s.ih[d] = 1.0 / cv.h[d];
-          s.vol *= cv.h[d];
-        }
-      s.gamma_fac = gamma / prm.timestep * 1.0 / diam2;
-      s.tfac = (prm.time - (prm.time - prm.old_timestep - prm.old_old_timestep)) /
-               (prm.time - prm.old_timestep - (prm.time - prm.old_timestep - prm.old_old_timestep));
-      for (int c = 0; c < 3; ++c)
-        for (int k = 0; k < 3; ++k)
-          s.cA[c][k] = (k == c ? prm.lambda + 2 * prm.mu : prm.mu) * s.ih[k] * s.ih[k];
-      s.cT[0] = s.ih[0] * s.ih[1];
-      s.cT[1] = s.ih[0] * s.ih[2];
-      s.cT[2] = s.ih[1] * s.ih[2];
-      s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
-      s.use_old = prm.use_old_timestep_pf;
-      return s;
-    }
   } // namespace
-
-  bool cart_matrix_supported(int dim) { return false && dim == 3; }
 
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
   {
@@ -549,13 +531,53 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
-    const int ncol = v.layout == PFM_LAYOUT_INTERLEAVED ? 4 : 3;
-    hipLaunchKernelGGL(k_cart_uu, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, ncol);
+    const char *abl_env = getenv("PFM_UU_ABL"); // profiling only: skip phases (results are then wrong)
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    unsigned long long *dbg = nullptr;
+    if (abl == 8)
+      {
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+          return PFM_ERR_HIP;
+        hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        hipLaunchKernelGGL((k_cart_uu<3, 8>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, d_dbg);
+        unsigned long long h[16];
+        hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char *names[7] = {"phase0 (halo loads)", "1a (w*g)", "1b (moments)", "node phase", "barrier after node",
+                                "copy-out", "barrier after copy"};
+        fprintf(stderr, "[k_cart_uu phase clock, wave 0, cycles per tile]");
+        for (int i = 0; i < 7; ++i)
+          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
+        fprintf(stderr, "\n");
+        return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+      }
+    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL(k_cart_uu<4>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+    else
+      switch (abl)
+        {
+          case 1:
+            hipLaunchKernelGGL((k_cart_uu<3, 1>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          case 2:
+            hipLaunchKernelGGL((k_cart_uu<3, 2>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          case 3:
+            hipLaunchKernelGGL((k_cart_uu<3, 3>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          case 4:
+            hipLaunchKernelGGL((k_cart_uu<3, 4>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          case 6:
+            hipLaunchKernelGGL((k_cart_uu<3, 6>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          case 7:
+            hipLaunchKernelGGL((k_cart_uu<3, 7>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+            break;
+          default:
+            hipLaunchKernelGGL((k_cart_uu<3, 0>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, vals_uu, dbg);
+        }
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
 
-  int launch_cart_matrix(const DevView &, const CartView &, const pfm_params &, double *const *, hipStream_t)
-  {
-    return PFM_ERR_UNSUPPORTED;
-  }
 } // namespace pfm

@@ -1,0 +1,686 @@
+// pfm_cart_phi.hip — row-owner kernel for the phase-field rows of the Jacobian (3-D):
+// the (phi,u) block (cracks.cc:2374-2376, 2381-2382 with a displacement trial function),
+// the (phi,phi) block (cracks.cc:2370-2371, 2377-2383 with a phase-field trial function) and
+// the placeholder diagonals of constrained rows (deal.II distribute_local_to_global).
+//
+// Same tile machinery as k_cart_uu (pfm_cart_matrix.hip).  With the un-split stress
+//   sigma_LinU:E + sigma+:E_LinU = 2 (sigma+ grad N_b)_d           (sigma+ = lambda trE I + 2 mu E)
+// the (phi,u) entry of trial dof (b,d) and test vertex a is
+//   K[a,(b,d)] = sum_k  s(b_k)/h_k * C^{dk}[a_k][g_i][g_j]
+//   C^{dk}[al][g_i][g_j] = sum_q Phi^{dk}(q) n_al(q_k) m_{g_i}(q_i) m_{g_j}(q_j)
+//   Phi^{dk} = w pf [ (2(1-kappa) lambda trE - 2(alpha_B-1) p) delta_dk + 4(1-kappa) mu E_dk ]
+// and the (phi,phi) entry is a single table look-up
+//   K[a,b] = M[g_x][g_y][g_z],  M = sum_q w c(q) m m m  +  G_c eps * (Laplace moments),
+//   c(q) = (1-kappa) sigma+:E + G_c/eps - 2(alpha_B-1) p div u + gamma/dt/diam^2 [pf >= pf_old].
+// One sub-phase per column component d keeps the LDS table at 54 numbers per cell.
+#include "pfm_internal.h"
+#include "pfm_cart_common.h"
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+namespace pfm
+{
+  namespace
+  {
+    constexpr int NNUM_PHI = 56; // 54 (C^{dk}) per sub-phase; phi-phi: 27 M + avg + gzero + 27 partial
+    constexpr int STG_PU = 81, STG_PP = 27;
+    constexpr int N_M = 0, N_AVG = 27, N_GZERO = 28, N_PART = 29; // phi-phi number layout
+
+    __host__ __device__ constexpr int idxC(int k, int al, int gi, int gj) { return k * 18 + al * 9 + gi * 3 + gj; }
+    __host__ __device__ constexpr int sgn_(int bit) { return bit ? 1 : -1; }
+
+    // (phi,u) entries of slot O for the current column component: sum over cells and over k
+    template <int OX, int OY, int OZ>
+    __device__ __forceinline__ double pu_entry(const double *__restrict__ lane_base, const MatScal &S)
+    {
+      double r = 0.0;
+      auto visit = [&](auto EX, auto EY, auto EZ) {
+        constexpr int ex = decltype(EX)::value, ey = decltype(EY)::value, ez = decltype(EZ)::value;
+        constexpr int a[3] = {-ex, -ey, -ez};
+        constexpr int b[3] = {a[0] + OX, a[1] + OY, a[2] + OZ};
+        if constexpr (b[0] >= 0 && b[0] <= 1 && b[1] >= 0 && b[1] <= 1 && b[2] >= 0 && b[2] <= 1)
+          {
+            constexpr int g[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
+            const double *p = lane_base + (ez * (CX * CY) + ey * CX + ex);
+            r += (double)sgn_(b[0]) * S.ih[0] * p[idxC(0, a[0], g[1], g[2]) * CS];
+            r += (double)sgn_(b[1]) * S.ih[1] * p[idxC(1, a[1], g[0], g[2]) * CS];
+            r += (double)sgn_(b[2]) * S.ih[2] * p[idxC(2, a[2], g[0], g[1]) * CS];
+          }
+      };
+      using M1 = std::integral_constant<int, -1>;
+      using Z0 = std::integral_constant<int, 0>;
+      visit(M1{}, M1{}, M1{});
+      visit(Z0{}, M1{}, M1{});
+      visit(M1{}, Z0{}, M1{});
+      visit(Z0{}, Z0{}, M1{});
+      visit(M1{}, M1{}, Z0{});
+      visit(Z0{}, M1{}, Z0{});
+      visit(M1{}, Z0{}, Z0{});
+      visit(Z0{}, Z0{}, Z0{});
+      return r;
+    }
+
+    // (phi,phi) entry of slot O; for the centre slot also the constrained-row placeholder
+    // sum_e (|K_e,aa| != 0 ? |K_e,aa| : avg_e) and the sum of avg_e over cells whose (u,u) diagonal is 0
+    template <int OX, int OY, int OZ>
+    __device__ __forceinline__ double pp_entry(const double *__restrict__ lane_base, double &placeholder,
+                                               double &uu_patch)
+    {
+      double r = 0.0;
+      auto visit = [&](auto EX, auto EY, auto EZ) {
+        constexpr int ex = decltype(EX)::value, ey = decltype(EY)::value, ez = decltype(EZ)::value;
+        constexpr int a[3] = {-ex, -ey, -ez};
+        constexpr int b[3] = {a[0] + OX, a[1] + OY, a[2] + OZ};
+        if constexpr (b[0] >= 0 && b[0] <= 1 && b[1] >= 0 && b[1] <= 1 && b[2] >= 0 && b[2] <= 1)
+          {
+            constexpr int g[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
+            const double *p = lane_base + (ez * (CX * CY) + ey * CX + ex);
+            const double m = p[(N_M + g[0] + 3 * g[1] + 9 * g[2]) * CS];
+            r += m;
+            if constexpr (OX == 0 && OY == 0 && OZ == 0)
+              {
+                const double avg = p[N_AVG * CS];
+                placeholder += (fabs(m) != 0.0) ? fabs(m) : avg;
+                uu_patch += (p[N_GZERO * CS] != 0.0) ? avg : 0.0;
+              }
+          }
+      };
+      using M1 = std::integral_constant<int, -1>;
+      using Z0 = std::integral_constant<int, 0>;
+      visit(M1{}, M1{}, M1{});
+      visit(Z0{}, M1{}, M1{});
+      visit(M1{}, Z0{}, M1{});
+      visit(Z0{}, Z0{}, M1{});
+      visit(M1{}, M1{}, Z0{});
+      visit(Z0{}, M1{}, Z0{});
+      visit(M1{}, Z0{}, Z0{});
+      visit(Z0{}, Z0{}, Z0{});
+      return r;
+    }
+
+    template <int O>
+    __device__ __forceinline__ void pu_slot(const double *lane_base, const MatScal &S, double *stage_row, int d,
+                                            unsigned row_flag, unsigned col_flag)
+    {
+      constexpr int OX = O % 3 - 1, OY = (O / 3) % 3 - 1, OZ = O / 9 - 1;
+      double val = pu_entry<OX, OY, OZ>(lane_base, S);
+      if (((row_flag >> 3) & 1u) || ((col_flag >> d) & 1u))
+        val = 0.0; // constrained row (active set) or eliminated column
+      stage_row[O * 3 + d] = val;
+    }
+
+    template <int O>
+    __device__ __forceinline__ void pp_slot(const double *lane_base, double *stage_row, unsigned row_flag,
+                                            unsigned col_flag, double &uu_patch)
+    {
+      constexpr int OX = O % 3 - 1, OY = (O / 3) % 3 - 1, OZ = O / 9 - 1;
+      double ph = 0.0;
+      double val = pp_entry<OX, OY, OZ>(lane_base, ph, uu_patch);
+      const bool rcon = (row_flag >> 3) & 1u;
+      if (rcon)
+        val = (O == 13) ? ph : 0.0;
+      else if ((col_flag >> 3) & 1u)
+        val = 0.0;
+      stage_row[O] = val;
+    }
+
+#define PFM_FOR_WAVE_SLOTS(W, X) \
+  if constexpr (W == 0) { X(13); } \
+  else if constexpr (W == 1) { X(4); X(22); } \
+  else if constexpr (W == 2) { X(10); X(16); } \
+  else if constexpr (W == 3) { X(12); X(14); } \
+  else if constexpr (W == 4) { X(1); X(3); X(5); X(7); } \
+  else if constexpr (W == 5) { X(9); X(11); X(15); X(17); } \
+  else if constexpr (W == 6) { X(19); X(21); X(23); X(25); } \
+  else { X(0); X(2); X(6); X(8); X(18); X(20); X(24); X(26); }
+
+    template <int W>
+    __device__ __forceinline__ void pu_wave(const double *lane_base, const MatScal &S, double *stage_row, int d,
+                                            unsigned row_flag, const unsigned char *nbf)
+    {
+#define PFM_X(O) pu_slot<O>(lane_base, S, stage_row, d, row_flag, nbf[O])
+      PFM_FOR_WAVE_SLOTS(W, PFM_X)
+#undef PFM_X
+    }
+
+    template <int W>
+    __device__ __forceinline__ void pp_wave(const double *lane_base, double *stage_row, unsigned row_flag,
+                                            const unsigned char *nbf, double &uu_patch)
+    {
+#define PFM_X(O) pp_slot<O>(lane_base, stage_row, row_flag, nbf[O], uu_patch)
+      PFM_FOR_WAVE_SLOTS(W, PFM_X)
+#undef PFM_X
+    }
+
+    // =====================================================================================
+    template <int NCOL>
+    __global__ __launch_bounds__(NTHREADS) void k_cart_phi(DevView v, CartView cv, MatScal S,
+                                                           double *__restrict__ vals_pu, double *__restrict__ vals_pp,
+                                                           double *__restrict__ vals_uu)
+    {
+      __shared__ double s_buf[NNUM_PHI * CS];
+      __shared__ double s_stage_pu[TX * TY * STG_PU];
+      __shared__ double s_stage_pp[TX * TY * STG_PP];
+      __shared__ double s_u[3][NH], s_phi[NH], s_po[NH], s_poo[NH];
+      __shared__ int s_node[NH];
+      __shared__ unsigned char s_flag[NH];
+      __shared__ long long s_off[TX * TY]; // node-graph offset of the row, -1 = not an owned node of the tile
+      __shared__ int s_deg[TX * TY];
+      __shared__ unsigned char s_inv[TX * TY * 27];
+
+      const int t = threadIdx.x;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
+      const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;
+      const int bid = blockIdx.x;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
+      const int i0 = cv.o0[0] + tix * TX, j0 = cv.o0[1] + tiy * TY, k0 = cv.o0[2] + tk;
+
+      // ---- phase 0
+      if (t < NH)
+        {
+          const int li = t % HX, lj = (t / HX) % HY, lk = t / (HX * HY);
+          const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = k0 - 1 + lk;
+          int n = -1;
+          double uu[3] = {0, 0, 0}, ph = 0.0, a = 0.0, b = 0.0;
+          unsigned char f = 0;
+          if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ)
+            {
+              n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * gk)];
+              uu[0] = v.u[0][n];
+              uu[1] = v.u[1][n];
+              uu[2] = v.u[2][n];
+              ph = v.phi[n];
+              a = v.phi_old[n];
+              b = v.phi_oldold[n];
+              f = v.node_flags[n];
+            }
+          s_node[t] = n;
+          s_u[0][t] = uu[0];
+          s_u[1][t] = uu[1];
+          s_u[2][t] = uu[2];
+          s_phi[t] = ph;
+          s_po[t] = a;
+          s_poo[t] = b;
+          s_flag[t] = f;
+        }
+      else if (t >= 320 && t < 320 + TX * TY)
+        {
+          const int nl = t - 320, li = nl % TX, lj = nl / TX;
+          const int gi = i0 + li, gj = j0 + lj;
+          long long off = -1;
+          int deg = 0;
+          if (gi <= cv.o1[0] && gj <= cv.o1[1])
+            {
+              const int r = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * k0)];
+              off = v.nadj_ptr[r];
+              deg = (int)(v.nadj_ptr[r + 1] - off);
+              for (int s = 0; s < 27; ++s)
+                s_inv[nl * 27 + s] = cv.inv27[(long long)r * 27 + s];
+            }
+          s_off[nl] = off;
+          s_deg[nl] = deg;
+        }
+      __syncthreads();
+
+      const int wave = t >> 6, lane = t & 63;
+      const int ti = lane % TX, tj = lane / TX;
+      const int hc = (ti + 1) + HX * ((tj + 1) + HY * 1);
+      const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
+      const unsigned row_flag = s_flag[hc];
+      unsigned char nbf[27];
+#pragma unroll
+      for (int o = 0; o < 27; ++o)
+        nbf[o] = s_flag[hc + (o % 3 - 1) + HX * ((o / 3) % 3 - 1) + HX * HY * (o / 9 - 1)];
+      const double *lane_base = s_buf + (CX * CY) + (tj + 1) * CX + (ti + 1);
+
+      // ---- (phi,u): one sub-phase per column component d
+      const double cdiag = -2.0 * S.aB1 * S.p;
+#pragma unroll 1
+      for (int d = 0; d < 3; ++d)
+        {
+          if (t < 3 * CS)
+            {
+              const int cs = t % CS, kk = t / CS; // derivative axis k of this thread
+              const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
+              const int h000 = cx + HX * (cy + HY * l);
+              const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
+              double *out = s_buf + (kk * 18) * CS + cs;
+              if (!valid)
+                {
+                  for (int m = 0; m < 18; ++m)
+                    out[m * CS] = 0.0;
+                }
+              else
+                {
+                  // local frame: axis 0 = k, axes 1,2 = the two others (ascending)
+                  const int ai = (kk == 0) ? 1 : 0, aj = (kk == 2) ? 1 : 2;
+                  const int hs[3] = {1, HX, HX * HY};
+                  const int st0 = hs[kk], st1 = hs[ai], st2 = hs[aj];
+                  const double ih0 = S.ih[kk], ih1 = S.ih[ai], ih2 = S.ih[aj];
+                  const int ld = (d == kk) ? 0 : (d == ai ? 1 : 2); // local index of axis d
+                  double Uk[8], Ud[8], Ui[8], Uj[8], PH[8];
+#pragma unroll
+                  for (int b = 0; b < 8; ++b)
+                    {
+                      const int hb = h000 + (b & 1) * st0 + ((b >> 1) & 1) * st1 + ((b >> 2) & 1) * st2;
+                      Uk[b] = s_u[kk][hb];
+                      Ud[b] = s_u[d][hb];
+                      Ui[b] = s_u[ai][hb];
+                      Uj[b] = s_u[aj][hb];
+                      PH[b] = s_phi[hb];
+                    }
+                  // edge differences for the gradients along local axes 0, 1, 2
+                  double dk_ud[4], dd_uk[4], di_ui[4], dj_uj[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    {
+                      const int b1 = e & 1, b2 = e >> 1;
+                      dk_ud[e] = (Ud[1 + 2 * b1 + 4 * b2] - Ud[2 * b1 + 4 * b2]) * ih0; // d/dx_k u_d   at (b1,b2)
+                      // d/dx_d u_k along local axis ld, indexed by the two remaining local axes (ascending)
+                      if (ld == 0)
+                        dd_uk[e] = (Uk[1 + 2 * b1 + 4 * b2] - Uk[2 * b1 + 4 * b2]) * ih0;
+                      else if (ld == 1)
+                        dd_uk[e] = (Uk[b1 + 2 + 4 * b2] - Uk[b1 + 4 * b2]) * ih1; // (b0 = e&1, b2 = e>>1)
+                      else
+                        dd_uk[e] = (Uk[b1 + 2 * b2 + 4] - Uk[b1 + 2 * b2]) * ih2; // (b0 = e&1, b1 = e>>1)
+                      di_ui[e] = (Ui[b1 + 2 + 4 * b2] - Ui[b1 + 4 * b2]) * ih1; // (b0, b2)
+                      dj_uj[e] = (Uj[b1 + 2 * b2 + 4] - Uj[b1 + 2 * b2]) * ih2; // (b0, b1)
+                    }
+                  const bool diag = (ld == 0);
+                  const double c_mu = 4.0 * (1.0 - S.kappa) * S.mu, c_la = 2.0 * (1.0 - S.kappa) * S.lam;
+                  // contraction accumulators: stage 1 over q0 happens on the fly
+                  double t1[2][3][3]; // [al][q2][q1]
+#pragma unroll
+                  for (int q2 = 0; q2 < 3; ++q2)
+#pragma unroll
+                    for (int q1 = 0; q1 < 3; ++q1)
+                      {
+                        const double n1a = c_g1.n[0][q1], n1b = c_g1.n[1][q1], n2a = c_g1.n[0][q2], n2b = c_g1.n[1][q2];
+                        const double w12 = S.vol * c_g1.w[q1] * c_g1.w[q2];
+                        // d/dx_k u_d: independent of q0
+                        const double gk_ud = n1a * n2a * dk_ud[0] + n1b * n2a * dk_ud[1] + n1a * n2b * dk_ud[2] + n1b * n2b * dk_ud[3];
+                        // phi collapsed over local axes 1,2
+                        const double p0 = n1a * n2a * PH[0] + n1b * n2a * PH[2] + n1a * n2b * PH[4] + n1b * n2b * PH[6];
+                        const double p1 = n1a * n2a * PH[1] + n1b * n2a * PH[3] + n1a * n2b * PH[5] + n1b * n2b * PH[7];
+                        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int q0 = 0; q0 < 3; ++q0)
+                          {
+                            const double n0a = c_g1.n[0][q0], n0b = c_g1.n[1][q0];
+                            double pf = n0a * p0 + n0b * p1;
+                            if (S.monolithic)
+                              pf = fmax(0.0, pf); // cracks.cc:2251-2256
+                            double gd_uk;
+                            if (ld == 0)
+                              gd_uk = gk_ud; // d == k: same derivative
+                            else if (ld == 1)
+                              gd_uk = n0a * n2a * dd_uk[0] + n0b * n2a * dd_uk[1] + n0a * n2b * dd_uk[2] + n0b * n2b * dd_uk[3];
+                            else
+                              gd_uk = n0a * n1a * dd_uk[0] + n0b * n1a * dd_uk[1] + n0a * n1b * dd_uk[2] + n0b * n1b * dd_uk[3];
+                            double bracket = c_mu * 0.5 * (gk_ud + gd_uk);
+                            if (diag)
+                              {
+                                const double gi_ui = n0a * n2a * di_ui[0] + n0b * n2a * di_ui[1] + n0a * n2b * di_ui[2] + n0b * n2b * di_ui[3];
+                                const double gj_uj = n0a * n1a * dj_uj[0] + n0b * n1a * dj_uj[1] + n0a * n1b * dj_uj[2] + n0b * n1b * dj_uj[3];
+                                const double trE = gk_ud + gi_ui + gj_uj;
+                                bracket += c_la * trE + cdiag;
+                              }
+                            const double Phi = (w12 * c_g1.w[q0]) * pf * bracket;
+                            acc0 += Phi * n0a;
+                            acc1 += Phi * n0b;
+                          }
+                        t1[0][q2][q1] = acc0;
+                        t1[1][q2][q1] = acc1;
+                      }
+#pragma unroll
+                  for (int al = 0; al < 2; ++al)
+#pragma unroll
+                    for (int g1 = 0; g1 < 3; ++g1)
+                      {
+                        double t2[3];
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2)
+                          t2[q2] = t1[al][q2][0] * c_g1.m[g1][0] + t1[al][q2][1] * c_g1.m[g1][1] + t1[al][q2][2] * c_g1.m[g1][2];
+#pragma unroll
+                        for (int g2 = 0; g2 < 3; ++g2)
+                          out[(al * 9 + g1 * 3 + g2) * CS] = t2[0] * c_g1.m[g2][0] + t2[1] * c_g1.m[g2][1] + t2[2] * c_g1.m[g2][2];
+                      }
+                }
+            }
+          __syncthreads();
+          if (owned)
+            {
+              double *stage_row = s_stage_pu + lane * STG_PU;
+              switch (wave)
+                {
+                  case 0: pu_wave<0>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 1: pu_wave<1>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 2: pu_wave<2>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 3: pu_wave<3>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 4: pu_wave<4>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 5: pu_wave<5>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  case 6: pu_wave<6>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                  default: pu_wave<7>(lane_base, S, stage_row, d, row_flag, nbf); break;
+                }
+            }
+          __syncthreads();
+        }
+
+      // ---- (phi,phi) cell phase, step 1: thread <-> (cell, qz) : partial moments over (qx,qy)
+      if (t < 3 * CS)
+        {
+          const int cs = t % CS, qz = t / CS;
+          const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
+          const int h000 = cx + HX * (cy + HY * l);
+          const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
+          double *out = s_buf + cs;
+          if (!valid)
+            {
+              for (int m = 0; m < 9; ++m)
+                out[(N_PART + qz * 9 + m) * CS] = 0.0;
+            }
+          else
+            {
+              double U[6][8]; // ux, uy, uz, phi, phi_old, phi_oldold
+#pragma unroll
+              for (int b = 0; b < 8; ++b)
+                {
+                  const int hb = h000 + (b & 1) + HX * ((b >> 1) & 1) + HX * HY * ((b >> 2) & 1);
+                  U[0][b] = s_u[0][hb];
+                  U[1][b] = s_u[1][hb];
+                  U[2][b] = s_u[2][hb];
+                  U[3][b] = s_phi[hb];
+                  U[4][b] = s_po[hb];
+                  U[5][b] = s_poo[hb];
+                }
+              const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
+              double Pl[6][4], Dz[3][4];
+#pragma unroll
+              for (int f = 0; f < 6; ++f)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                  Pl[f][b] = nz0 * U[f][b] + nz1 * U[f][b + 4];
+#pragma unroll
+              for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                  Dz[f][b] = (U[f][b + 4] - U[f][b]) * S.ih[2];
+              double part[3][3]; // [gy][gx] partial moments
+#pragma unroll
+              for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                  part[a][b] = 0.0;
+#pragma unroll
+              for (int qy = 0; qy < 3; ++qy)
+                {
+                  const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
+                  double L[6][2], Dy[3][2], DzL[3][2];
+#pragma unroll
+                  for (int f = 0; f < 6; ++f)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                      L[f][b] = ny0 * Pl[f][b] + ny1 * Pl[f][b + 2];
+#pragma unroll
+                  for (int f = 0; f < 3; ++f)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                      {
+                        Dy[f][b] = (Pl[f][b + 2] - Pl[f][b]) * S.ih[1];
+                        DzL[f][b] = ny0 * Dz[f][b] + ny1 * Dz[f][b + 2];
+                      }
+                  double Dx[3];
+#pragma unroll
+                  for (int f = 0; f < 3; ++f)
+                    Dx[f] = (L[f][1] - L[f][0]) * S.ih[0];
+                  double rowx[3] = {0.0, 0.0, 0.0}; // moments over qx for this qy
+#pragma unroll
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_g1.n[0][qx], nx1 = c_g1.n[1][qx];
+                      const double JxW = S.vol * c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz];
+                      double gu[3][3];
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        {
+                          gu[c][0] = Dx[c];
+                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                          gu[c][2] = nx0 * DzL[c][0] + nx1 * DzL[c][1];
+                        }
+                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
+                      double pfo = nx0 * L[4][0] + nx1 * L[4][1];
+                      if (S.monolithic)
+                        {
+                          pf = fmax(0.0, pf);
+                          pfo = fmax(0.0, pfo);
+                        }
+                      double trE = 0.0, EE = 0.0;
+#pragma unroll
+                      for (int a = 0; a < 3; ++a)
+                        {
+                          trE += gu[a][a];
+#pragma unroll
+                          for (int b = 0; b < 3; ++b)
+                            {
+                              const double e = 0.5 * (gu[a][b] + gu[b][a]);
+                              EE += e * e;
+                            }
+                        }
+                      const double spE = S.lam * trE * trE + 2 * S.mu * EE; // sigma+ : E
+                      const double pen = ((pf - pfo) < 0.0) ? 0.0 : S.gamma_fac; // cracks.cc:2311-2315, 2370
+                      const double cq = (1 - S.kappa) * spE + S.Gc / S.eps - 2.0 * S.aB1 * S.p * trE + pen;
+                      const double wc = JxW * cq;
+                      rowx[0] += wc * c_g1.m[0][qx];
+                      rowx[1] += wc * c_g1.m[1][qx];
+                      rowx[2] += wc * c_g1.m[2][qx];
+                    }
+#pragma unroll
+                  for (int gy = 0; gy < 3; ++gy)
+#pragma unroll
+                    for (int gx = 0; gx < 3; ++gx)
+                      part[gy][gx] += rowx[gx] * c_g1.m[gy][qy];
+                }
+#pragma unroll
+              for (int gy = 0; gy < 3; ++gy)
+#pragma unroll
+                for (int gx = 0; gx < 3; ++gx)
+                  out[(N_PART + qz * 9 + gy * 3 + gx) * CS] = part[gy][gx];
+            }
+        }
+      __syncthreads();
+      // ---- (phi,phi) cell phase, step 2: thread <-> (cell, gz): finish the z moment, add the Laplace part
+      if (t < 3 * CS)
+        {
+          const int cs = t % CS, gz = t / CS;
+          double *out = s_buf + cs;
+          const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
+          const int h000 = cx + HX * (cy + HY * l);
+          const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
+          // 1-D mass moments mbar_g = sum_q w m_g(q)
+          double mb[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            mb[g] = c_g1.w[0] * c_g1.m[g][0] + c_g1.w[1] * c_g1.m[g][1] + c_g1.w[2] * c_g1.m[g][2];
+          const double lap = S.Gc * S.eps * S.vol;
+          const double sz = (gz == 1) ? -1.0 : 1.0;
+#pragma unroll
+          for (int gy = 0; gy < 3; ++gy)
+#pragma unroll
+            for (int gx = 0; gx < 3; ++gx)
+              {
+                double m = 0.0;
+#pragma unroll
+                for (int qz = 0; qz < 3; ++qz)
+                  m += out[(N_PART + qz * 9 + gy * 3 + gx) * CS] * c_g1.m[gz][qz];
+                const double sx = (gx == 1) ? -1.0 : 1.0, sy = (gy == 1) ? -1.0 : 1.0;
+                // G_c eps sum_q w grad N_a . grad N_b  (sign = -1 where a_k != b_k)
+                const double L = lap * (sx * S.ih[0] * S.ih[0] * mb[gy] * mb[gz] + sy * S.ih[1] * S.ih[1] * mb[gx] * mb[gz] +
+                                        sz * S.ih[2] * S.ih[2] * mb[gx] * mb[gy]);
+                m = valid ? m + L : 0.0;
+                out[(N_M + gx + 3 * gy + 9 * gz) * CS] = m;
+              }
+        }
+      __syncthreads();
+      // ---- (phi,phi) cell phase, step 3: mean |diagonal| of the element matrix (deal.II uses it as
+      // the placeholder of a constrained row whose own diagonal entry is exactly zero)
+      if (t < CS)
+        {
+          const int cs = t;
+          double *out = s_buf + cs;
+          const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
+          const int h000 = cx + HX * (cy + HY * l);
+          const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
+          double avg = 0.0, gzero = 0.0;
+          if (valid)
+            {
+              double dsum = 0.0; // sum_a |K_phiphi[a,a]|
+#pragma unroll
+              for (int a = 0; a < 8; ++a)
+                dsum += fabs(out[(N_M + 2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * ((a >> 2) & 1)) * CS]);
+              // sum_{a,c} K_uu[(a,c),(a,c)] = sum_k (sum_c cA[c][k]) * 2 * sum_q w g mu(q_i) mu(q_j),  mu = m_00 + m_11
+              double po[8], poo[8];
+#pragma unroll
+              for (int b = 0; b < 8; ++b)
+                {
+                  const int hb = h000 + (b & 1) + HX * ((b >> 1) & 1) + HX * HY * ((b >> 2) & 1);
+                  po[b] = s_po[hb];
+                  poo[b] = s_poo[hb];
+                }
+              double gsum = 0.0, gk[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+              for (int qz = 0; qz < 3; ++qz)
+                {
+                  double wg[9];
+                  cell_wg_plane(po, poo, S, qz, wg);
+                  const double muz = c_g1.m[0][qz] + c_g1.m[2][qz];
+#pragma unroll
+                  for (int qy = 0; qy < 3; ++qy)
+#pragma unroll
+                    for (int qx = 0; qx < 3; ++qx)
+                      {
+                        const double w = wg[qx + 3 * qy];
+                        const double mux = c_g1.m[0][qx] + c_g1.m[2][qx], muy = c_g1.m[0][qy] + c_g1.m[2][qy];
+                        gsum += w;
+                        gk[0] += w * muy * muz;
+                        gk[1] += w * mux * muz;
+                        gk[2] += w * mux * muy;
+                      }
+                }
+              double usum = 0.0;
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                usum += (S.cA[0][k] + S.cA[1][k] + S.cA[2][k]) * 2.0 * gk[k];
+              avg = (dsum + usum) / 32.0;
+              gzero = (gsum == 0.0) ? 1.0 : 0.0;
+            }
+          out[N_AVG * CS] = avg;
+          out[N_GZERO * CS] = gzero;
+        }
+      __syncthreads();
+
+      // ---- (phi,phi) node phase
+      double uu_patch = 0.0;
+      if (owned)
+        {
+          double *stage_row = s_stage_pp + lane * STG_PP;
+          switch (wave)
+            {
+              case 0: pp_wave<0>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 1: pp_wave<1>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 2: pp_wave<2>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 3: pp_wave<3>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 4: pp_wave<4>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 5: pp_wave<5>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              case 6: pp_wave<6>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+              default: pp_wave<7>(lane_base, stage_row, row_flag, nbf, uu_patch); break;
+            }
+          // wave 0 owns the centre slot: fix the placeholder of constrained displacement rows whose
+          // element diagonal vanished in some cell (kernel k_cart_uu wrote the plain sum earlier in the stream)
+          if (wave == 0 && (row_flag & 7u) && uu_patch != 0.0)
+            {
+              const int nl = lane;
+              const long long off = s_off[nl];
+              const int deg = s_deg[nl];
+              int sself = 0;
+              for (int s = 0; s < deg; ++s)
+                if (s_inv[nl * 27 + s] == 13)
+                  sself = s;
+              for (int c = 0; c < 3; ++c)
+                if ((row_flag >> c) & 1u)
+                  vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += uu_patch;
+            }
+        }
+      __syncthreads();
+
+      // ---- copy-out of the phase-field rows
+      if constexpr (NCOL == 3)
+        {
+          for (int f = t; f < TX * TY * STG_PU; f += NTHREADS)
+            {
+              const int nl = f / STG_PU, e = f - nl * STG_PU;
+              const int s = e / 3, d = e - s * 3;
+              const long long off = s_off[nl];
+              const int deg = s_deg[nl];
+              if (off < 0 || s >= deg)
+                continue;
+              const int o = s_inv[nl * 27 + s];
+              vals_pu[3 * off + s * 3 + d] = s_stage_pu[nl * STG_PU + o * 3 + d];
+            }
+          for (int f = t; f < TX * TY * STG_PP; f += NTHREADS)
+            {
+              const int nl = f / STG_PP, s = f - nl * STG_PP;
+              const long long off = s_off[nl];
+              const int deg = s_deg[nl];
+              if (off < 0 || s >= deg)
+                continue;
+              const int o = s_inv[nl * 27 + s];
+              vals_pp[off + s] = s_stage_pp[nl * STG_PP + o];
+            }
+        }
+      else
+        {
+          // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
+          for (int f = t; f < TX * TY * 27 * 4; f += NTHREADS)
+            {
+              const int nl = f / 108, e = f - nl * 108;
+              const int s = e / 4, d = e - s * 4;
+              const long long off = s_off[nl];
+              const int deg = s_deg[nl];
+              if (off < 0 || s >= deg)
+                continue;
+              const int o = s_inv[nl * 27 + s];
+              const double val = (d < 3) ? s_stage_pu[nl * STG_PU + o * 3 + d] : s_stage_pp[nl * STG_PP + o];
+              vals_uu[16 * off + (long long)3 * 4 * deg + s * 4 + d] = val;
+            }
+        }
+    }
+  } // namespace
+
+  bool cart_matrix_supported(int dim) { return dim == 3; }
+
+  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s)
+  {
+    if (v.dim != 3)
+      return PFM_ERR_UNSUPPORTED;
+    int rc = ensure_g1();
+    if (rc)
+      return rc;
+    // (u,u) rows first: k_cart_phi patches constrained diagonals afterwards (same stream)
+    rc = launch_cart_uu_only(v, cv, p, d_values[0], s);
+    if (rc)
+      return rc;
+    const MatScal S = make_mat_scal(p, cv);
+    const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+    const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;
+    const unsigned nb = (unsigned)(ntx * nty * OWZ);
+    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL(k_cart_phi<4>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, nullptr, nullptr, d_values[0]);
+    else
+      {
+        // the structurally zero (u,phi) block (cracks.cc:2333-2337) is cleared by the host side
+        hipLaunchKernelGGL(k_cart_phi<3>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0]);
+      }
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+} // namespace pfm

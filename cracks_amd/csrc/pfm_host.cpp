@@ -636,7 +636,9 @@ extern "C"
         {
           if (!d_values[b])
             return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
-          if (!cart)
+          // the row-owner kernels write every value once; only the structurally zero (u,phi)
+          // block of the blocked layout has no kernel and is cleared here
+          if (!cart || (c->n_blocks == 4 && b == 1))
             e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
         }
     if (e != hipSuccess)

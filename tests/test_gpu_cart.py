@@ -96,3 +96,46 @@ def test_non_lattice_meshes_fall_back_to_general():
     assert make_context(c).kernel_path == 0
     c = cases.kat_sneddon_2d()  # hanging nodes
     assert make_context(c).kernel_path == 0
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("dim,n,lo,hi", [b for b in BOXES if b[0] == 3] + [(3, (17, 10, 3), -10.0, 10.0)])
+def test_cart_full_matrix_matches_oracle(dim, n, lo, hi, blocked):
+    _full(box_case(dim, n, lo, hi, blocked), path=1)
+
+
+def test_cart_full_monolithic_and_active_set():
+    c = box_case(3, (7, 6, 5), -10.0, 10.0, True, monolithic=True)
+    node, comp = c.layout.node_comp_of_dof()
+    phi_dofs = np.nonzero(comp == 3)[0]
+    c.cu = M.update_constraints(c.mesh, c.layout, M.sneddon_dirichlet_dofs(c.mesh, c.layout), phi_dofs[::5])
+    _full(c, path=1)
+    c.params.use_old_timestep_pf = 1
+    _full(c, path=1)
+
+
+def test_cart_full_vanishing_degradation_uses_mean_diagonal():
+    """kappa = 0 and pf_extra = 0 in whole cells: the (u,u) element diagonal is exactly zero and
+    deal.II's placeholder for constrained rows falls back to the mean |diagonal| of the element."""
+    c = box_case(3, (6, 5, 4), -10.0, 10.0, True)
+    c.params.constant_k = 0.0
+    node, comp = c.layout.node_comp_of_dof()
+    is_phi = comp == 3
+    x = c.mesh.coords[node[is_phi]]
+    dead = x[:, 0] < 0.0  # half of the domain fully broken in the two old steps, reaching the boundary
+    o = c.old.copy()
+    o[np.nonzero(is_phi)[0][dead]] = 0.0
+    c.old, c.oldold = o, o.copy()
+    _full(c, path=1)
+
+
+def test_cart_is_the_default_full_path_for_boxes():
+    c = box_case(3, (5, 5, 5), -10.0, 10.0, True)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    values, res_pde, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    ctx.force_path(0)
+    values_g, res_g, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    for a, b in zip(values, values_g):
+        assert linf_scaled(a, b) < TOL
+    assert linf_scaled(res_pde, res_g) < TOL
