@@ -164,8 +164,6 @@ def main():
     lp = P.build_local_problem(dim, ncell, p, rank)
     h = (20.0 / n) * np.sqrt(dim)
     u, phi, po, poo, flags = synthetic_state(lp.mesh, lp.global_ids, h, dim)
-    if world == 1:
-        lp.mesh.box_shape = ncell
     halo = None
     if world > 1:
         halo = HaloExchange(dim, lp.peers, lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes, dev)

@@ -5,6 +5,7 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace pfm
 {
@@ -17,6 +18,15 @@ namespace pfm
     constexpr int CS = CX * CY * 2;              // 162 cell slots (two layers)
     constexpr int NNUM_UU = 64;                  // 27 A + 36 T + 1 spare
     constexpr int STG = 81;                      // staged row width (27 slots x 3), odd => conflict-free
+    template <int N, class F>
+    __device__ __forceinline__ __attribute__((always_inline)) void static_for(F &&f)
+    {
+      if constexpr (N > 0)
+        {
+          static_for<N - 1>(f);
+          f(std::integral_constant<int, N - 1>{});
+        }
+    }
 
     struct G1
     {

@@ -172,7 +172,8 @@ def build_local_problem(dim: int, n: Sequence[int], p: Sequence[int], rank: int,
         rem //= npg[d]
         bn[2 * d] = np.nonzero(i == 0)[0].astype(np.int32)
         bn[2 * d + 1] = np.nonzero(i == n[d])[0].astype(np.int32)
-    mesh = Mesh(dim=dim, coords=coords, cells=np.ascontiguousarray(cells), boundary_nodes=bn)
+    mesh = Mesh(dim=dim, coords=coords, cells=np.ascontiguousarray(cells), boundary_nodes=bn,
+                box_shape=tuple(lc))  # the local (extended) cell box is itself a uniform lattice
     # halo lists
     ghost_gid = global_ids[n_owned:]
     ghost_owner = owner_of_nodes(n, p, ghost_gid)
