@@ -1,0 +1,48 @@
+"""End-to-end set-ups of reference regression tests for the Newton harness (cracks_amd/newton.py)."""
+import numpy as np
+
+import cases
+import oracle_api as O
+from cracks_amd import mesh as M
+from cracks_amd.newton import ProblemSetup
+
+
+class OracleAssembler:
+    """Assembler protocol backed by the CPU oracle (tests only)."""
+
+    def __init__(self, mesh, layout):
+        self.mesh, self.layout = mesh, layout
+        self.rowptr, self.colind = M.dof_sparsity(mesh, layout)
+
+    def assemble(self, residual_only, sol, old, oldold, params, cu, ch):
+        import scipy.sparse as sp
+
+        p = O.PfmParams.from_buffer_copy(bytes(params))
+        r = O.assemble(self.mesh, self.layout, p, sol, old, oldold, cu, ch, residual_only,
+                       None if residual_only else self.rowptr, None if residual_only else self.colind)
+        if r.err:
+            raise RuntimeError(f"oracle error {r.err}")
+        A = None
+        if not residual_only:
+            A = sp.csr_matrix((r.values, self.colind, self.rowptr), shape=(self.layout.n_dofs,) * 2)
+        return A, r.residual_pde, r.residual_total
+
+
+def miehe_shear_2_setup() -> ProblemSetup:
+    """tests/miehe_shear_2.prm (direct solver, stress split, 256 cells, no refinement)."""
+    c = cases.kat_miehe_shear_2()
+    mesh, lay = c.mesh, c.layout
+    top = mesh.boundary_nodes[3]
+    dd = M.miehe_shear_dirichlet_dofs(mesh, lay)
+
+    def initial_bc(time):
+        vals = {int(d): 0.0 for d in dd}
+        for n in top:  # BoundaryShearTest, cracks.cc:838-858
+            vals[int(lay.dof(n, 0))] = -1.0 * time
+        return vals
+
+    sol0 = lay.pack(np.zeros((mesh.n_nodes, 2)), np.ones(mesh.n_nodes))
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd, initial_bc=initial_bc,
+                        solution0=sol0, E_modulus=1.0e3, timestep=5.0e-4, max_no_timesteps=24,
+                        newton_tol=1.0e-6, max_newton_steps=100, max_line_search=10, line_search_damping=0.6,
+                        compute_load=True)

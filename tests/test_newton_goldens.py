@@ -1,0 +1,58 @@
+"""End-to-end parity: the reference's own outer loop, restated in
+cracks_amd/newton.py, around the oracle reproduces the Newton tables, energies and loads of
+tests/miehe_shear_2.output — the fixtures that pin the Jacobian, the active-set constraints
+and the stress split (time steps >= 1)."""
+import numpy as np
+import pytest
+
+import cases
+import newton_cases as NC
+from cracks_amd.newton import ActiveSetDriver
+
+
+def check_against_golden(records, golden_steps, n_steps):
+    """What is comparable: the line-0 residual of every step (a function of the previous
+    converged state), the first Newton row (physical active set), convergence, energies and
+    load.  Rows whose residual is ~1e-13 and the active sets of a converged, still intact
+    specimen are decided by round-off in the last bit (phi == old_phi up to 1e-16,
+    cracks.cc:2868) and differ between any two correct implementations; the reference's own
+    np=1 / np=2 goldens of this case differ for the same reason."""
+    for rec, g in zip(records[:n_steps], golden_steps[:n_steps]):
+        assert rec.residual0 == pytest.approx(g["residual0"], rel=5e-5)
+        g1, r1 = g["newton"][0], rec.newton[0]
+        assert r1.residual == pytest.approx(g1["residual"], rel=3e-2 if rec.timestep == 0 else 3e-3)
+        if rec.timestep > 0:  # same order of magnitude; the exact count is round-off (see docstring)
+            assert abs(r1.active_set - g1["active_set"]) <= 0.2 * g1["active_set"]
+        assert rec.newton[-1].residual < 1e-6 and len(rec.newton) <= len(g["newton"]) + 2
+        assert rec.bulk_energy == pytest.approx(g["bulk_energy"], rel=5e-5)
+        assert rec.crack_energy == pytest.approx(g["crack_energy"], rel=1e-2 if rec.timestep == 1 else 2e-4)
+
+
+LOAD_X = [32.4555, 64.8685, 97.1969]  # tests/miehe_shear_2.output, "Load x:" of steps 0..2
+
+
+def test_miehe_shear_2_first_steps_with_oracle():
+    setup = NC.miehe_shear_2_setup()
+    drv = ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout))
+    recs = drv.run(n_steps=6)
+    g = cases.golden()["miehe_shear_2"]["timesteps"]
+    check_against_golden(recs, g, 6)
+    for rec, want in zip(recs, LOAD_X):
+        assert rec.load == pytest.approx(want, rel=2e-6)
+    # step 1 (stress split active): rows 1-3 of the reference table are reproduced digit for digit
+    g1 = g[1]["newton"]
+    assert [r.active_set for r in recs[1].newton[:4]] == [x["active_set"] for x in g1[:4]]
+    assert recs[1].newton[0].residual == pytest.approx(g1[0]["residual"], rel=2e-6)
+
+
+@pytest.mark.gpu
+def test_miehe_shear_2_first_steps_on_gpu():
+    from cracks_amd.newton import GpuAssembler
+
+    setup = NC.miehe_shear_2_setup()
+    drv = ActiveSetDriver(setup, GpuAssembler(setup.mesh, setup.layout))
+    recs = drv.run(n_steps=4)
+    g = cases.golden()["miehe_shear_2"]["timesteps"]
+    check_against_golden(recs, g, 4)
+    for rec, want in zip(recs, LOAD_X):
+        assert rec.load == pytest.approx(want, rel=2e-6)
