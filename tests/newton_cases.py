@@ -46,3 +46,14 @@ def miehe_shear_2_setup() -> ProblemSetup:
                         solution0=sol0, E_modulus=1.0e3, timestep=5.0e-4, max_no_timesteps=24,
                         newton_tol=1.0e-6, max_newton_steps=100, max_line_search=10, line_search_damping=0.6,
                         compute_load=True)
+
+
+def sneddon_3d_setup() -> ProblemSetup:
+    """tests/sneddon_3d_1.prm (10^3 cells, iterative solver in the reference; the harness solves exactly)."""
+    c = cases.kat_sneddon_3d()
+    mesh, lay = c.mesh, c.layout
+    dd = M.sneddon_dirichlet_dofs(mesh, lay)
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd,
+                        initial_bc=lambda time: {int(d): 0.0 for d in dd}, solution0=c.sol.copy(), E_modulus=1.0,
+                        timestep=1.0, max_no_timesteps=5, newton_tol=1.0e-7, max_newton_steps=60,
+                        max_line_search=50, line_search_damping=0.6)
