@@ -524,6 +524,8 @@ namespace pfm
 
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
   {
+    if (!getenv("PFM_CART_V1"))
+      return launch_cart_uu3(v, cv, p, vals_uu, s); // third generation (pfm_cart_uu3.hip)
     int rc = ensure_g1();
     if (rc)
       return rc;

@@ -1,0 +1,465 @@
+// pfm_cart_uu3.hip — (u,u) block, row-owner kernel, third generation ("mirrored half-waves").
+//
+// Mathematics: 63 moment tables per cell, see the header of pfm_cart.hip / pfm_cart_matrix.hip.
+//
+// Why a third generation.  k_cart_uu (tile 8x8 nodes, both cell layers + a row staging buffer in
+// LDS = 130 KB) runs ONE workgroup per CU; its phases (halo load, cell phase, node phase, copy-out)
+// are serialised by barriers and every phase's latency is exposed (profiles/r01: VALU active 38 %
+// of the wave cycles, copy-out alone at the HBM write floor).  Forcing the same code to 16 waves
+// per CU gave 1.6x; keeping one cell layer resident and the partial sums in registers did not pay
+// (spills + twice the barriers).  This version halves the TILE instead (8x4 nodes: 45 KB tables +
+// 21 KB staging => two workgroups per CU) and keeps all 64 lanes busy with 32 nodes by splitting
+// the two cell LAYERS over the two halves of each wave:
+//
+//   lanes  0..31  <->  node n, cells below the node plane (a_z = 1)
+//   lanes 32..63  <->  node n, cells above the node plane (a_z = 0)
+//
+// Both halves execute the SAME instruction stream: the tables of the upper layer are stored
+// z-mirrored (index permutation gamma_z -> 2-gamma_z, alpha_z -> 1-alpha_z, sign flip where exactly
+// one z-derivative is involved), so "upper cell, slot (ox,oy,+oz)" looks like "lower cell, slot
+// (ox,oy,-oz)".  A slot with oz = -1 is completed by the lower half while the upper half completes
+// its mirror slot oz = +1; slots with oz = 0 need one cross-half add.
+#include "pfm_internal.h"
+#include "pfm_cart_common.h"
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+namespace pfm
+{
+  namespace
+  {
+    constexpr int T3X = 8, T3Y = 4, NT3 = 512;
+    constexpr int H3X = T3X + 2, H3Y = T3Y + 2, NH3 = H3X * H3Y * 3; // nodal halo 10 x 6 x 3
+    constexpr int C3X = T3X + 1, C3Y = T3Y + 1, CL3 = C3X * C3Y;     // 45 cells per layer
+    constexpr int CS3 = 2 * CL3;                                     // 90 cell slots
+    constexpr int NN3 = T3X * T3Y;                                   // 32 nodes per tile
+    constexpr int NNUM3 = 63;
+
+    __host__ __device__ constexpr int idxA3(int c, int gi, int gj) { return c * 9 + gi * 3 + gj; }
+    __host__ __device__ constexpr int pair3(int lo, int hi) { return lo == 0 ? (hi == 1 ? 0 : 1) : 2; }
+    __host__ __device__ constexpr int idxT3(int p, int al, int be, int g) { return 27 + p * 12 + al * 6 + be * 3 + g; }
+    __host__ __device__ constexpr int sg3(int bit) { return bit ? 1 : -1; }
+
+    template <int C, int D, int AX, int AY, int AZ, int BX, int BY, int BZ>
+    __device__ __forceinline__ double kuu3(const double *__restrict__ lds, const MatScal &S)
+    {
+      constexpr int a[3] = {AX, AY, AZ}, b[3] = {BX, BY, BZ};
+      constexpr int g[3] = {AX + BX, AY + BY, AZ + BZ};
+      if constexpr (C == D)
+        {
+          double r = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            {
+              const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
+              r += (double)(sg3(a[k]) * sg3(b[k])) * S.cA[C][k] * lds[idxA3(k, g[i], g[j]) * CS3];
+            }
+          return r;
+        }
+      else
+        {
+          constexpr int lo = C < D ? C : D, hi = C < D ? D : C, e = 3 - C - D, p = pair3(lo, hi);
+          constexpr int al1 = (C < D) ? b[lo] : a[lo], be1 = (C < D) ? a[hi] : b[hi]; // G^{CD}
+          constexpr int al2 = (C < D) ? a[lo] : b[lo], be2 = (C < D) ? b[hi] : a[hi]; // G^{DC}
+          const double t1 = lds[idxT3(p, al1, be1, g[e]) * CS3];
+          const double t2 = lds[idxT3(p, al2, be2, g[e]) * CS3];
+          return S.cT[p] * (S.lam * (double)(sg3(a[C]) * sg3(b[D])) * t1 + S.mu * (double)(sg3(a[D]) * sg3(b[C])) * t2);
+        }
+    }
+
+    // lower-layer contribution (a_z = 1, b_z = 1 + OZ) of the 4 cells around the node to entry (C, D, slot)
+    template <int C, int D, int OX, int OY, int OZ>
+    __device__ __forceinline__ double uu3_lower(const double *__restrict__ lane_base, const MatScal &S)
+    {
+      static_assert(OZ == -1 || OZ == 0, "only slots below or in the node plane have lower-layer cells");
+      double r = 0.0;
+      auto visit = [&](auto EX, auto EY) __attribute__((always_inline)) {
+        constexpr int ex = decltype(EX)::value, ey = decltype(EY)::value;
+        constexpr int ax = -ex, ay = -ey, bx = ax + OX, by = ay + OY;
+        if constexpr (bx >= 0 && bx <= 1 && by >= 0 && by <= 1)
+          r += kuu3<C, D, ax, ay, 1, bx, by, 1 + OZ>(lane_base + (ey * C3X + ex), S);
+      };
+      using M1 = std::integral_constant<int, -1>;
+      using Z0 = std::integral_constant<int, 0>;
+      visit(M1{}, M1{});
+      visit(Z0{}, M1{});
+      visit(M1{}, Z0{});
+      visit(Z0{}, Z0{});
+      return r;
+    }
+
+    // one slot (given by its in-plane offset and OZ in {-1, 0}) of row component C for both half-waves
+    template <int C, int OX, int OY, int OZ>
+    __device__ __forceinline__ void uu3_slot(const double *__restrict__ lane_base, const MatScal &S, double *__restrict__ stage_row,
+                                             bool upper, bool masked, unsigned row_flag, const unsigned char *__restrict__ s_flag, int hc)
+    {
+      double v0 = uu3_lower<C, 0, OX, OY, OZ>(lane_base, S);
+      double v1 = uu3_lower<C, 1, OX, OY, OZ>(lane_base, S);
+      double v2 = uu3_lower<C, 2, OX, OY, OZ>(lane_base, S);
+      constexpr int o_lo = (OX + 1) + 3 * (OY + 1) + 9 * (OZ + 1);
+      constexpr int o_up = (OX + 1) + 3 * (OY + 1) + 9 * (-OZ + 1);
+      if constexpr (OZ == 0)
+        {
+          // both layers contribute: add the two halves
+          v0 += __shfl_xor(v0, 32);
+          v1 += __shfl_xor(v1, 32);
+          v2 += __shfl_xor(v2, 32);
+          if (upper)
+            return; // the lower half stores
+        }
+      const int o = upper ? o_up : o_lo; // the upper half has completed the mirror slot
+      if (masked)
+        {
+          const int oz = upper ? -OZ : OZ;
+          const unsigned cf = s_flag[hc + OX + H3X * OY + H3X * H3Y * oz];
+          const bool rcon = (row_flag >> C) & 1u;
+          const bool centre = (OX == 0 && OY == 0 && OZ == 0);
+          if (rcon || (cf & 1u))
+            v0 = (rcon && centre && C == 0) ? v0 : 0.0;
+          if (rcon || (cf & 2u))
+            v1 = (rcon && centre && C == 1) ? v1 : 0.0;
+          if (rcon || (cf & 4u))
+            v2 = (rcon && centre && C == 2) ? v2 : 0.0;
+        }
+      stage_row[o * 3 + 0] = v0;
+      stage_row[o * 3 + 1] = v1;
+      stage_row[o * 3 + 2] = v2;
+    }
+
+    // z-symmetric slot sets, 4 lower-layer cell visits per (row, column component) each
+    template <int C, int W>
+    __device__ __forceinline__ void uu3_wave(const double *lane_base, const MatScal &S, double *stage_row, bool upper, bool masked,
+                                             unsigned row_flag, const unsigned char *s_flag, int hc)
+    {
+#define PFM_S(OX, OY, OZ) uu3_slot<C, OX, OY, OZ>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc)
+      if constexpr (W == 0)
+        {
+          PFM_S(0, 0, 0);
+        }
+      else if constexpr (W == 1)
+        {
+          PFM_S(0, 0, -1);
+        }
+      else if constexpr (W == 2)
+        {
+          PFM_S(0, -1, 0);
+          PFM_S(0, 1, 0);
+        }
+      else if constexpr (W == 3)
+        {
+          PFM_S(-1, 0, 0);
+          PFM_S(1, 0, 0);
+        }
+      else if constexpr (W == 4)
+        {
+          PFM_S(0, -1, -1);
+          PFM_S(0, 1, -1);
+        }
+      else if constexpr (W == 5)
+        {
+          PFM_S(-1, 0, -1);
+          PFM_S(1, 0, -1);
+        }
+      else if constexpr (W == 6)
+        {
+          PFM_S(-1, -1, 0);
+          PFM_S(1, -1, 0);
+          PFM_S(-1, 1, 0);
+          PFM_S(1, 1, 0);
+        }
+      else
+        {
+          PFM_S(-1, -1, -1);
+          PFM_S(1, -1, -1);
+          PFM_S(-1, 1, -1);
+          PFM_S(1, 1, -1);
+        }
+#undef PFM_S
+    }
+
+    template <int C>
+    __device__ __forceinline__ void uu3_dispatch(int wave, const double *lane_base, const MatScal &S, double *stage_row, bool upper,
+                                                 bool masked, unsigned row_flag, const unsigned char *s_flag, int hc)
+    {
+      switch (wave)
+        {
+          case 0: uu3_wave<C, 0>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 1: uu3_wave<C, 1>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 2: uu3_wave<C, 2>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 3: uu3_wave<C, 3>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 4: uu3_wave<C, 4>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 5: uu3_wave<C, 5>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 6: uu3_wave<C, 6>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          default: uu3_wave<C, 7>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+        }
+    }
+
+    // =====================================================================================
+    template <int NCOL /* 3 blocked, 4 interleaved */>
+    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, MatScal S, double *__restrict__ vals)
+    {
+      __shared__ double s_tab[NNUM3 * CS3];  // moment tables [number][cell]; layer 1 stored z-mirrored
+      __shared__ double s_stage[NN3 * STG];  // staged rows [node][81]; w*g(q) [27][90] during the cell phase
+      __shared__ double s_po[NH3], s_poo[NH3];
+      __shared__ int s_node[NH3];
+      __shared__ unsigned char s_flag[NH3];
+      __shared__ long long s_rowbase[NN3];
+      __shared__ int s_deg[NN3];
+      __shared__ unsigned char s_inv[NN3 * 27];
+      __shared__ int s_info[2];
+      static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
+
+      const int t = threadIdx.x;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
+      const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
+      const int bid = blockIdx.x;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
+      const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
+
+      // ---- phase 0: nodal halo + CSR row info
+      if (t < 2)
+        s_info[t] = 0;
+      __syncthreads();
+      if (t < NH3)
+        {
+          const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / (H3X * H3Y);
+          const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = k - 1 + lk;
+          int n = -1;
+          double a = 0.0, b = 0.0;
+          unsigned char f = 0;
+          if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ)
+            {
+              n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * gk)];
+              a = v.phi_old[n];
+              b = v.phi_oldold[n];
+              f = v.node_flags[n];
+            }
+          s_node[t] = n;
+          s_po[t] = a;
+          s_poo[t] = b;
+          s_flag[t] = f;
+          if (f & 7u)
+            atomicOr(&s_info[0], 1);
+        }
+      else if (t >= 256 && t < 256 + NN3)
+        {
+          const int nl = t - 256, li = nl % T3X, lj = nl / T3X;
+          const int gi = i0 + li, gj = j0 + lj;
+          long long base = -1;
+          int deg = 0;
+          bool regular = false;
+          if (gi <= cv.o1[0] && gj <= cv.o1[1])
+            {
+              const int r = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * k)];
+              const long long off = v.nadj_ptr[r];
+              deg = (int)(v.nadj_ptr[r + 1] - off);
+              base = (long long)NCOL * NCOL * off;
+              regular = deg == 27;
+              for (int s = 0; s < 27; ++s)
+                {
+                  const unsigned char o = cv.inv27[(long long)r * 27 + s];
+                  s_inv[nl * 27 + s] = o;
+                  regular = regular && o == s;
+                }
+            }
+          s_rowbase[nl] = base;
+          s_deg[nl] = deg;
+          if (!regular)
+            atomicAdd(&s_info[1], 1);
+        }
+      __syncthreads();
+
+      // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
+      if (t < 3 * CS3)
+        {
+          const int cs = t % CS3, qz = t / CS3;
+          const int l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
+          const int h000 = cx + H3X * (cy + H3Y * l);
+          const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + H3X + H3X * H3Y] >= 0;
+          double wg[9];
+          if (valid)
+            {
+              double po[8], poo[8];
+#pragma unroll
+              for (int b = 0; b < 8; ++b)
+                {
+                  const int hb = h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1);
+                  po[b] = s_po[hb];
+                  poo[b] = s_poo[hb];
+                }
+              cell_wg_plane(po, poo, S, qz, wg);
+            }
+          else
+            {
+#pragma unroll
+              for (int q = 0; q < 9; ++q)
+                wg[q] = 0.0;
+            }
+#pragma unroll
+          for (int q = 0; q < 9; ++q)
+            s_stage[(qz * 9 + q) * CS3 + cs] = wg[q];
+        }
+      __syncthreads();
+
+      // ---- cell phase b: moment tables, thread <-> (cell, {A^x, A^y, A^z, T^xy, T^xz, T^yz}).
+      // The upper layer (l = 1) is written z-mirrored so that both half-waves run the same node phase.
+      for (int tt = t; tt < 6 * CS3; tt += NT3)
+        {
+          const int cs = tt % CS3, sub = tt / CS3;
+          const bool mir = cs >= CL3;
+          double *out = s_tab + cs;
+          const double *wq = s_stage + cs;
+          if (sub < 3)
+            {
+              const int c = sub;
+              const int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
+              const int si = (c == 0) ? 3 : 1;
+              const int sj = (c == 2) ? 3 : 9;
+              double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+#pragma unroll
+              for (int qj = 0; qj < 3; ++qj)
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi)
+                  {
+                    const int q0 = qi * si + qj * sj;
+                    s9[qj][qi] = (wq[q0 * CS3] + wq[(q0 + sc) * CS3]) + wq[(q0 + 2 * sc) * CS3];
+                  }
+              const bool zj = (c != 2); // for c = x or y the second moment axis j is z
+#pragma unroll
+              for (int gi = 0; gi < 3; ++gi)
+                {
+                  double tq[3];
+#pragma unroll
+                  for (int qj = 0; qj < 3; ++qj)
+                    tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
+#pragma unroll
+                  for (int gj = 0; gj < 3; ++gj)
+                    {
+                      const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
+                      const int gjs = (mir && zj) ? 2 - gj : gj;
+                      out[(c * 9 + gi * 3 + gjs) * CS3] = val;
+                    }
+                }
+            }
+          else
+            {
+              const int p = sub - 3; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
+              const int slo = (p == 2) ? 3 : 1;
+              const int shi = (p == 0) ? 3 : 9;
+              const int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
+#pragma unroll
+              for (int al = 0; al < 2; ++al)
+                {
+                  double t1[3][3]; // [q_e][q_hi]
+#pragma unroll
+                  for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                    for (int qh = 0; qh < 3; ++qh)
+                      {
+                        const int q0 = qh * shi + qe * se;
+                        t1[qe][qh] = (wq[q0 * CS3] * c_g1.n[al][0] + wq[(q0 + slo) * CS3] * c_g1.n[al][1]) +
+                                     wq[(q0 + 2 * slo) * CS3] * c_g1.n[al][2];
+                      }
+#pragma unroll
+                  for (int be = 0; be < 2; ++be)
+                    {
+                      double t2[3];
+#pragma unroll
+                      for (int qe = 0; qe < 3; ++qe)
+                        t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
+#pragma unroll
+                      for (int g = 0; g < 3; ++g)
+                        {
+                          double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
+                          int bes = be, gs = g;
+                          if (mir)
+                            {
+                              if (p == 0)
+                                gs = 2 - g; // e = z
+                              else
+                                {
+                                  bes = 1 - be; // hi = z carries n_be(q_z): one z-derivative => sign flip
+                                  val = -val;
+                                }
+                            }
+                          out[(27 + p * 12 + al * 6 + bes * 3 + gs) * CS3] = val;
+                        }
+                    }
+                }
+            }
+        }
+      __syncthreads();
+
+      // ---- node phase + copy-out per row component
+      const int wave = t >> 6, lane = t & 63;
+      const bool upper = lane >= 32;
+      const int nl_lane = lane & 31;
+      const int ti = nl_lane % T3X, tj = nl_lane / T3X;
+      const int hc = (ti + 1) + H3X * ((tj + 1) + H3Y * 1);
+      const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
+      const bool masked = s_info[0] != 0;
+      const bool regular_tile = (NCOL == 3) && s_info[1] == 0;
+      const unsigned row_flag = s_flag[hc];
+      // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
+      const double *lane_base = s_tab + (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1);
+      double *stage_row = s_stage + nl_lane * STG;
+
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c)
+        {
+          // all 64 lanes take part (cross-half adds); stores of tiles' non-owned nodes are dropped at copy-out
+          if (c == 0)
+            uu3_dispatch<0>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+          else if (c == 1)
+            uu3_dispatch<1>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+          else
+            uu3_dispatch<2>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+          __syncthreads();
+          if (regular_tile)
+            {
+#pragma unroll 2
+              for (int f = t; f < NN3 * STG; f += NT3)
+                {
+                  const int nl = f / STG;
+                  vals[s_rowbase[nl] + c * STG + (f - nl * STG)] = s_stage[f];
+                }
+            }
+          else
+            {
+              constexpr int rowlen = 27 * NCOL;
+              for (int f = t; f < NN3 * rowlen; f += NT3)
+                {
+                  const int nl = f / rowlen, e = f - nl * rowlen;
+                  const int s = e / NCOL, d = e - s * NCOL;
+                  const long long base = s_rowbase[nl];
+                  const int deg = s_deg[nl];
+                  if (base < 0 || s >= deg)
+                    continue;
+                  const int o = s_inv[nl * 27 + s];
+                  const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
+                  vals[base + (long long)c * NCOL * deg + s * NCOL + d] = val;
+                }
+            }
+          __syncthreads();
+        }
+      (void)owned;
+    }
+  } // namespace
+
+  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
+  {
+    int rc = ensure_g1();
+    if (rc)
+      return rc;
+    const MatScal S = make_mat_scal(p, cv);
+    const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+    const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
+    const unsigned nb = (unsigned)(ntx * nty * OWZ);
+    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu);
+    else
+      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+} // namespace pfm

@@ -59,6 +59,7 @@ namespace pfm
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s);
   bool cart_matrix_supported(int dim);
+  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
