@@ -28,6 +28,13 @@ namespace pfm
         }
     }
 
+    // third-generation tiles (pfm_cart_uu3.hip, pfm_cart_phi3.hip): 8 x 4 nodes, 512 threads
+    constexpr int T3X = 8, T3Y = 4, NT3 = 512;
+    constexpr int H3X = T3X + 2, H3Y = T3Y + 2, NH3 = H3X * H3Y * 3; // nodal halo 10 x 6 x 3
+    constexpr int C3X = T3X + 1, C3Y = T3Y + 1, CL3 = C3X * C3Y;     // 45 cells per layer
+    constexpr int CS3 = 2 * CL3;                                     // 90 cell slots
+    constexpr int NN3 = T3X * T3Y;                                   // 32 nodes per tile
+
     struct G1
     {
       double n[2][3], m[3][3], w[3]; // n_al(q), m_g(q) (g = 0:00, 1:01, 2:11), weights

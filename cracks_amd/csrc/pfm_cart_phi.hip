@@ -17,6 +17,7 @@
 #include "pfm_cart_common.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 
 namespace pfm

@@ -29,11 +29,6 @@ namespace pfm
 {
   namespace
   {
-    constexpr int T3X = 8, T3Y = 4, NT3 = 512;
-    constexpr int H3X = T3X + 2, H3Y = T3Y + 2, NH3 = H3X * H3Y * 3; // nodal halo 10 x 6 x 3
-    constexpr int C3X = T3X + 1, C3Y = T3Y + 1, CL3 = C3X * C3Y;     // 45 cells per layer
-    constexpr int CS3 = 2 * CL3;                                     // 90 cell slots
-    constexpr int NN3 = T3X * T3Y;                                   // 32 nodes per tile
     constexpr int NNUM3 = 63;
 
     __host__ __device__ constexpr int idxA3(int c, int gi, int gj) { return c * 9 + gi * 3 + gj; }
