@@ -94,38 +94,48 @@ namespace pfm
     }
 
     // =====================================================================================
-    // Residual, row owner: one lane per owned node, loop over its 2^dim cells
-    // (cracks.cc:2393-2432 gathered per test vertex).
+    // Residual, row owner (cracks.cc:2393-2432 gathered per test vertex).  One wave covers 63
+    // x-consecutive owned nodes of one lattice row (+ 1 halo lane): lane l evaluates the q-point state
+    // of the 2^(dim-1) cells to the RIGHT of its node once and integrates it against the test functions
+    // of both x-neighbours of the cell (a_x = 0: its own node, a_x = 1: the node of lane l+1, handed over
+    // with one wave shift).  Every cell column is thus evaluated once per (j,k) row instead of twice.
     // =====================================================================================
     template <int dim>
-    __global__ __launch_bounds__(128) void k_cart_residual(DevView v, CartView cv, Scal S,
+    __global__ __launch_bounds__(256) void k_cart_residual(DevView v, CartView cv, Scal S,
                                                            double *__restrict__ res_pde,
                                                            double *__restrict__ res_tot, int write_total)
     {
       constexpr int nv = 1 << dim, nc = dim + 1;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
-      const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-      if (t >= v.n_owned)
-        return;
-      const int i = cv.o0[0] + (int)(t % OWX);
-      const int j = cv.o0[1] + (int)((t / OWX) % OWY);
-      const int k = dim == 3 ? cv.o0[2] + (int)(t / ((long long)OWX * OWY)) : 0;
-      const int row = cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+      const int OWZ = dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
+      const int lane = threadIdx.x & 63;
+      const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      const int chunks = (OWX + 62) / 63;
+      const long long n_rows = (long long)OWY * OWZ;
+      if (wave >= n_rows * chunks)
+        return; // whole wave
+      const int chunk = (int)(wave % chunks);
+      const long long rowid = wave / chunks;
+      const int j = cv.o0[1] + (int)(rowid % OWY);
+      const int k = dim == 3 ? cv.o0[2] + (int)(rowid / OWY) : 0;
+      const int xi = chunk * 63 + lane - 1; // lane 0 is the halo lane of the chunk
+      const int i = cv.o0[0] + xi;
 
       const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = dim == 3 ? 1.0 / cv.h[2] : 0.0;
       const double vol = cv.h[0] * cv.h[1] * (dim == 3 ? cv.h[2] : 1.0);
-      double R[nc];
+      double R0[nc], R1[nc]; // contributions to node i (a_x = 0) and to node i+1 (a_x = 1)
 #pragma unroll
       for (int c = 0; c < nc; ++c)
-        R[c] = 0.0;
+        R0[c] = R1[c] = 0.0;
 
-#pragma unroll
-      for (int e = 0; e < nv; ++e)
+      const int ci = i; // the cell column to the right of node i
+      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && xi < OWX;
+#pragma unroll 1
+      for (int e = 0; e < nv / 2; ++e)
         {
-          // cell (i+ex, j+ey, k+ez), e in {-1,0}^dim; this node is its vertex a = -e
-          const int ax = (e & 1), ay = (e >> 1) & 1, az = (e >> 2) & 1;
-          const int ci = i - ax, cj = j - ay, ck = k - az;
-          if (ci < 0 || ci >= cv.NX - 1 || cj < 0 || cj >= cv.NY - 1)
+          const int ay = e & 1, az = (e >> 1) & 1;
+          const int cj = j - ay, ck = k - az;
+          if (!col_ok || cj < 0 || cj >= cv.NY - 1)
             continue;
           if (dim == 3 && (ck < 0 || ck >= cv.NZ - 1))
             continue;
@@ -145,9 +155,9 @@ namespace pfm
               U[dim + 2][b] = v.phi_oldold[n];
             }
           constexpr int NZQ = dim == 3 ? 3 : 1;
+#pragma unroll 1
           for (int qz = 0; qz < NZQ; ++qz)
             {
-              // collapse z: plane values P[f][vy][vx] and z-derivatives Dz[f][vy][vx]
               double Pl[dim + 3][4], Dz[dim + 1][4];
               const double nz0 = dim == 3 ? c_t1.n[0][qz] : 1.0, nz1 = dim == 3 ? c_t1.n[1][qz] : 0.0;
 #pragma unroll
@@ -172,6 +182,7 @@ namespace pfm
                   }
               const double naz = dim == 3 ? (az ? nz1 : nz0) : 1.0;
               const double wz = dim == 3 ? c_t1.w[qz] : 1.0;
+#pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
                 {
                   const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy];
@@ -191,7 +202,6 @@ namespace pfm
                       }
                   const double nay = ay ? ny1 : ny0;
                   const double wyz = c_t1.w[qy] * wz;
-                  // x-derivatives do not depend on qx
                   double Dx[dim + 1];
 #pragma unroll
                   for (int f = 0; f < dim + 1; ++f)
@@ -242,44 +252,59 @@ namespace pfm
                             E[a][b] = 0.5 * (gu[a][b] + gu[b][a]);
                           trE += E[a][a];
                         }
-                      double sp[dim][dim], spE = 0.0;
+                      // Z = (g sigma+ - (alpha_B-1) p pfx^2 I) JxW, scalar part of the phi row
+                      double Z[dim][dim], spE = 0.0;
 #pragma unroll
                       for (int a = 0; a < dim; ++a)
 #pragma unroll
                         for (int b = 0; b < dim; ++b)
                           {
-                            sp[a][b] = S.lam * trE * (a == b ? 1.0 : 0.0) + 2 * S.mu * E[a][b];
-                            spE += sp[a][b] * E[a][b];
+                            const double sp = S.lam * trE * (a == b ? 1.0 : 0.0) + 2 * S.mu * E[a][b];
+                            spE += sp * E[a][b];
+                            Z[a][b] = (g * sp - (a == b ? S.aB1 * S.p * pfx * pfx : 0.0)) * JxW;
                           }
-                      // test function of vertex a at q
-                      const double nax = ax ? nx1 : nx0;
-                      const double Na = nax * nay * naz;
-                      double gNa[dim];
-                      gNa[0] = (ax ? ihx : -ihx) * nay * naz;
-                      gNa[1] = (ay ? ihy : -ihy) * nax * naz;
-                      if constexpr (dim == 3)
-                        gNa[2] = (az ? ihz : -ihz) * nax * nay;
+                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
+                                         2.0 * S.aB1 * S.p * pf * divu) *
+                                        JxW;
+                      const double ge = S.Gc * S.eps * JxW;
+                      // test functions of the two x-neighbours of the cell at q
 #pragma unroll
-                      for (int c = 0; c < dim; ++c)
+                      for (int ax = 0; ax < 2; ++ax)
                         {
-                          double tt = 0.0;
+                          const double nax = ax ? nx1 : nx0;
+                          double gNa[dim];
+                          gNa[0] = (ax ? ihx : -ihx) * nay * naz;
+                          gNa[1] = (ay ? ihy : -ihy) * nax * naz;
+                          if constexpr (dim == 3)
+                            gNa[2] = (az ? ihz : -ihz) * nax * nay;
+                          double *R = ax ? R1 : R0;
+#pragma unroll
+                          for (int c = 0; c < dim; ++c)
+                            {
+                              double tt = 0.0;
+#pragma unroll
+                              for (int kk = 0; kk < dim; ++kk)
+                                tt += Z[c][kk] * gNa[kk];
+                              R[c] -= tt;
+                            }
+                          double gg = 0.0;
 #pragma unroll
                           for (int kk = 0; kk < dim; ++kk)
-                            tt += g * sp[c][kk] * gNa[kk];
-                          R[c] -= (tt - S.aB1 * S.p * pfx * pfx * gNa[c]) * JxW;
+                            gg += gpf[kk] * gNa[kk];
+                          R[dim] -= rq * (nax * nay * naz) + ge * gg;
                         }
-                      double gg = 0.0;
-#pragma unroll
-                      for (int kk = 0; kk < dim; ++kk)
-                        gg += gpf[kk] * gNa[kk];
-                      R[dim] -= S.gamma_fac * pen * Na * JxW;
-                      R[dim] -= ((1.0 - S.kappa) * spE * pf * Na - S.Gc / S.eps * (1.0 - pf) * Na + S.Gc * S.eps * gg -
-                                 2.0 * S.aB1 * S.p * pf * divu * Na) *
-                                JxW;
                     }
                 }
             }
         }
+      // node i = own a_x = 0 part + the a_x = 1 part of the cell column on its left (lane - 1)
+      double R[nc];
+#pragma unroll
+      for (int c = 0; c < nc; ++c)
+        R[c] = R0[c] + __shfl_up(R1[c], 1);
+      if (lane == 0 || xi >= OWX)
+        return;
+      const int row = cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
       // constrained scatter degenerates to a masked store (cracks.cc:2440-2456)
       const unsigned fl = v.node_flags[row];
 #pragma unroll
@@ -322,8 +347,10 @@ namespace pfm
     if ((p.decompose_stress_matrix > 0 || p.decompose_stress_rhs > 0) && p.timestep_number > 0)
       return PFM_ERR_UNSUPPORTED; // the host routes split runs to the general path
     const Scal S = make_scal(p, cv, v.dim);
-    const int bs = 128;
-    const unsigned nb = (unsigned)((v.n_owned + bs - 1) / bs);
+    const int bs = 256;
+    const long long OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = v.dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
+    const long long n_waves = OWY * OWZ * ((OWX + 62) / 63);
+    const unsigned nb = (unsigned)((n_waves + 3) / 4);
     if (v.dim == 2)
       hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
     else
