@@ -17,6 +17,7 @@
 #include "pfm_cart_common.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -140,7 +141,7 @@ namespace pfm
     __device__ __forceinline__ void pu_wave(const double *lane_base, const MatScal &S, double *stage_row, int d,
                                             unsigned row_flag, const unsigned char *nbf)
     {
-#define PFM_X(O) pu_slot<O>(lane_base, S, stage_row, d, row_flag, nbf[O])
+#define PFM_X(O) pu_slot<O>(lane_base, S, stage_row, d, row_flag, nbf[((O) % 3 - 1) + HX * (((O) / 3) % 3 - 1) + HX * HY * ((O) / 9 - 1)])
       PFM_FOR_WAVE_SLOTS(W, PFM_X)
 #undef PFM_X
     }
@@ -149,17 +150,29 @@ namespace pfm
     __device__ __forceinline__ void pp_wave(const double *lane_base, double *stage_row, unsigned row_flag,
                                             const unsigned char *nbf, double &uu_patch)
     {
-#define PFM_X(O) pp_slot<O>(lane_base, stage_row, row_flag, nbf[O], uu_patch)
+#define PFM_X(O) pp_slot<O>(lane_base, stage_row, row_flag, nbf[((O) % 3 - 1) + HX * (((O) / 3) % 3 - 1) + HX * HY * ((O) / 9 - 1)], uu_patch)
       PFM_FOR_WAVE_SLOTS(W, PFM_X)
 #undef PFM_X
     }
 
     // =====================================================================================
-    template <int NCOL>
+    template <int NCOL, bool CLK = false /* profiling only: per-phase cycle counts of wave 0 */>
     __global__ __launch_bounds__(NTHREADS) void k_cart_phi(DevView v, CartView cv, MatScal S,
                                                            double *__restrict__ vals_pu, double *__restrict__ vals_pp,
-                                                           double *__restrict__ vals_uu)
+                                                           double *__restrict__ vals_uu,
+                                                           unsigned long long *__restrict__ dbg)
     {
+      long long tclk = 0;
+      auto stamp = [&](int phase) __attribute__((always_inline)) {
+        if constexpr (CLK)
+          {
+            const long long now = clock64();
+            if (threadIdx.x == 0 && phase >= 0)
+              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+            tclk = now;
+          }
+      };
+      stamp(-1);
       __shared__ double s_buf[NNUM_PHI * CS];
       __shared__ double s_stage_pu[TX * TY * STG_PU];
       __shared__ double s_stage_pp[TX * TY * STG_PP];
@@ -223,16 +236,14 @@ namespace pfm
           s_deg[nl] = deg;
         }
       __syncthreads();
+      stamp(0);
 
       const int wave = t >> 6, lane = t & 63;
       const int ti = lane % TX, tj = lane / TX;
       const int hc = (ti + 1) + HX * ((tj + 1) + HY * 1);
       const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
       const unsigned row_flag = s_flag[hc];
-      unsigned char nbf[27];
-#pragma unroll
-      for (int o = 0; o < 27; ++o)
-        nbf[o] = s_flag[hc + (o % 3 - 1) + HX * ((o / 3) % 3 - 1) + HX * HY * (o / 9 - 1)];
+      const unsigned char *nbf = s_flag + hc; // flags of the 27 neighbours, read per slot (saves 27 live VGPRs)
       const double *lane_base = s_buf + (CX * CY) + (tj + 1) * CX + (ti + 1);
 
       // ---- (phi,u): one sub-phase per column component d
@@ -240,9 +251,13 @@ namespace pfm
 #pragma unroll 1
       for (int d = 0; d < 3; ++d)
         {
-          if (t < 3 * CS)
+          // Launder the thread id: everything below is invariant in d and would otherwise be hoisted out of
+          // the loop and kept live across the three sub-phases (register spills = scratch traffic to HBM).
+          int tq = t;
+          asm volatile("" : "+v"(tq));
+          if (tq < 3 * CS)
             {
-              const int cs = t % CS, kk = t / CS; // derivative axis k of this thread
+              const int cs = tq % CS, kk = tq / CS; // derivative axis k of this thread
               const int l = cs / (CX * CY), cy = (cs % (CX * CY)) / CX, cx = cs % CX;
               const int h000 = cx + HX * (cy + HY * l);
               const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
@@ -350,6 +365,7 @@ namespace pfm
                 }
             }
           __syncthreads();
+          stamp(1);
           if (owned)
             {
               double *stage_row = s_stage_pu + lane * STG_PU;
@@ -366,6 +382,7 @@ namespace pfm
                 }
             }
           __syncthreads();
+          stamp(2);
         }
 
       // ---- (phi,phi) cell phase, step 1: thread <-> (cell, qz) : partial moments over (qx,qy)
@@ -490,6 +507,7 @@ namespace pfm
             }
         }
       __syncthreads();
+      stamp(3);
       // ---- (phi,phi) cell phase, step 2: thread <-> (cell, gz): finish the z moment, add the Laplace part
       if (t < 3 * CS)
         {
@@ -523,6 +541,7 @@ namespace pfm
               }
         }
       __syncthreads();
+      stamp(4);
       // ---- (phi,phi) cell phase, step 3: mean |diagonal| of the element matrix (deal.II uses it as
       // the placeholder of a constrained row whose own diagonal entry is exactly zero)
       if (t < CS)
@@ -579,6 +598,7 @@ namespace pfm
           out[N_GZERO * CS] = gzero;
         }
       __syncthreads();
+      stamp(5);
 
       // ---- (phi,phi) node phase
       double uu_patch = 0.0;
@@ -613,6 +633,7 @@ namespace pfm
             }
         }
       __syncthreads();
+      stamp(6);
 
       // ---- copy-out of the phase-field rows
       if constexpr (NCOL == 3)
@@ -655,6 +676,11 @@ namespace pfm
               vals_uu[16 * off + (long long)3 * 4 * deg + s * 4 + d] = val;
             }
         }
+      if constexpr (CLK)
+        {
+          __syncthreads();
+          stamp(7);
+        }
     }
   } // namespace
 
@@ -676,11 +702,28 @@ namespace pfm
     const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_phi<4>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, nullptr, nullptr, d_values[0]);
+      hipLaunchKernelGGL(k_cart_phi<4>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr);
+    else if (getenv("PFM_PHI_CLK")) // profiling only
+      {
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+          return PFM_ERR_HIP;
+        hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        hipLaunchKernelGGL((k_cart_phi<3, true>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, d_values[2], d_values[3],
+                           d_values[0], d_dbg);
+        unsigned long long h[16];
+        hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char *names[8] = {"phase0", "pu-cell(x3)", "pu-node(x3)", "pp-step1", "pp-step2", "pp-step3", "pp-node", "copy-out"};
+        fprintf(stderr, "[k_cart_phi phase clock, thread 0, cycles per tile]");
+        for (int i = 0; i < 8; ++i)
+          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
+        fprintf(stderr, "\n");
+      }
     else
       {
         // the structurally zero (u,phi) block (cracks.cc:2333-2337) is cleared by the host side
-        hipLaunchKernelGGL(k_cart_phi<3>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0]);
+        hipLaunchKernelGGL(k_cart_phi<3>, dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0],
+                           nullptr);
       }
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
