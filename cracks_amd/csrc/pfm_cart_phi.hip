@@ -127,6 +127,133 @@ namespace pfm
       stage_row[O] = val;
     }
 
+
+    // (phi,u) cell tables C^{dk}[al][g1][g2] of one (cell, derivative axis kk) pair for the column component d.
+    // Local frame: axis 0 = kk, axes 1 < 2 the two others.  Everything that depends on the role of d in that
+    // frame is expressed through per-lane strides and 0/1 masks, so the quadrature loop has no branches;
+    // ANYDIAG = some lane of the wave has d == kk (trace and pressure terms present).
+    template <bool ANYDIAG>
+    __device__ __forceinline__ void pu_cell(const double (*__restrict__ s_u)[NH], const double *__restrict__ s_phi,
+                                            int h000, int kk, int d, const MatScal &S, double *__restrict__ out)
+    {
+      const int ai = (kk == 0) ? 1 : 0, aj = (kk == 2) ? 1 : 2;
+      const bool diag = d == kk;
+      auto hstride = [](int a) { return a == 0 ? 1 : (a == 1 ? HX : HX * HY); };
+      const int st0 = hstride(kk), st1 = hstride(ai), st2 = hstride(aj);
+      const double ih0 = kk == 0 ? S.ih[0] : (kk == 1 ? S.ih[1] : S.ih[2]);
+      // frame of u_k for d/dx_d u_k: derivative axis d, remaining axis aB (diag lanes: any valid frame, masked below)
+      const int aB = diag ? aj : 3 - kk - d;
+      const int stD = diag ? st1 : hstride(d), stB = hstride(aB);
+      const bool Bis2 = aB == aj; // the weight of axis aB is n(q2), otherwise n(q1)
+      const double ihd = S.ih[d];
+      const double *uk = s_u[0] + kk * NH + h000, *ud = s_u[d] + h000, *ph = s_phi + h000;
+
+      double dk[4], dd[4], PH[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        {
+          const int b1 = e & 1, b2 = e >> 1;
+          dk[e] = (ud[st0 + b1 * st1 + b2 * st2] - ud[b1 * st1 + b2 * st2]) * ih0;  // d/dx_k u_d at (b1,b2)
+          dd[e] = (uk[b1 * st0 + stD + b2 * stB] - uk[b1 * st0 + b2 * stB]) * ihd;   // d/dx_d u_k at (b0,bB)
+        }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        PH[b] = ph[(b & 1) * st0 + ((b >> 1) & 1) * st1 + ((b >> 2) & 1) * st2];
+      const double c_muh = 2.0 * (1.0 - S.kappa) * S.mu;
+      double di[4], dj[4], cl = 0.0, cd = 0.0;
+      if constexpr (ANYDIAG)
+        {
+          const double *ui = s_u[0] + ai * NH + h000, *uj = s_u[0] + aj * NH + h000;
+          const double ih1 = ai == 0 ? S.ih[0] : S.ih[1], ih2 = aj == 1 ? S.ih[1] : S.ih[2];
+          const double mi = diag ? ih1 : 0.0, mj = diag ? ih2 : 0.0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            {
+              const int b0 = e & 1, bo = e >> 1;
+              di[e] = (ui[b0 * st0 + st1 + bo * st2] - ui[b0 * st0 + bo * st2]) * mi; // d/dx_i u_i at (b0,b2)
+              dj[e] = (uj[b0 * st0 + bo * st1 + st2] - uj[b0 * st0 + bo * st1]) * mj; // d/dx_j u_j at (b0,b1)
+            }
+          cl = diag ? 2.0 * (1.0 - S.kappa) * S.lam : 0.0;
+          cd = diag ? -2.0 * S.aB1 * S.p : 0.0;
+        }
+      double wn[2][3]; // vol * w(q0) * n_al(q0)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        {
+          wn[0][q] = S.vol * c_g1.w[q] * c_g1.n[0][q];
+          wn[1][q] = S.vol * c_g1.w[q] * c_g1.n[1][q];
+        }
+      double t1[2][3][3]; // [al][q2][q1], the q0 contraction done on the fly
+#pragma unroll
+      for (int q2 = 0; q2 < 3; ++q2)
+        {
+          const double n2a = c_g1.n[0][q2], n2b = c_g1.n[1][q2];
+          double s0 = 0.0, s1 = 0.0;
+          if constexpr (ANYDIAG)
+            {
+              s0 = n2a * di[0] + n2b * di[2];
+              s1 = n2a * di[1] + n2b * di[3];
+            }
+#pragma unroll
+          for (int q1 = 0; q1 < 3; ++q1)
+            {
+              const double n1a = c_g1.n[0][q1], n1b = c_g1.n[1][q1];
+              const double w00 = n1a * n2a, w10 = n1b * n2a, w01 = n1a * n2b, w11 = n1b * n2b;
+              const double gk = w00 * dk[0] + w10 * dk[1] + w01 * dk[2] + w11 * dk[3];
+              const double p0 = w00 * PH[0] + w10 * PH[2] + w01 * PH[4] + w11 * PH[6];
+              const double p1 = w00 * PH[1] + w10 * PH[3] + w01 * PH[5] + w11 * PH[7];
+              const double nBa = Bis2 ? n2a : n1a, nBb = Bis2 ? n2b : n1b;
+              double r0 = nBa * dd[0] + nBb * dd[2], r1 = nBa * dd[1] + nBb * dd[3];
+              double A = c_muh * gk, sv0 = 0.0, sv1 = 0.0;
+              if constexpr (ANYDIAG)
+                {
+                  r0 = diag ? gk : r0; // d == k: d/dx_d u_k is d/dx_k u_d
+                  r1 = diag ? gk : r1;
+                  sv0 = s0 + (n1a * dj[0] + n1b * dj[2]);
+                  sv1 = s1 + (n1a * dj[1] + n1b * dj[3]);
+                  A += cl * gk + cd;
+                }
+              double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+              for (int q0 = 0; q0 < 3; ++q0)
+                {
+                  const double n0a = c_g1.n[0][q0], n0b = c_g1.n[1][q0];
+                  double pf = n0a * p0 + n0b * p1;
+                  if (S.monolithic)
+                    pf = fmax(0.0, pf); // cracks.cc:2251-2256
+                  const double gd = n0a * r0 + n0b * r1;
+                  double br = c_muh * gd + A; // 4(1-kappa) mu E_dk
+                  if constexpr (ANYDIAG)
+                    br += cl * (n0a * sv0 + n0b * sv1); // + [2(1-kappa) lambda trE - 2(alpha_B-1) p] delta_dk
+                  const double Phi = pf * br;
+                  acc0 += Phi * wn[0][q0];
+                  acc1 += Phi * wn[1][q0];
+                }
+              t1[0][q2][q1] = acc0;
+              t1[1][q2][q1] = acc1;
+            }
+        }
+      double wm[3][3]; // w(q) m_g(q)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          wm[g][q] = c_g1.w[q] * c_g1.m[g][q];
+#pragma unroll
+      for (int al = 0; al < 2; ++al)
+#pragma unroll
+        for (int g1 = 0; g1 < 3; ++g1)
+          {
+            double t2[3];
+#pragma unroll
+            for (int q2 = 0; q2 < 3; ++q2)
+              t2[q2] = t1[al][q2][0] * wm[g1][0] + t1[al][q2][1] * wm[g1][1] + t1[al][q2][2] * wm[g1][2];
+#pragma unroll
+            for (int g2 = 0; g2 < 3; ++g2)
+              out[(al * 9 + g1 * 3 + g2) * CS] = t2[0] * wm[g2][0] + t2[1] * wm[g2][1] + t2[2] * wm[g2][2];
+          }
+    }
+
 #define PFM_FOR_WAVE_SLOTS(W, X) \
   if constexpr (W == 0) { X(13); } \
   else if constexpr (W == 1) { X(4); X(22); } \
@@ -182,8 +309,12 @@ namespace pfm
       __shared__ long long s_off[TX * TY]; // node-graph offset of the row, -1 = not an owned node of the tile
       __shared__ int s_deg[TX * TY];
       __shared__ unsigned char s_inv[TX * TY * 27];
+      __shared__ int s_irregular; // number of tile nodes that are not owned interior nodes with identity slot order
 
       const int t = threadIdx.x;
+      if (t == 0)
+        s_irregular = 0;
+      __syncthreads();
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;
       const int bid = blockIdx.x;
@@ -224,16 +355,24 @@ namespace pfm
           const int gi = i0 + li, gj = j0 + lj;
           long long off = -1;
           int deg = 0;
+          bool regular = false;
           if (gi <= cv.o1[0] && gj <= cv.o1[1])
             {
               const int r = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * k0)];
               off = v.nadj_ptr[r];
               deg = (int)(v.nadj_ptr[r + 1] - off);
+              regular = deg == 27;
               for (int s = 0; s < 27; ++s)
-                s_inv[nl * 27 + s] = cv.inv27[(long long)r * 27 + s];
+                {
+                  const unsigned char o = cv.inv27[(long long)r * 27 + s];
+                  s_inv[nl * 27 + s] = o;
+                  regular = regular && o == s;
+                }
             }
           s_off[nl] = off;
           s_deg[nl] = deg;
+          if (!regular)
+            atomicAdd(&s_irregular, 1);
         }
       __syncthreads();
       stamp(0);
@@ -247,7 +386,6 @@ namespace pfm
       const double *lane_base = s_buf + (CX * CY) + (tj + 1) * CX + (ti + 1);
 
       // ---- (phi,u): one sub-phase per column component d
-      const double cdiag = -2.0 * S.aB1 * S.p;
 #pragma unroll 1
       for (int d = 0; d < 3; ++d)
         {
@@ -267,102 +405,10 @@ namespace pfm
                   for (int m = 0; m < 18; ++m)
                     out[m * CS] = 0.0;
                 }
+              else if (__any(d == kk))
+                pu_cell<true>(s_u, s_phi, h000, kk, d, S, out);
               else
-                {
-                  // local frame: axis 0 = k, axes 1,2 = the two others (ascending)
-                  const int ai = (kk == 0) ? 1 : 0, aj = (kk == 2) ? 1 : 2;
-                  const int hs[3] = {1, HX, HX * HY};
-                  const int st0 = hs[kk], st1 = hs[ai], st2 = hs[aj];
-                  const double ih0 = S.ih[kk], ih1 = S.ih[ai], ih2 = S.ih[aj];
-                  const int ld = (d == kk) ? 0 : (d == ai ? 1 : 2); // local index of axis d
-                  double Uk[8], Ud[8], Ui[8], Uj[8], PH[8];
-#pragma unroll
-                  for (int b = 0; b < 8; ++b)
-                    {
-                      const int hb = h000 + (b & 1) * st0 + ((b >> 1) & 1) * st1 + ((b >> 2) & 1) * st2;
-                      Uk[b] = s_u[kk][hb];
-                      Ud[b] = s_u[d][hb];
-                      Ui[b] = s_u[ai][hb];
-                      Uj[b] = s_u[aj][hb];
-                      PH[b] = s_phi[hb];
-                    }
-                  // edge differences for the gradients along local axes 0, 1, 2
-                  double dk_ud[4], dd_uk[4], di_ui[4], dj_uj[4];
-#pragma unroll
-                  for (int e = 0; e < 4; ++e)
-                    {
-                      const int b1 = e & 1, b2 = e >> 1;
-                      dk_ud[e] = (Ud[1 + 2 * b1 + 4 * b2] - Ud[2 * b1 + 4 * b2]) * ih0; // d/dx_k u_d   at (b1,b2)
-                      // d/dx_d u_k along local axis ld, indexed by the two remaining local axes (ascending)
-                      if (ld == 0)
-                        dd_uk[e] = (Uk[1 + 2 * b1 + 4 * b2] - Uk[2 * b1 + 4 * b2]) * ih0;
-                      else if (ld == 1)
-                        dd_uk[e] = (Uk[b1 + 2 + 4 * b2] - Uk[b1 + 4 * b2]) * ih1; // (b0 = e&1, b2 = e>>1)
-                      else
-                        dd_uk[e] = (Uk[b1 + 2 * b2 + 4] - Uk[b1 + 2 * b2]) * ih2; // (b0 = e&1, b1 = e>>1)
-                      di_ui[e] = (Ui[b1 + 2 + 4 * b2] - Ui[b1 + 4 * b2]) * ih1; // (b0, b2)
-                      dj_uj[e] = (Uj[b1 + 2 * b2 + 4] - Uj[b1 + 2 * b2]) * ih2; // (b0, b1)
-                    }
-                  const bool diag = (ld == 0);
-                  const double c_mu = 4.0 * (1.0 - S.kappa) * S.mu, c_la = 2.0 * (1.0 - S.kappa) * S.lam;
-                  // contraction accumulators: stage 1 over q0 happens on the fly
-                  double t1[2][3][3]; // [al][q2][q1]
-#pragma unroll
-                  for (int q2 = 0; q2 < 3; ++q2)
-#pragma unroll
-                    for (int q1 = 0; q1 < 3; ++q1)
-                      {
-                        const double n1a = c_g1.n[0][q1], n1b = c_g1.n[1][q1], n2a = c_g1.n[0][q2], n2b = c_g1.n[1][q2];
-                        const double w12 = S.vol * c_g1.w[q1] * c_g1.w[q2];
-                        // d/dx_k u_d: independent of q0
-                        const double gk_ud = n1a * n2a * dk_ud[0] + n1b * n2a * dk_ud[1] + n1a * n2b * dk_ud[2] + n1b * n2b * dk_ud[3];
-                        // phi collapsed over local axes 1,2
-                        const double p0 = n1a * n2a * PH[0] + n1b * n2a * PH[2] + n1a * n2b * PH[4] + n1b * n2b * PH[6];
-                        const double p1 = n1a * n2a * PH[1] + n1b * n2a * PH[3] + n1a * n2b * PH[5] + n1b * n2b * PH[7];
-                        double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                        for (int q0 = 0; q0 < 3; ++q0)
-                          {
-                            const double n0a = c_g1.n[0][q0], n0b = c_g1.n[1][q0];
-                            double pf = n0a * p0 + n0b * p1;
-                            if (S.monolithic)
-                              pf = fmax(0.0, pf); // cracks.cc:2251-2256
-                            double gd_uk;
-                            if (ld == 0)
-                              gd_uk = gk_ud; // d == k: same derivative
-                            else if (ld == 1)
-                              gd_uk = n0a * n2a * dd_uk[0] + n0b * n2a * dd_uk[1] + n0a * n2b * dd_uk[2] + n0b * n2b * dd_uk[3];
-                            else
-                              gd_uk = n0a * n1a * dd_uk[0] + n0b * n1a * dd_uk[1] + n0a * n1b * dd_uk[2] + n0b * n1b * dd_uk[3];
-                            double bracket = c_mu * 0.5 * (gk_ud + gd_uk);
-                            if (diag)
-                              {
-                                const double gi_ui = n0a * n2a * di_ui[0] + n0b * n2a * di_ui[1] + n0a * n2b * di_ui[2] + n0b * n2b * di_ui[3];
-                                const double gj_uj = n0a * n1a * dj_uj[0] + n0b * n1a * dj_uj[1] + n0a * n1b * dj_uj[2] + n0b * n1b * dj_uj[3];
-                                const double trE = gk_ud + gi_ui + gj_uj;
-                                bracket += c_la * trE + cdiag;
-                              }
-                            const double Phi = (w12 * c_g1.w[q0]) * pf * bracket;
-                            acc0 += Phi * n0a;
-                            acc1 += Phi * n0b;
-                          }
-                        t1[0][q2][q1] = acc0;
-                        t1[1][q2][q1] = acc1;
-                      }
-#pragma unroll
-                  for (int al = 0; al < 2; ++al)
-#pragma unroll
-                    for (int g1 = 0; g1 < 3; ++g1)
-                      {
-                        double t2[3];
-#pragma unroll
-                        for (int q2 = 0; q2 < 3; ++q2)
-                          t2[q2] = t1[al][q2][0] * c_g1.m[g1][0] + t1[al][q2][1] * c_g1.m[g1][1] + t1[al][q2][2] * c_g1.m[g1][2];
-#pragma unroll
-                        for (int g2 = 0; g2 < 3; ++g2)
-                          out[(al * 9 + g1 * 3 + g2) * CS] = t2[0] * c_g1.m[g2][0] + t2[1] * c_g1.m[g2][1] + t2[2] * c_g1.m[g2][2];
-                      }
-                }
+                pu_cell<false>(s_u, s_phi, h000, kk, d, S, out);
             }
           __syncthreads();
           stamp(1);
@@ -522,21 +568,25 @@ namespace pfm
           for (int g = 0; g < 3; ++g)
             mb[g] = c_g1.w[0] * c_g1.m[g][0] + c_g1.w[1] * c_g1.m[g][1] + c_g1.w[2] * c_g1.m[g][2];
           const double lap = S.Gc * S.eps * S.vol;
-          const double sz = (gz == 1) ? -1.0 : 1.0;
+          // per-thread z factors; an invalid cell gets an all-zero table (its partial moments are zero already)
+          const double mbz = valid ? mb[gz] : 0.0;
+          const double szz = valid ? ((gz == 1) ? -lap * S.ih[2] * S.ih[2] : lap * S.ih[2] * S.ih[2]) : 0.0;
+          const double mz0 = c_g1.m[gz][0], mz1 = c_g1.m[gz][1], mz2 = c_g1.m[gz][2];
 #pragma unroll
           for (int gy = 0; gy < 3; ++gy)
 #pragma unroll
             for (int gx = 0; gx < 3; ++gx)
               {
-                double m = 0.0;
-#pragma unroll
-                for (int qz = 0; qz < 3; ++qz)
-                  m += out[(N_PART + qz * 9 + gy * 3 + gx) * CS] * c_g1.m[gz][qz];
+                double m = out[(N_PART + 0 * 9 + gy * 3 + gx) * CS] * mz0;
+                m += out[(N_PART + 1 * 9 + gy * 3 + gx) * CS] * mz1;
+                m += out[(N_PART + 2 * 9 + gy * 3 + gx) * CS] * mz2;
                 const double sx = (gx == 1) ? -1.0 : 1.0, sy = (gy == 1) ? -1.0 : 1.0;
-                // G_c eps sum_q w grad N_a . grad N_b  (sign = -1 where a_k != b_k)
-                const double L = lap * (sx * S.ih[0] * S.ih[0] * mb[gy] * mb[gz] + sy * S.ih[1] * S.ih[1] * mb[gx] * mb[gz] +
-                                        sz * S.ih[2] * S.ih[2] * mb[gx] * mb[gy]);
-                m = valid ? m + L : 0.0;
+                // G_c eps sum_q w grad N_a . grad N_b  (sign = -1 where a_k != b_k):
+                //   L = mbar_gz * P[gy][gx] + s_z ih_z^2 * Q[gy][gx], P and Q the same for every thread
+                const double P = lap * (sx * S.ih[0] * S.ih[0] * mb[gy] + sy * S.ih[1] * S.ih[1] * mb[gx]);
+                const double Q = mb[gx] * mb[gy];
+                m += mbz * P;
+                m += szz * Q;
                 out[(N_M + gx + 3 * gy + 9 * gz) * CS] = m;
               }
         }
@@ -552,12 +602,27 @@ namespace pfm
           const int h000 = cx + HX * (cy + HY * l);
           const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + HX + HX * HY] >= 0;
           double avg = 0.0, gzero = 0.0;
+          // avg is consumed only by constrained rows (placeholder of a zero diagonal entry), gzero only by
+          // constrained displacement rows; with 0 < kappa <= 1 every g(q) >= kappa > 0 so gzero stays 0.
+          bool needed = false;
+          double dsum = 0.0; // sum_a |K_phiphi[a,a]|
           if (valid)
             {
-              double dsum = 0.0; // sum_a |K_phiphi[a,a]|
+              unsigned anyflag = 0;
+              bool zero_diag = false;
 #pragma unroll
               for (int a = 0; a < 8; ++a)
-                dsum += fabs(out[(N_M + 2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * ((a >> 2) & 1)) * CS]);
+                {
+                  const double dg = fabs(out[(N_M + 2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * ((a >> 2) & 1)) * CS]);
+                  dsum += dg;
+                  zero_diag = zero_diag || dg == 0.0;
+                  anyflag |= s_flag[h000 + (a & 1) + HX * ((a >> 1) & 1) + HX * HY * ((a >> 2) & 1)];
+                }
+              const bool g_positive = S.kappa > 0.0 && S.kappa <= 1.0;
+              needed = anyflag != 0 && (zero_diag || !g_positive);
+            }
+          if (needed)
+            {
               // sum_{a,c} K_uu[(a,c),(a,c)] = sum_k (sum_c cA[c][k]) * 2 * sum_q w g mu(q_i) mu(q_j),  mu = m_00 + m_11
               double po[8], poo[8];
 #pragma unroll
@@ -636,7 +701,23 @@ namespace pfm
       stamp(6);
 
       // ---- copy-out of the phase-field rows
-      if constexpr (NCOL == 3)
+      if (NCOL == 3 && s_irregular == 0)
+        {
+          // interior tile: slot order = offset order and every row is full, the staged rows are the CSR rows
+#pragma unroll 2
+          for (int f = t; f < TX * TY * STG_PU; f += NTHREADS)
+            {
+              const int nl = f / STG_PU;
+              vals_pu[3 * s_off[nl] + (f - nl * STG_PU)] = s_stage_pu[f];
+            }
+#pragma unroll 2
+          for (int f = t; f < TX * TY * STG_PP; f += NTHREADS)
+            {
+              const int nl = f / STG_PP;
+              vals_pp[s_off[nl] + (f - nl * STG_PP)] = s_stage_pp[f];
+            }
+        }
+      else if constexpr (NCOL == 3)
         {
           for (int f = t; f < TX * TY * STG_PU; f += NTHREADS)
             {
@@ -708,11 +789,11 @@ namespace pfm
         static unsigned long long *d_dbg = nullptr;
         if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
-        hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
         hipLaunchKernelGGL((k_cart_phi<3, true>), dim3(nb), dim3(NTHREADS), 0, s, v, cv, S, d_values[2], d_values[3],
                            d_values[0], d_dbg);
         unsigned long long h[16];
-        hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
         const char *names[8] = {"phase0", "pu-cell(x3)", "pu-node(x3)", "pp-step1", "pp-step2", "pp-step3", "pp-node", "copy-out"};
         fprintf(stderr, "[k_cart_phi phase clock, thread 0, cycles per tile]");
         for (int i = 0; i < 8; ++i)
