@@ -27,6 +27,7 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace pfm
 {
@@ -318,6 +319,245 @@ namespace pfm
         }
     }
 
+
+    // =====================================================================================
+    // 3-D residual, z-marching cell columns (cracks.cc:2393-2432).
+    //
+    // A workgroup owns a 15 x 15 column of nodes over a chunk of z-planes; thread <-> one of the 16 x 16
+    // cell columns touching those nodes.  Marching up in z, a thread evaluates the q-point state of its cell
+    // ONCE, integrates it against all 8 test vertices with the x-sum factored out (22 accumulate-ops per
+    // q-point instead of 160), keeps the part that belongs to the upper node plane in registers for the
+    // next step, and hands the lower part to the 4 nodes of the plane through LDS, where each owned node
+    // adds its 4 cell columns in a fixed order and writes its rows exactly once.  Nodal values live in a
+    // two-plane LDS ring: every plane is read from HBM/L2 once per tile.
+    // =====================================================================================
+    constexpr int RTX = 16, RTY = 16;           // cell columns per workgroup = threads
+    constexpr int RNX = RTX - 1, RNY = RTY - 1; // owned nodes per tile plane
+    constexpr int RHX = RTX + 1, RHY = RTY + 1; // nodal halo per plane
+    constexpr int RPL = RHX * RHY + 3;          // padded plane stride (292)
+
+    __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3(DevView v, CartView cv, Scal S,
+                                                                 double *__restrict__ res_pde,
+                                                                 double *__restrict__ res_tot, int write_total,
+                                                                 int zc /* node planes per chunk */)
+    {
+      __shared__ double s_U[2][6][RPL]; // [ring][u_x u_y u_z phi phi_old phi_oldold][halo node]
+      __shared__ double s_P[16][RTX * RTY];
+
+      const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
+      const int ntx = (OWX + RNX - 1) / RNX, nty = (OWY + RNY - 1) / RNY;
+      const int bid = blockIdx.x;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
+      const int i0 = cv.o0[0] + tix * RNX, j0 = cv.o0[1] + tiy * RNY;
+      const int kA = cv.o0[2] + chunk * zc;
+      const int kB = min(kA + zc, cv.o1[2] + 1); // node planes [kA, kB)
+      const int ci = i0 - 1 + cx, cj = j0 - 1 + cy;
+      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1;
+      const bool node_ok = cx < RNX && cy < RNY && (i0 + cx) <= cv.o1[0] && (j0 + cy) <= cv.o1[1];
+
+      const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = 1.0 / cv.h[2];
+      const double vol = cv.h[0] * cv.h[1] * cv.h[2];
+
+      auto load_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+        for (int idx = t; idx < RHX * RHY; idx += RTX * RTY)
+          {
+            const int hx = idx % RHX, hy = idx / RHX;
+            const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
+            double val[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
+              {
+                const int n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                val[0] = v.u[0][n];
+                val[1] = v.u[1][n];
+                val[2] = v.u[2][n];
+                val[3] = v.phi[n];
+                val[4] = v.phi_old[n];
+                val[5] = v.phi_oldold[n];
+              }
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+              s_U[buf][f][idx] = val[f];
+          }
+      };
+
+      double R[2][2][2][4]; // [ax][ay][az][component]
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          R[a & 1][(a >> 1) & 1][a >> 2][c] = 0.0;
+
+      load_plane(kA - 1, 0);
+      const int hb = cy * RHX + cx;
+#pragma unroll 1
+      for (int ck = kA - 1; ck < kB; ++ck)
+        {
+          const int lo = (ck - (kA - 1)) & 1, hi = lo ^ 1;
+          load_plane(ck + 1, hi);
+          __syncthreads();
+          if (col_ok && ck >= 0 && ck < cv.NZ - 1)
+            {
+              const double *Ulo = &s_U[lo][0][hb], *Uhi = &s_U[hi][0][hb];
+#pragma unroll 1
+              for (int p = 0; p < 9; ++p)
+                {
+                  const int qy = p % 3, qz = p / 3;
+                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy], nz0 = c_t1.n[0][qz], nz1 = c_t1.n[1][qz];
+                  const double wyz = vol * c_t1.w[qy] * c_t1.w[qz];
+                  double L[6][2], Dy[4][2], Dz[4][2], Dx[4];
+#pragma unroll
+                  for (int f = 0; f < 6; ++f)
+                    {
+                      const double a00 = Ulo[f * RPL], a10 = Ulo[f * RPL + 1], a01 = Ulo[f * RPL + RHX],
+                                   a11 = Ulo[f * RPL + RHX + 1];
+                      const double b00 = Uhi[f * RPL], b10 = Uhi[f * RPL + 1], b01 = Uhi[f * RPL + RHX],
+                                   b11 = Uhi[f * RPL + RHX + 1];
+                      const double lo0 = ny0 * a00 + ny1 * a01, lo1 = ny0 * a10 + ny1 * a11;
+                      const double hi0 = ny0 * b00 + ny1 * b01, hi1 = ny0 * b10 + ny1 * b11;
+                      L[f][0] = nz0 * lo0 + nz1 * hi0;
+                      L[f][1] = nz0 * lo1 + nz1 * hi1;
+                      if (f < 4)
+                        {
+                          Dz[f][0] = (hi0 - lo0) * ihz;
+                          Dz[f][1] = (hi1 - lo1) * ihz;
+                          Dy[f][0] = (nz0 * (a01 - a00) + nz1 * (b01 - b00)) * ihy;
+                          Dy[f][1] = (nz0 * (a11 - a10) + nz1 * (b11 - b10)) * ihy;
+                          Dx[f] = (L[f][1] - L[f][0]) * ihx;
+                        }
+                      __builtin_amdgcn_sched_barrier(0); // one field at a time: keeps the 8 nodal values short-lived
+                    }
+                  // x-stage accumulators: F_c = (Z_c0, Z_c1, Z_c2 | S_c), c = 3: (G_c eps grad phi | rq)
+                  double X0[4], X1[4][2], X2[4][2], XS[2];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    X0[c] = X1[c][0] = X1[c][1] = X2[c][0] = X2[c][1] = 0.0;
+                  XS[0] = XS[1] = 0.0;
+#pragma unroll
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
+                      const double JxW = wyz * c_t1.w[qx];
+                      // Newton state at q (cracks.cc:2222-2232)
+                      double gu[3][3], gpf[3];
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        {
+                          gu[c][0] = Dx[c];
+                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                          gu[c][2] = nx0 * Dz[c][0] + nx1 * Dz[c][1];
+                        }
+                      gpf[0] = Dx[3];
+                      gpf[1] = nx0 * Dy[3][0] + nx1 * Dy[3][1];
+                      gpf[2] = nx0 * Dz[3][0] + nx1 * Dz[3][1];
+                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
+                      double pfo = nx0 * L[4][0] + nx1 * L[4][1];
+                      double pfoo = nx0 * L[5][0] + nx1 * L[5][1];
+                      if (S.monolithic)
+                        {
+                          pf = fmax(0.0, pf);
+                          pfo = fmax(0.0, pfo);
+                          pfoo = fmax(0.0, pfoo);
+                        }
+                      const double pen = fmax(0.0, pf - pfo);
+                      double pfx = pfoo + S.tfac * (pfo - pfoo);
+                      if (pfx <= 0.0)
+                        pfx = 0.0;
+                      if (pfx >= 1.0)
+                        pfx = 1.0;
+                      if (S.use_old)
+                        pfx = pfo;
+                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+                      const double e01 = 0.5 * (gu[0][1] + gu[1][0]), e02 = 0.5 * (gu[0][2] + gu[2][0]),
+                                   e12 = 0.5 * (gu[1][2] + gu[2][1]);
+                      const double trE = gu[0][0] + gu[1][1] + gu[2][2];
+                      const double lt = S.lam * trE, mu2 = 2 * S.mu;
+                      const double s00 = lt + mu2 * gu[0][0], s11 = lt + mu2 * gu[1][1], s22 = lt + mu2 * gu[2][2];
+                      const double s01 = mu2 * e01, s02 = mu2 * e02, s12 = mu2 * e12;
+                      const double spE = s00 * gu[0][0] + s11 * gu[1][1] + s22 * gu[2][2] +
+                                         2.0 * (s01 * e01 + s02 * e02 + s12 * e12);
+                      const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;
+                      // Z = (g sigma+ - (alpha_B-1) p pfx^2 I) JxW (symmetric)
+                      const double z00 = gJ * s00 - pd, z11 = gJ * s11 - pd, z22 = gJ * s22 - pd;
+                      const double z01 = gJ * s01, z02 = gJ * s02, z12 = gJ * s12;
+                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
+                                         2.0 * S.aB1 * S.p * pf * trE) *
+                                        JxW;
+                      const double ge = S.Gc * S.eps * JxW;
+                      const double F[4][3] = {{z00, z01, z02}, {z01, z11, z12}, {z02, z12, z22},
+                                              {ge * gpf[0], ge * gpf[1], ge * gpf[2]}};
+#pragma unroll
+                      for (int c = 0; c < 4; ++c)
+                        {
+                          X0[c] += F[c][0];
+                          X1[c][0] += F[c][1] * nx0;
+                          X1[c][1] += F[c][1] * nx1;
+                          X2[c][0] += F[c][2] * nx0;
+                          X2[c][1] += F[c][2] * nx1;
+                        }
+                      XS[0] += rq * nx0;
+                      XS[1] += rq * nx1;
+                    }
+                  // y and z factors of the 8 test vertices
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax)
+                      {
+                        double tA = (ax ? ihx : -ihx) * X0[c];
+                        if (c == 3)
+                          tA += XS[ax];
+#pragma unroll
+                        for (int ay = 0; ay < 2; ++ay)
+                          {
+                            const double nay = ay ? ny1 : ny0;
+                            const double uA = nay * tA + (ay ? ihy : -ihy) * X1[c][ax];
+                            const double tC = nay * ihz * X2[c][ax];
+                            R[ax][ay][0][c] -= nz0 * uA - tC;
+                            R[ax][ay][1][c] -= nz1 * uA + tC;
+                          }
+                      }
+                }
+            }
+          const bool emit = ck >= kA;
+          if (emit)
+            {
+#pragma unroll
+              for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  s_P[a * 4 + c][t] = R[a & 1][a >> 1][0][c];
+            }
+          __syncthreads();
+          if (emit && node_ok)
+            {
+              const int row = cv.local_of_box[(i0 + cx) + (long long)cv.NX * ((j0 + cy) + (long long)cv.NY * ck)];
+              const unsigned fl = v.node_flags[row];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                {
+                  // cells (i-1,j-1), (i,j-1), (i-1,j), (i,j) of the plane, lower + upper layer already merged
+                  const double r = ((s_P[3 * 4 + c][t] + s_P[2 * 4 + c][t + 1]) + s_P[1 * 4 + c][t + RTX]) +
+                                   s_P[0 * 4 + c][t + RTX + 1];
+                  const bool con = (fl >> c) & 1u;
+                  const long long di = dof_index_c<3>(v, row, c);
+                  res_pde[di] = con ? 0.0 : r; // constrained scatter = masked store (cracks.cc:2440-2456)
+                  if (write_total)
+                    res_tot[di] = (con && S.total_via_update) ? 0.0 : r;
+                }
+            }
+          // the upper-vertex part becomes the lower-vertex part of the next layer
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              {
+                R[a & 1][a >> 1][0][c] = R[a & 1][a >> 1][1][c];
+                R[a & 1][a >> 1][1][c] = 0.0;
+              }
+        }
+    }
+
     bool g_tab_ready[16] = {};
     int ensure_tab()
     {
@@ -353,8 +593,20 @@ namespace pfm
     const unsigned nb = (unsigned)((n_waves + 3) / 4);
     if (v.dim == 2)
       hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
-    else
+    else if (getenv("PFM_RES_V1")) // previous generation, kept for A/B profiling
       hipLaunchKernelGGL(k_cart_residual<3>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+    else
+      {
+        const int ntx = (int)((OWX + RNX - 1) / RNX), nty = (int)((OWY + RNY - 1) / RNY);
+        // chunks of z-planes: enough workgroups to fill 256 CUs several times over, at most ~8 % redundant layers
+        int nch = (int)((OWZ + 11) / 12);
+        while (nch > 1 && (long long)ntx * nty * nch > 8192)
+          --nch;
+        const int zc = (int)((OWZ + nch - 1) / nch);
+        nch = (int)((OWZ + zc - 1) / zc);
+        hipLaunchKernelGGL(k_cart_residual3, dim3((unsigned)(ntx * nty * nch)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
+                           res_tot, residual_only, zc);
+      }
     if (hipGetLastError() != hipSuccess)
       return PFM_ERR_HIP;
     if (!residual_only)
