@@ -18,6 +18,14 @@ namespace pfm
     constexpr int CS = CX * CY * 2;              // 162 cell slots (two layers)
     constexpr int NNUM_UU = 64;                  // 27 A + 36 T + 1 spare
     constexpr int STG = 81;                      // staged row width (27 slots x 3), odd => conflict-free
+    // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e.
+    // every wave would sit out the full HBM write latency of the rows it has just streamed out; the kernels
+    // here never exchange data through global memory inside a launch, so outstanding stores may stay in flight.
+    __device__ __forceinline__ void lds_barrier()
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
     template <int N, class F>
     __device__ __forceinline__ __attribute__((always_inline)) void static_for(F &&f)
     {
@@ -38,6 +46,7 @@ namespace pfm
     struct G1
     {
       double n[2][3], m[3][3], w[3]; // n_al(q), m_g(q) (g = 0:00, 1:01, 2:11), weights
+      double mb[3];                  // 1-D mass moments mbar_g = sum_q w m_g(q)
     };
     __constant__ G1 c_g1;
 
@@ -55,6 +64,8 @@ namespace pfm
           t.m[2][q] = t.n[1][q] * t.n[1][q];
           t.w[q] = gw[q];
         }
+      for (int g = 0; g < 3; ++g)
+        t.mb[g] = t.w[0] * t.m[g][0] + t.w[1] * t.m[g][1] + t.w[2] * t.m[g][2];
       return t;
     }
 
@@ -65,6 +76,11 @@ namespace pfm
       double cA[3][3]; // cA[c][k] = (k == c ? lam + 2 mu : mu) / h_k^2
       double cT[3];    // 1 / (h_lo h_hi) for the pairs (0,1), (0,2), (1,2)
       int monolithic, use_old;
+      // uniform constants of the phase-field rows, precomputed on the host so that they arrive in scalar registers
+      double c_muh, c_la, cdiag;       // 2(1-kappa) mu, 2(1-kappa) lambda, -2(alpha_B-1) p
+      double omk, gc_eps, aB1p2, lap;  // 1-kappa, G_c/eps, 2(alpha_B-1) p, G_c eps vol
+      double vww[3][3];                // vol w(a) w(b)
+      double lapP[3][3], lapQ[3][3];   // Laplace moments [g_x][g_y]: in-plane part (times mbar_gz), d/dz part (times s(g_z))
     };
 
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
@@ -156,6 +172,22 @@ namespace pfm
       s.cT[2] = s.ih[1] * s.ih[2];
       s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
       s.use_old = prm.use_old_timestep_pf;
+      s.c_muh = 2.0 * (1.0 - s.kappa) * s.mu;
+      s.c_la = 2.0 * (1.0 - s.kappa) * s.lam;
+      s.cdiag = -2.0 * s.aB1 * s.p;
+      s.omk = 1.0 - s.kappa;
+      s.gc_eps = s.Gc / s.eps;
+      s.aB1p2 = 2.0 * s.aB1 * s.p;
+      s.lap = s.Gc * s.eps * s.vol;
+      const G1 g = make_g1();
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          {
+            s.vww[a][b] = s.vol * g.w[a] * g.w[b];
+            const double sa = (a == 1) ? -1.0 : 1.0, sb = (b == 1) ? -1.0 : 1.0;
+            s.lapP[a][b] = s.lap * (sa * s.ih[0] * s.ih[0] * g.mb[b] + sb * s.ih[1] * s.ih[1] * g.mb[a]);
+            s.lapQ[a][b] = s.lap * s.ih[2] * s.ih[2] * g.mb[a] * g.mb[b];
+          }
       return s;
     }
   } // namespace

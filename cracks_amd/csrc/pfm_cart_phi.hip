@@ -778,6 +778,8 @@ namespace pfm
     rc = launch_cart_uu_only(v, cv, p, d_values[0], s);
     if (rc)
       return rc;
+    if (!getenv("PFM_PHI_V1"))
+      return launch_cart_phi4(v, cv, p, d_values, s); // z-marching push kernel (pfm_cart_phi4.hip)
     const MatScal S = make_mat_scal(p, cv);
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + TX - 1) / TX, nty = (OWY + TY - 1) / TY;

@@ -1,0 +1,829 @@
+// pfm_cart_phi4.hip — phase-field rows of the Jacobian (3-D), z-marching "push" kernel:
+// the (phi,u) block (cracks.cc:2374-2376, 2381-2382 with a displacement trial function), the (phi,phi)
+// block (cracks.cc:2370-2371, 2377-2383) and the placeholder diagonals of constrained rows
+// (deal.II distribute_local_to_global).
+//
+// For these rows a finished CSR row (108 doubles per node) is smaller than the sum-factorised cell
+// tables it is built from (191 doubles per cell), so the tables never leave the registers:
+//
+//   * a workgroup owns a 7 x 7 column of nodes over a chunk of z-planes; its 4 waves are 4 ROLES
+//     (column component d = 0,1,2 of the (phi,u) block, and the (phi,phi) block), lane <-> one of the
+//     8 x 8 cells of the current layer touching those nodes;
+//   * marching up in z, every lane evaluates its cell ONCE per role (quadrature with all three 1-D
+//     contractions factored), then pushes the cell's entries into the LDS-staged rows of its 8 vertices:
+//     the 4 lower vertices complete the rows of node plane k, the 4 upper ones start the rows of plane k+1.
+//     Pushes of one role touch disjoint entries and are issued vertex by vertex in a fixed order, so there
+//     are no atomics, no barriers inside the push, and the summation order is that of a lexicographic
+//     cell loop (bitwise reproducible);
+//   * plane k is then masked (constraints) and streamed out: every CSR value is written exactly once,
+//     x-consecutive rows are contiguous in memory.
+//
+// Staged rows are split by the z-offset of the neighbour slot (oz = -1, 0, +1): only the oz <= 0 parts of
+// the next plane are live across steps, which keeps LDS at 80 KB (2 workgroups per CU).
+//
+// (phi,u) entry of test vertex a and trial dof (b,d):  K = sum_k s(b_k)/h_k C^{dk}[a_k][g_i][g_j],
+//   C^{dk}[al][g_i][g_j] = sum_q Phi^{dk}(q) n_al(q_k) m_{g_i}(q_i) m_{g_j}(q_j),   g = a + b per axis,
+//   Phi^{dk} = w pf [ (2(1-kappa) lambda trE - 2(alpha_B-1) p) delta_dk + 4(1-kappa) mu E_dk ]
+// (phi,phi) entry: M[g_x][g_y][g_z] = sum_q w c(q) m m m + G_c eps (Laplace moments),
+//   c(q) = (1-kappa) sigma+:E + G_c/eps - 2(alpha_B-1) p div u + gamma/dt/diam^2 [pf >= pf_old].
+#include "pfm_internal.h"
+#include "pfm_cart_common.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace pfm
+{
+  namespace
+  {
+    constexpr int PT = 8, PN = PT - 1, PH = PT + 1; // cells, owned nodes, halo nodes per tile edge
+    constexpr int NPN = PN * PN, NPH = PH * PH;     // 49 owned nodes, 81 halo nodes per plane
+    constexpr int NT4 = 4 * PT * PT;                // 4 roles x 64 cells
+    constexpr int SLAB_PU = NPN * 27, SLAB_PP = NPN * 9;
+
+    struct Lds4
+    {
+      double U[2][6][NPH];   // nodal ring: u_x u_y u_z phi phi_old phi_oldold
+      double pu[5][SLAB_PU]; // staged (phi,u) rows: [0,1] oz=-1 ring, [2,3] oz=0 ring, [4] oz=+1; [node][o9][d]
+      double pp[5][SLAB_PP]; // staged (phi,phi) rows, same slabs; [node][o9]
+      double ex[2][NPN][2];  // per node: placeholder sum, (u,u) placeholder patch
+      long long off[2][NPN]; // node-graph offset of the row, -1 = not an owned node of this tile
+      int deg[2][NPN];
+      int row[2][NPN];       // local node id of the row
+      int irregular[2];
+      int anyflag[4];
+      unsigned char flag[4][NPH];
+    };
+
+    __host__ __device__ constexpr int idxC4(int al, int gi, int gj) { return al * 9 + gi * 3 + gj; }
+
+    // values of one nodal field at the (qy,qz) line of a cell: L = value at x-vertex 0/1, Dy/Dz = d/dy, d/dz there
+    template <bool DY, bool DZ>
+    __device__ __forceinline__ void line_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double ny0,
+                                                  double ny1, double nz0, double nz1, double ihy, double ihz, double (&L)[2],
+                                                  double (&Dy)[2], double (&Dz)[2])
+    {
+      const double a00 = lo[0], a10 = lo[1], a01 = lo[PH], a11 = lo[PH + 1];
+      const double b00 = hi[0], b10 = hi[1], b01 = hi[PH], b11 = hi[PH + 1];
+      const double l0 = ny0 * a00 + ny1 * a01, l1 = ny0 * a10 + ny1 * a11;
+      const double h0 = ny0 * b00 + ny1 * b01, h1 = ny0 * b10 + ny1 * b11;
+      L[0] = nz0 * l0 + nz1 * h0;
+      L[1] = nz0 * l1 + nz1 * h1;
+      if constexpr (DZ)
+        {
+          Dz[0] = (h0 - l0) * ihz;
+          Dz[1] = (h1 - l1) * ihz;
+        }
+      if constexpr (DY)
+        {
+          Dy[0] = (nz0 * (a01 - a00) + nz1 * (b01 - b00)) * ihy;
+          Dy[1] = (nz0 * (a11 - a10) + nz1 * (b11 - b10)) * ihy;
+        }
+    }
+
+    struct PushDst // staged rows the 8 vertices of a cell push into
+    {
+      double *lo_z0, *lo_p1; // current plane: oz = 0 and oz = +1 slabs (lower vertices)
+      double *hi_m1, *hi_z0; // next plane: oz = -1 and oz = 0 slabs (upper vertices)
+      bool push_lo, push_hi;
+    };
+
+    // ---- role d: (phi,u) entries of column component D of one cell.  The x- and y-contractions are factored
+    // (X, Y accumulators); the z-contraction is folded into the push, one push per z-level of q-points, so the
+    // 54 numbers C^{dk}[al][g_i][g_j] never have to be held in registers.
+    template <int D>
+    __device__ __forceinline__ void pu_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
+                                            bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
+    {
+      const double c_muh = S.c_muh, c_la = S.c_la, cdiag = S.cdiag;
+#pragma unroll 1
+      for (int qz = 0; qz < 3; ++qz)
+        {
+          double Yx[2][3], Yy[3][2], Yz[3][3]; // k=x: [al][g_y], k=y: [g_x][al], k=z: [g_x][g_y]
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            {
+              Yx[0][i] = Yx[1][i] = Yy[i][0] = Yy[i][1] = 0.0;
+              Yz[i][0] = Yz[i][1] = Yz[i][2] = 0.0;
+            }
+          const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
+          if (cell_ok)
+            {
+#pragma unroll 1
+              for (int qy = 0; qy < 3; ++qy)
+                {
+                  const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
+                  const double wyz = S.vww[qy][qz];
+                  double L[4][2], Dy[3][2], Dz[3][2];
+                  static_for<3>([&](auto F) __attribute__((always_inline)) {
+                    constexpr int f = decltype(F)::value;
+                    constexpr bool need_dy = (f == D) || (D == 1) || (f == 1);
+                    constexpr bool need_dz = (f == D) || (D == 2) || (f == 2);
+                    line_of_field<need_dy, need_dz>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f],
+                                                    Dy[f], Dz[f]);
+                    __builtin_amdgcn_sched_barrier(0);
+                  });
+                  {
+                    double dummy[2];
+                    line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
+                                                dummy);
+                  }
+                  double Dx[3];
+#pragma unroll
+                  for (int f = 0; f < 3; ++f)
+                    Dx[f] = (L[f][1] - L[f][0]) * S.ih[0];
+                  double Xx[2] = {0.0, 0.0}, Xy[3] = {0.0, 0.0, 0.0}, Xz[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_g1.n[0][qx], nx1 = c_g1.n[1][qx];
+                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
+                      if (S.monolithic)
+                        pf = fmax(0.0, pf); // cracks.cc:2251-2256
+                      const double wp = (wyz * c_g1.w[qx]) * pf;
+                      // d/dx_k u_c at q (only the row D, the column D and the diagonal are ever requested)
+                      auto grad = [&](auto Cc, auto Kk) __attribute__((always_inline)) -> double {
+                        constexpr int c = decltype(Cc)::value, k = decltype(Kk)::value;
+                        if constexpr (k == 0)
+                          return Dx[c];
+                        else if constexpr (k == 1)
+                          return nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                        else
+                          return nx0 * Dz[c][0] + nx1 * Dz[c][1];
+                      };
+                      using I0 = std::integral_constant<int, 0>;
+                      using I1 = std::integral_constant<int, 1>;
+                      using I2 = std::integral_constant<int, 2>;
+                      using ID = std::integral_constant<int, D>;
+                      const double g00 = grad(I0{}, I0{}), g11 = grad(I1{}, I1{}), g22 = grad(I2{}, I2{});
+                      const double dterm = c_la * (g00 + g11 + g22) + cdiag;
+                      const double gD0 = grad(ID{}, I0{}), gD1 = grad(ID{}, I1{}), gD2 = grad(ID{}, I2{});
+                      const double g0D = grad(I0{}, ID{}), g1D = grad(I1{}, ID{}), g2D = grad(I2{}, ID{});
+                      const double Phi0 = wp * (c_muh * (gD0 + g0D) + (D == 0 ? dterm : 0.0));
+                      const double Phi1 = wp * (c_muh * (gD1 + g1D) + (D == 1 ? dterm : 0.0));
+                      const double Phi2 = wp * (c_muh * (gD2 + g2D) + (D == 2 ? dterm : 0.0));
+                      Xx[0] += Phi0 * nx0;
+                      Xx[1] += Phi0 * nx1;
+#pragma unroll
+                      for (int g = 0; g < 3; ++g)
+                        {
+                          Xy[g] += Phi1 * c_g1.m[g][qx];
+                          Xz[g] += Phi2 * c_g1.m[g][qx];
+                        }
+                    }
+#pragma unroll
+                  for (int g = 0; g < 3; ++g)
+                    {
+                      const double my = c_g1.m[g][qy];
+                      Yx[0][g] += Xx[0] * my;
+                      Yx[1][g] += Xx[1] * my;
+#pragma unroll
+                      for (int gx = 0; gx < 3; ++gx)
+                        Yz[gx][g] += Xz[gx] * my;
+                      Yy[g][0] += Xy[g] * ny0;
+                      Yy[g][1] += Xy[g] * ny1;
+                    }
+                }
+              // K = sum_k s(b_k)/h_k C^{dk}: fold 1/h_k in
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                {
+                  Yx[0][i] *= S.ih[0];
+                  Yx[1][i] *= S.ih[0];
+                  Yy[i][0] *= S.ih[1];
+                  Yy[i][1] *= S.ih[1];
+#pragma unroll
+                  for (int j = 0; j < 3; ++j)
+                    Yz[i][j] *= S.ih[2];
+                }
+            }
+          const double mz[3] = {c_g1.m[0][qz], c_g1.m[1][qz], c_g1.m[2][qz]};
+          // push this z-level's part of the entries of the 8 vertices, in the order of a lexicographic cell loop
+          static_for<8>([&](auto A) __attribute__((always_inline)) {
+            constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+            const int hx = cx + ax, hy = cy + ay;
+            if ((az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN)
+              {
+                const int nb = (nl0 + ax + PN * ay) * 27 + D;
+                const double nza = az ? nz1 : nz0;
+                static_for<8>([&](auto B) __attribute__((always_inline)) {
+                  constexpr int bx = decltype(B)::value & 1, by = (decltype(B)::value >> 1) & 1, bz = decltype(B)::value >> 2;
+                  constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
+                  constexpr int gx = ax + bx, gy = ay + by, gz = az + bz;
+                  constexpr int o9 = (ox + 1) + 3 * (oy + 1);
+                  const double t0 = Yx[ax][gy], t1 = Yy[gx][ay], t2 = Yz[gx][gy];
+                  const double txy = (bx ? t0 : -t0) + (by ? t1 : -t1);
+                  const double e = txy * mz[gz] + (bz ? nza : -nza) * t2;
+                  double *slab = (az == 0) ? (oz == 0 ? dst.lo_z0 : dst.lo_p1) : (oz == -1 ? dst.hi_m1 : dst.hi_z0);
+                  slab[nb + o9 * 3] += e;
+                });
+              }
+          });
+        }
+    }
+
+    // ---- role 3: (phi,phi) entries of one cell, same scheme; returns the 8 diagonal entries of the element matrix
+    __device__ __forceinline__ void pp_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
+                                            bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
+                                            double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
+                                            double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
+    {
+      double M[27]; // M[g_x + 3 g_y + 9 g_z]
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+        M[m] = 0.0;
+      // G_c eps sum_q w grad N_a . grad N_b = mbar_gz P[g_x][g_y] + s(g_z)/h_z^2 G_c eps vol Q[g_x][g_y]
+      // (s = -1 where a_k != b_k), mbar_g = sum_q w m_g(q): added as sum_qz w(qz) [ m_gz(qz) P + s(g_z) ... Q ]
+#pragma unroll 1
+      for (int qz = 0; qz < 3; ++qz)
+        {
+          double Y[3][3]; // [g_x][g_y]
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            Y[i][0] = Y[i][1] = Y[i][2] = 0.0;
+          const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
+          if (cell_ok)
+            {
+#pragma unroll 1
+              for (int qy = 0; qy < 3; ++qy)
+                {
+                  const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
+                  const double wyz = S.vww[qy][qz];
+                  double L[5][2], Dy[3][2], Dz[3][2], dummy[2];
+                  static_for<3>([&](auto F) __attribute__((always_inline)) {
+                    constexpr int f = decltype(F)::value;
+                    line_of_field<true, true>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], Dy[f],
+                                              Dz[f]);
+                    __builtin_amdgcn_sched_barrier(0);
+                  });
+                  line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
+                                              dummy);
+                  line_of_field<false, false>(Ulo + 4 * NPH, Uhi + 4 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy,
+                                              dummy);
+                  double Dx[3];
+#pragma unroll
+                  for (int f = 0; f < 3; ++f)
+                    Dx[f] = (L[f][1] - L[f][0]) * S.ih[0];
+                  double X[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_g1.n[0][qx], nx1 = c_g1.n[1][qx];
+                      double gu[3][3];
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        {
+                          gu[c][0] = Dx[c];
+                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                          gu[c][2] = nx0 * Dz[c][0] + nx1 * Dz[c][1];
+                        }
+                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
+                      double pfo = nx0 * L[4][0] + nx1 * L[4][1];
+                      if (S.monolithic)
+                        {
+                          pf = fmax(0.0, pf);
+                          pfo = fmax(0.0, pfo);
+                        }
+                      const double trE = gu[0][0] + gu[1][1] + gu[2][2];
+                      const double e01 = 0.5 * (gu[0][1] + gu[1][0]), e02 = 0.5 * (gu[0][2] + gu[2][0]),
+                                   e12 = 0.5 * (gu[1][2] + gu[2][1]);
+                      const double EE = gu[0][0] * gu[0][0] + gu[1][1] * gu[1][1] + gu[2][2] * gu[2][2] +
+                                        2.0 * (e01 * e01 + e02 * e02 + e12 * e12);
+                      const double spE = S.lam * trE * trE + 2 * S.mu * EE;       // sigma+ : E
+                      const double pen = ((pf - pfo) < 0.0) ? 0.0 : S.gamma_fac; // cracks.cc:2311-2315, 2370
+                      const double cq = S.omk * spE + S.gc_eps - S.aB1p2 * trE + pen;
+                      const double wc = (wyz * c_g1.w[qx]) * cq;
+                      X[0] += wc * c_g1.m[0][qx];
+                      X[1] += wc * c_g1.m[1][qx];
+                      X[2] += wc * c_g1.m[2][qx];
+                    }
+#pragma unroll
+                  for (int gy = 0; gy < 3; ++gy)
+#pragma unroll
+                    for (int gx = 0; gx < 3; ++gx)
+                      Y[gx][gy] += X[gx] * c_g1.m[gy][qy];
+                }
+            }
+          const double mz[3] = {c_g1.m[0][qz], c_g1.m[1][qz], c_g1.m[2][qz]};
+          const double wz = cell_ok ? c_g1.w[qz] : 0.0;
+          double Qz[3][3]; // this z-level's share of the d/dz d/dz Laplace moment
+#pragma unroll
+          for (int gx = 0; gx < 3; ++gx)
+#pragma unroll
+            for (int gy = 0; gy < 3; ++gy)
+              {
+                Y[gx][gy] += wz * S.lapP[gx][gy];
+                Qz[gx][gy] = wz * S.lapQ[gx][gy];
+              }
+#pragma unroll
+          for (int gz = 0; gz < 3; ++gz)
+#pragma unroll
+            for (int gy = 0; gy < 3; ++gy)
+#pragma unroll
+              for (int gx = 0; gx < 3; ++gx)
+                M[gx + 3 * gy + 9 * gz] += Y[gx][gy] * mz[gz] + (gz == 1 ? -Qz[gx][gy] : Qz[gx][gy]);
+        }
+      // one push per cell: the 27 moments fit in registers (unlike the 54 numbers of a (phi,u) role)
+      static_for<8>([&](auto A) __attribute__((always_inline)) {
+        constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+        const int hx = cx + ax, hy = cy + ay;
+        if ((az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN)
+          {
+            const int nb = (nl0 + ax + PN * ay) * 9;
+            static_for<8>([&](auto B) __attribute__((always_inline)) {
+              constexpr int bx = decltype(B)::value & 1, by = (decltype(B)::value >> 1) & 1, bz = decltype(B)::value >> 2;
+              constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
+              constexpr int o9 = (ox + 1) + 3 * (oy + 1);
+              double *slab = (az == 0) ? (oz == 0 ? pp_lo_z0 : pp_lo_p1) : (oz == -1 ? pp_hi_m1 : pp_hi_z0);
+              slab[nb + o9] += M[(ax + bx) + 3 * (ay + by) + 9 * (az + bz)];
+            });
+          }
+      });
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        Mdiag[a] = M[2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * (a >> 2)];
+    }
+
+    // =====================================================================================
+    template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */>
+    __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, MatScal S, double *__restrict__ vals_pu,
+                                                          double *__restrict__ vals_pp, double *__restrict__ vals_uu,
+                                                          int zc /* node planes per chunk */,
+                                                          unsigned long long *__restrict__ dbg)
+    {
+      __shared__ Lds4 s;
+      long long tclk = 0;
+      auto stamp = [&](int phase) __attribute__((always_inline)) {
+        if constexpr (CLK == 1)
+          {
+            const long long now = clock64();
+            if (threadIdx.x == 0 && phase >= 0)
+              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+            tclk = now;
+          }
+      };
+      stamp(-1);
+      const int t = threadIdx.x, lane = t & 63;
+      const int role = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform: scalar branches between the roles
+      const int cx = lane % PT, cy = lane / PT;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
+      const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
+      const int bid = blockIdx.x;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
+      const int i0 = cv.o0[0] + tix * PN, j0 = cv.o0[1] + tiy * PN;
+      const int kA = cv.o0[2] + chunk * zc;
+      const int kB = min(kA + zc, cv.o1[2] + 1); // node planes [kA, kB)
+      const int ci = i0 - 1 + cx, cj = j0 - 1 + cy;
+      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1;
+      const int hb = cy * PH + cx;               // halo index of the cell's (0,0) vertex
+      const int nl0 = (cx - 1) + PN * (cy - 1);  // owned-node index of that vertex (may be out of range)
+
+      // nodal plane / row info of a plane: global memory -> registers -> LDS
+      double pv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // plane in flight (threads < NPH): nodal values, flags
+      unsigned pflag = 0;
+      auto fetch_plane = [&](int kz) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          pv[c] = 0.0;
+        pflag = 0;
+        if (t < NPH)
+          {
+            const int hx = t % PH, hy = t / PH;
+            const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
+            if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
+              {
+                const int n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                pv[0] = v.u[0][n];
+                pv[1] = v.u[1][n];
+                pv[2] = v.u[2][n];
+                pv[3] = v.phi[n];
+                pv[4] = v.phi_old[n];
+                pv[5] = v.phi_oldold[n];
+                pflag = v.node_flags[n];
+              }
+          }
+      };
+      auto put_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+        if (t == 0)
+          s.anyflag[kz & 3] = 0;
+        if (t < NPH)
+          {
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+              s.U[buf][c][t] = pv[c];
+            s.flag[kz & 3][t] = (unsigned char)pflag;
+          }
+      };
+      long long r_off = -1; // row info in flight (threads 128 .. 128 + NPN, all in wave 2)
+      int r_deg = 0, r_row = 0;
+      auto fetch_rows = [&](int kz) __attribute__((always_inline)) {
+        r_off = -1;
+        r_deg = 0;
+        r_row = 0;
+        if (t >= 128 && t < 128 + NPN)
+          {
+            const int nl = t - 128, nx = nl % PN, ny = nl / PN;
+            const int gi = i0 + nx, gj = j0 + ny;
+            if (gi <= cv.o1[0] && gj <= cv.o1[1])
+              {
+                r_row = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                r_off = v.nadj_ptr[r_row];
+                r_deg = (int)(v.nadj_ptr[r_row + 1] - r_off);
+                if (!cv.row_regular[r_row])
+                  r_deg |= 1 << 16;
+              }
+          }
+      };
+      auto put_rows = [&](int kz) __attribute__((always_inline)) {
+        const int par = kz & 1;
+        if (role == 2)
+          {
+            const bool mine = t < 128 + NPN;
+            const unsigned long long irr = __ballot(mine && (r_deg >> 16));
+            if (mine)
+              {
+                s.off[par][t - 128] = r_off;
+                s.deg[par][t - 128] = r_deg;
+                s.row[par][t - 128] = r_row;
+              }
+            if (lane == 0)
+              s.irregular[par] = irr != 0;
+          }
+      };
+
+      // every push accumulates: staged rows start at zero and the copy-out clears what it has streamed out
+      for (int i = t; i < 5 * SLAB_PU; i += NT4)
+        (&s.pu[0][0])[i] = 0.0;
+      for (int i = t; i < 5 * SLAB_PP; i += NT4)
+        (&s.pp[0][0])[i] = 0.0;
+      for (int i = t; i < 2 * NPN * 2; i += NT4)
+        (&s.ex[0][0][0])[i] = 0.0;
+      fetch_plane(kA - 1);
+      put_plane(kA - 1, 0);
+      __syncthreads();
+      if (t < NPH && s.flag[(kA - 1) & 3][t])
+        s.anyflag[(kA - 1) & 3] = 1;
+#pragma unroll 1
+      for (int ck = kA - 1; ck < kB; ++ck)
+        {
+          const int lo = (ck - (kA - 1)) & 1, hi = lo ^ 1;
+          const int cp = ck & 1, np = cp ^ 1;
+          stamp(3);
+          if constexpr (CLK == 2)
+            tclk = clock64();
+          fetch_plane(ck + 1);
+          put_plane(ck + 1, hi);
+          if (ck >= kA)
+            {
+              fetch_rows(ck);
+              put_rows(ck);
+            }
+          lds_barrier();
+          stamp(0);
+          if (t < NPH && s.flag[(ck + 1) & 3][t])
+            s.anyflag[(ck + 1) & 3] = 1;
+
+          // ---- entries of layer ck, pushed into the rows of planes ck (lower vertices) and ck+1 (upper vertices)
+          const bool cell_ok = col_ok && ck >= 0 && ck < cv.NZ - 1;
+          PushDst dst;
+          dst.push_lo = ck >= kA;
+          dst.push_hi = ck + 1 < kB;
+          dst.lo_z0 = s.pu[2 + cp];
+          dst.lo_p1 = s.pu[4];
+          dst.hi_m1 = s.pu[np];
+          dst.hi_z0 = s.pu[2 + np];
+          const double *Ulo = &s.U[lo][0][hb], *Uhi = &s.U[hi][0][hb];
+          if (role == 0)
+            pu_role<0>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+          else if (role == 1)
+            pu_role<1>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+          else if (role == 2)
+            pu_role<2>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+          else
+            {
+              double Mdiag[8];
+              pp_role(Ulo, Uhi, S, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+              double avg = 0.0, patch = 0.0;
+              if (cell_ok)
+                {
+                  // mean |diagonal| of the element matrix: deal.II's placeholder for a constrained row whose own
+                  // diagonal entry vanishes.  Consumed only by constrained rows; with 0 < kappa <= 1 every
+                  // g(q) >= kappa > 0, so the (u,u) diagonal cannot vanish.
+                  double dsum = 0.0;
+                  bool zero_diag = false;
+                  unsigned anyflag = 0;
+#pragma unroll
+                  for (int a = 0; a < 8; ++a)
+                    {
+                      const double dg = fabs(Mdiag[a]);
+                      dsum += dg;
+                      zero_diag = zero_diag || dg == 0.0;
+                      anyflag |= s.flag[(ck + (a >> 2)) & 3][hb + (a & 1) + PH * ((a >> 1) & 1)];
+                    }
+                  const bool g_positive = S.kappa > 0.0 && S.kappa <= 1.0;
+                  if (anyflag != 0 && (zero_diag || !g_positive))
+                    {
+                      double po[8], poo[8];
+#pragma unroll
+                      for (int b = 0; b < 8; ++b)
+                        {
+                          const double *src = (b >> 2) ? Uhi : Ulo;
+                          po[b] = src[4 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
+                          poo[b] = src[5 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
+                        }
+                      // sum_{a,c} K_uu[(a,c),(a,c)] = sum_k (sum_c cA[c][k]) 2 sum_q w g mu(q_i) mu(q_j), mu = m_00 + m_11
+                      double gsum = 0.0, gk[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+                      for (int qz = 0; qz < 3; ++qz)
+                        {
+                          double wg[9];
+                          cell_wg_plane(po, poo, S, qz, wg);
+                          const double muz = c_g1.m[0][qz] + c_g1.m[2][qz];
+#pragma unroll
+                          for (int qy = 0; qy < 3; ++qy)
+#pragma unroll
+                            for (int qx = 0; qx < 3; ++qx)
+                              {
+                                const double w = wg[qx + 3 * qy];
+                                const double mux = c_g1.m[0][qx] + c_g1.m[2][qx], muy = c_g1.m[0][qy] + c_g1.m[2][qy];
+                                gsum += w;
+                                gk[0] += w * muy * muz;
+                                gk[1] += w * mux * muz;
+                                gk[2] += w * mux * muy;
+                              }
+                        }
+                      double usum = 0.0;
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        usum += (S.cA[0][k] + S.cA[1][k] + S.cA[2][k]) * 2.0 * gk[k];
+                      avg = (dsum + usum) / 32.0;
+                      patch = (gsum == 0.0) ? avg : 0.0;
+                    }
+                }
+              // placeholder of a constrained row: sum_e (|K_e,aa| != 0 ? |K_e,aa| : mean |diag K_e|)
+              static_for<8>([&](auto A) __attribute__((always_inline)) {
+                constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+                const int hx = cx + ax, hy = cy + ay;
+                if ((az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN)
+                  {
+                    const double dg = fabs(Mdiag[ax + 2 * ay + 4 * az]);
+                    double *ex = &s.ex[az == 0 ? cp : np][nl0 + ax + PN * ay][0];
+                    ex[0] += (dg != 0.0) ? dg : avg;
+                    ex[1] += patch;
+                  }
+              });
+            }
+          if constexpr (CLK == 2)
+            {
+              if (lane == 0)
+                atomicAdd(dbg + 4 + role, (unsigned long long)(clock64() - tclk));
+            }
+          stamp(1);
+          lds_barrier();
+          stamp(2);
+
+          // ---- plane ck is complete: constraints as masks, then stream the rows out
+          if (ck >= kA)
+            {
+              const bool regular = s.irregular[cp] == 0;
+              const bool masked = (s.anyflag[(ck - 1) & 3] | s.anyflag[ck & 3] | s.anyflag[(ck + 1) & 3]) != 0;
+              double *pu_m1 = s.pu[cp], *pu_z0 = s.pu[2 + cp], *pu_p1 = s.pu[4];
+              double *pp_m1 = s.pp[cp], *pp_z0 = s.pp[2 + cp], *pp_p1 = s.pp[4];
+              if (regular)
+                {
+                  // interior plane: slot order = lattice order, all rows full.  Thread <-> one of the 108 elements
+                  // of a row, two rows at a time; consecutive lanes store consecutive addresses.
+                  if (t < 2 * 108)
+                    {
+                      // thread <-> element fe_e of a row (0..80 (phi,u), 81..107 (phi,phi)); recomputed per plane
+                      // rather than kept live across the whole march
+                      int tq = t;
+                      asm volatile("" : "+v"(tq));
+                      const int fe_e = tq % 108, fe_sub = tq / 108;
+                      const bool fe_pp = fe_e >= 81;
+                      const int fe_o = fe_pp ? fe_e - 81 : fe_e / 3, fe_d = fe_pp ? 3 : fe_e % 3; // lattice offset index, column component
+                      const int fe_oz = fe_o / 9, fe_o9 = fe_o % 9;
+                      const int fe_stride = fe_pp ? 9 : 27, fe_src = fe_pp ? fe_o9 : fe_o9 * 3 + fe_d;
+                      const int fe_nbo = (fe_o9 % 3 - 1) + PH * (fe_o9 / 3 - 1); // halo offset of the neighbour node
+                      const int fe_mul = (NCOL == 3) ? (fe_pp ? 1 : 3) : 16;
+                      const int fe_dst = (NCOL == 3) ? (fe_pp ? fe_e - 81 : fe_e) : 3 * 4 * 27 + fe_o * 4 + fe_d;
+                      double *src = (fe_oz == 0) ? (fe_pp ? pp_m1 : pu_m1) : (fe_oz == 1 ? (fe_pp ? pp_z0 : pu_z0) : (fe_pp ? pp_p1 : pu_p1));
+                      src += fe_src;
+                      const unsigned char *nfl = &s.flag[(ck + fe_oz - 1) & 3][fe_nbo];
+                      double *dstp = (NCOL == 3) ? (fe_pp ? vals_pp : vals_pu) : vals_uu;
+                      const bool tile_full = (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1];
+                      if (!masked && tile_full)
+                        {
+                          // the common case is free of control flow so that the LDS reads of several rows are in
+                          // flight together
+#pragma unroll 1
+                          for (int n0 = fe_sub; n0 < NPN; n0 += 10)
+                            {
+                              long long offb[5];
+                              double valb[5];
+#pragma unroll
+                              for (int i = 0; i < 5; ++i)
+                                {
+                                  const int nl = min(n0 + 2 * i, NPN - 1); // clamped duplicates are dropped below
+                                  offb[i] = s.off[cp][nl];
+                                  valb[i] = src[nl * fe_stride];
+                                }
+#pragma unroll
+                              for (int i = 0; i < 5; ++i)
+                                if (n0 + 2 * i < NPN)
+                                  {
+                                    dstp[fe_mul * offb[i] + fe_dst] = valb[i];
+                                    src[(n0 + 2 * i) * fe_stride] = 0.0; // these slabs are the next planes' accumulators
+                                  }
+                            }
+                        }
+                      else
+                        {
+#pragma unroll 1
+                          for (int nl = fe_sub; nl < NPN; nl += 2)
+                            {
+                              const long long off = s.off[cp][nl];
+                              double val = src[nl * fe_stride];
+                              src[nl * fe_stride] = 0.0;
+                              if (masked)
+                                {
+                                  const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
+                                  const unsigned row_flag = s.flag[ck & 3][hn], nflag = nfl[hn];
+                                  const bool rcon = (row_flag >> 3) & 1u;
+                                  if (fe_pp)
+                                    {
+                                      if (rcon)
+                                        val = (fe_o == 13) ? s.ex[cp][nl][0] : 0.0;
+                                      else if ((nflag >> 3) & 1u)
+                                        val = 0.0;
+                                    }
+                                  else if (rcon || ((nflag >> fe_d) & 1u))
+                                    val = 0.0; // constrained row (active set) or eliminated column
+                                }
+                              if (off >= 0) // owned node (partial tiles at the high faces)
+                                dstp[fe_mul * off + fe_dst] = val;
+                            }
+                        }
+                    }
+                  stamp(8);
+                  lds_barrier(); // placeholders are read above, cleared below
+                  stamp(9);
+                  if (t < NPN)
+                    {
+                      const int nl = t;
+                      const double patch = s.ex[cp][nl][1];
+                      s.ex[cp][nl][0] = 0.0;
+                      s.ex[cp][nl][1] = 0.0;
+                      const long long off = s.off[cp][nl];
+                      if (masked && off >= 0 && patch != 0.0)
+                        {
+                          // constrained displacement rows whose element diagonal vanished in some cell
+                          const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
+                          for (int c = 0; c < 3; ++c)
+                            if ((row_flag >> c) & 1u)
+                              vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * 27 + 13 * NCOL + c] += patch;
+                        }
+                    }
+                }
+              else
+                {
+                  // boundary plane (rows with fewer than 27 neighbours, or slot order != lattice order):
+                  // same thread <-> element mapping, the lattice offset of CSR slot sl comes from inv27
+                  if (t < 2 * 108)
+                    {
+                      int tq = t;
+                      asm volatile("" : "+v"(tq));
+                      const int ge = tq % 108, gsub = tq / 108;
+                      const bool gpp = ge >= 81;
+                      const int sl = gpp ? ge - 81 : ge / 3, gd = gpp ? 3 : ge % 3; // CSR slot, column component
+#pragma unroll 1
+                      for (int n0 = gsub; n0 < NPN; n0 += 10)
+                        {
+                          long long offb[5];
+                          int degb[5];
+                          unsigned char ob[5];
+#pragma unroll
+                          for (int i = 0; i < 5; ++i)
+                            {
+                              const int nl = min(n0 + 2 * i, NPN - 1);
+                              offb[i] = (n0 + 2 * i < NPN) ? s.off[cp][nl] : -1;
+                              degb[i] = s.deg[cp][nl] & 0xffff;
+                              ob[i] = 0xff;
+                              if (offb[i] >= 0 && sl < degb[i])
+                                ob[i] = cv.inv27[(long long)s.row[cp][nl] * 27 + sl];
+                            }
+#pragma unroll
+                          for (int i = 0; i < 5; ++i)
+                            if (ob[i] != 0xff)
+                              {
+                                const int nl = n0 + 2 * i, o = ob[i];
+                                const int oz = o / 9, o9 = o - 9 * oz;
+                                double *src = gpp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nl * 9 + o9)
+                                                  : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nl * 27 + o9 * 3 + gd);
+                                double val = *src;
+                                *src = 0.0;
+                                if (masked)
+                                  {
+                                    const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
+                                    const int oy = o9 / 3, ox = o9 - 3 * oy;
+                                    const unsigned row_flag = s.flag[ck & 3][hn];
+                                    const unsigned nflag = s.flag[(ck + oz - 1) & 3][hn + (ox - 1) + PH * (oy - 1)];
+                                    const bool rcon = (row_flag >> 3) & 1u;
+                                    if (gpp)
+                                      {
+                                        if (rcon)
+                                          val = (o == 13) ? s.ex[cp][nl][0] : 0.0;
+                                        else if ((nflag >> 3) & 1u)
+                                          val = 0.0;
+                                      }
+                                    else if (rcon || ((nflag >> gd) & 1u))
+                                      val = 0.0;
+                                  }
+                                if constexpr (NCOL == 3)
+                                  {
+                                    if (gpp)
+                                      vals_pp[offb[i] + sl] = val;
+                                    else
+                                      vals_pu[3 * offb[i] + sl * 3 + gd] = val;
+                                  }
+                                else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
+                                  vals_uu[16 * offb[i] + (long long)3 * 4 * degb[i] + sl * 4 + gd] = val;
+                              }
+                        }
+                    }
+                  lds_barrier(); // placeholders are read above, cleared below
+                  if (t < NPN)
+                    {
+                      const int nl = t;
+                      const double patch = s.ex[cp][nl][1];
+                      s.ex[cp][nl][0] = 0.0;
+                      s.ex[cp][nl][1] = 0.0;
+                      const long long off = s.off[cp][nl];
+                      if (masked && off >= 0 && patch != 0.0)
+                        {
+                          const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
+                          const int deg = s.deg[cp][nl] & 0xffff, row = s.row[cp][nl];
+                          int sself = 0;
+                          for (int q = 0; q < deg; ++q)
+                            if (cv.inv27[(long long)row * 27 + q] == 13)
+                              sself = q;
+                          for (int c = 0; c < 3; ++c)
+                            if ((row_flag >> c) & 1u)
+                              vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += patch;
+                        }
+                    }
+                }
+            }
+        }
+      stamp(3);
+    }
+  } // namespace
+
+  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s)
+  {
+    if (v.dim != 3)
+      return PFM_ERR_UNSUPPORTED;
+    int rc = ensure_g1();
+    if (rc)
+      return rc;
+    const MatScal S = make_mat_scal(p, cv);
+    const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+    const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
+    // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
+    int nch = (OWZ + 26) / 27;
+    const int zc = (OWZ + nch - 1) / nch;
+    nch = (OWZ + zc - 1) / zc;
+    const unsigned nb = (unsigned)(ntx * nty * nch);
+    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(nb), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], zc, nullptr);
+    else if (getenv("PFM_PHI_CLK")) // profiling only
+      {
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+          return PFM_ERR_HIP;
+        (void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        if (atoi(getenv("PFM_PHI_CLK")) == 2)
+          hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+                             d_values[0], zc, d_dbg);
+        else
+          hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+                             d_values[0], zc, d_dbg);
+        unsigned long long h[16];
+        (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char *names[4] = {"load+barrier", "entries+push", "barrier", "copy-out"};
+        fprintf(stderr, "[k_cart_phi4 phase clock, wave 0, cycles per workgroup (%d planes)]", zc);
+        for (int i = 0; i < 4; ++i)
+          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
+        for (int i = 0; i < 4; ++i)
+          fprintf(stderr, " role%d=%.0f", i, (double)h[4 + i] / nb);
+        fprintf(stderr, " copy-loop=%.0f copy-barrier=%.0f", (double)h[8] / nb, (double)h[9] / nb);
+        fprintf(stderr, "\n");
+      }
+    else
+      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], zc,
+                         nullptr);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+} // namespace pfm

@@ -173,6 +173,14 @@ namespace
         if (found != (int)(re - rb))
           return false;
       }
+    std::vector<uint8_t> regular((size_t)NO, 0);
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        bool reg = (c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]) == no;
+        for (int o = 0; reg && o < no; ++o)
+          reg = inv[(size_t)n * no + o] == (uint8_t)o;
+        regular[n] = reg ? 1 : 0;
+      }
     CartView &cv = c->cv;
     cv.NX = NX;
     cv.NY = NY;
@@ -185,6 +193,7 @@ namespace
       }
     cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
     cv.inv27 = dev_upload(c, inv.data(), inv.size());
+    cv.row_regular = dev_upload(c, regular.data(), regular.size());
     return true;
   }
 } // namespace

@@ -42,6 +42,7 @@ namespace pfm
     double h[3];
     const int32_t *local_of_box; // [NX*NY*NZ] lattice index -> local node id
     const uint8_t *inv27;        // [n_owned][3^dim] CSR neighbour slot -> lattice offset index, 0xff = none
+    const uint8_t *row_regular;  // [n_owned] 1: the row has all 3^dim neighbours and slot s is lattice offset s
   };
 
   struct HaloPeer
@@ -59,6 +60,7 @@ namespace pfm
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s);
   bool cart_matrix_supported(int dim);
+  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s);
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
