@@ -39,6 +39,24 @@ def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
     return 120.0 if residual_only else 744.0
 
 
+def measured_hbm_traffic(dim: int, n: int, residual_only: bool):
+    """HBM bytes per assembly from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes of this very
+    command, tools/hbm_traffic.sh; summaries committed under profiles/).  None if this workload was not profiled."""
+    import glob
+
+    key = f"hbm_traffic_{dim}d_{n}{'_residual' if residual_only else ''}.json"
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key)))
+    if not found:
+        return None, None
+    rec = json.load(open(found[-1]))
+    total = 0.0
+    for name, d in rec["per_launch"].items():
+        if residual_only and name not in ("k_cart_residual3", "k_cart_residual", "k_state_set"):
+            continue
+        total += d.get("write_bytes", 0.0) + d.get("fetch_bytes", 0.0)
+    return total, os.path.relpath(found[-1], ROOT)
+
+
 def sneddon_params(h: float, dim: int):
     from cracks_amd.capi import PfmParams
 
@@ -222,6 +240,7 @@ def main():
     if rank == 0:
         abytes = algorithmic_bytes_per_cell(dim, residual_only) * lp.mesh.n_cells  # this rank's launch
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = measured_hbm_traffic(dim, n, residual_only) if world == 1 else (None, None)
         out = {
             "metric": "assembled DoFs/sec (residual+Jacobian) on 3D Sneddon" if (dim == 3 and not residual_only)
             else f"assembled DoFs/sec ({'residual-only' if residual_only else 'residual+Jacobian'}) on {dim}D Sneddon",
@@ -239,7 +258,8 @@ def main():
                        "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
                        "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": abytes,
                          "kernel_ms": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
         }

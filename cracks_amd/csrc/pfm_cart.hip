@@ -579,8 +579,13 @@ namespace pfm
                          hipStream_t s);
 
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
-                           double *const *d_values, double *res_pde, double *res_tot, hipStream_t s)
+                           double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
+                           hipStream_t s_residual)
   {
+    // the residual and the Jacobian only read the node state: on different streams they overlap
+    // (s_residual == s: plain stream order)
+    hipStream_t s_jac = s;
+    s = s_residual;
     int rc = ensure_tab();
     if (rc)
       return rc;
@@ -610,7 +615,7 @@ namespace pfm
     if (hipGetLastError() != hipSuccess)
       return PFM_ERR_HIP;
     if (!residual_only)
-      return launch_cart_matrix(v, cv, p, d_values, s);
+      return launch_cart_matrix(v, cv, p, d_values, s_jac);
     return PFM_OK;
   }
 } // namespace pfm

@@ -23,6 +23,8 @@
 #include "pfm_cart_common.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace pfm
@@ -191,9 +193,21 @@ namespace pfm
     }
 
     // =====================================================================================
-    template <int NCOL /* 3 blocked, 4 interleaved */>
-    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, MatScal S, double *__restrict__ vals)
+    template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */>
+    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, MatScal S, double *__restrict__ vals,
+                                                         unsigned long long *__restrict__ dbg)
     {
+      long long tclk = 0;
+      auto stamp = [&](int phase) __attribute__((always_inline)) {
+        if constexpr (CLK)
+          {
+            const long long now = clock64();
+            if (threadIdx.x == 0 && phase >= 0)
+              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+            tclk = now;
+          }
+      };
+      stamp(-1);
       __shared__ double s_tab[NNUM3 * CS3];  // moment tables [number][cell]; layer 1 stored z-mirrored
       __shared__ double s_stage[NN3 * STG];  // staged rows [node][81]; w*g(q) [27][90] during the cell phase
       __shared__ double s_po[NH3], s_poo[NH3];
@@ -216,6 +230,7 @@ namespace pfm
       if (t < 2)
         s_info[t] = 0;
       __syncthreads();
+      stamp(0);
       if (t < NH3)
         {
           const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / (H3X * H3Y);
@@ -264,6 +279,7 @@ namespace pfm
             atomicAdd(&s_info[1], 1);
         }
       __syncthreads();
+      stamp(0);
 
       // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
       if (t < 3 * CS3)
@@ -296,6 +312,7 @@ namespace pfm
             s_stage[(qz * 9 + q) * CS3 + cs] = wg[q];
         }
       __syncthreads();
+      stamp(1);
 
       // ---- cell phase b: moment tables, thread <-> (cell, {A^x, A^y, A^z, T^xy, T^xz, T^yz}).
       // The upper layer (l = 1) is written z-mirrored so that both half-waves run the same node phase.
@@ -385,6 +402,7 @@ namespace pfm
             }
         }
       __syncthreads();
+      stamp(2);
 
       // ---- node phase + copy-out per row component
       const int wave = t >> 6, lane = t & 63;
@@ -411,6 +429,7 @@ namespace pfm
           else
             uu3_dispatch<2>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
           __syncthreads();
+          stamp(3);
           if (regular_tile)
             {
 #pragma unroll 2
@@ -437,6 +456,7 @@ namespace pfm
                 }
             }
           __syncthreads();
+          stamp(4);
         }
       (void)owned;
     }
@@ -452,9 +472,24 @@ namespace pfm
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu);
+      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+    else if (getenv("PFM_UU_CLK")) // profiling only
+      {
+        static unsigned long long *d_dbg = nullptr;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+          return PFM_ERR_HIP;
+        (void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        hipLaunchKernelGGL((k_cart_uu3<3, true>), dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, d_dbg);
+        unsigned long long h[16];
+        (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const char *names[5] = {"phase0", "w*g", "moments", "node(x3)", "copy-out(x3)"};
+        fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per tile]");
+        for (int i = 0; i < 5; ++i)
+          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
+        fprintf(stderr, "\n");
+      }
     else
-      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu);
+      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
 } // namespace pfm

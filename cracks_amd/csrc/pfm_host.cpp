@@ -432,6 +432,12 @@ extern "C"
         if (p.d_recv)
           hipFree(p.d_recv);
       }
+    if (c->side_stream)
+      {
+        hipStreamDestroy(c->side_stream);
+        hipEventDestroy(c->ev_fork);
+        hipEventDestroy(c->ev_join);
+      }
     for (auto &ev : c->ev_pool)
       {
         hipEventDestroy(ev.first);
@@ -634,24 +640,6 @@ extern "C"
                        c->prm.timestep_number > 0;
     const bool cart = c->kernel_path == 1 && !split && (residual_only || cart_matrix_supported(c->v.dim));
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
-    // zero the outputs (cracks.cc:2133-2137); the row-owner kernels of the cartesian path
-    // write every entry exactly once and need no zeroing pass
-    if (!cart)
-      e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
-    if (!cart && e == hipSuccess && residual_only)
-      e = hipMemsetAsync(d_res_tot, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
-    if (e == hipSuccess && !residual_only)
-      for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
-        {
-          if (!d_values[b])
-            return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
-          // the row-owner kernels write every value once; only the structurally zero (u,phi)
-          // block of the blocked layout has no kernel and is cleared here
-          if (!cart || (c->n_blocks == 4 && b == 1))
-            e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
-        }
-    if (e != hipSuccess)
-      return hipfail(c, e, "zero outputs");
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing)
       {
@@ -667,8 +655,55 @@ extern "C"
         ++c->ev_used;
         hipEventRecord(ev0, c->stream);
       }
-    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream)
+    // Optional (PFM_SIDE_STREAM=1): residual kernel and clearing of the structurally zero (u,phi) block on a side
+    // stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
+    // the kernels do not share CUs usefully; off by default.
+    hipStream_t s_res = c->stream;
+    const bool fork = cart && !residual_only && getenv("PFM_SIDE_STREAM");
+    if (fork)
+      {
+        if (!c->side_stream)
+          {
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+              return fail(c, PFM_ERR_HIP, "side stream");
+          }
+        s_res = c->side_stream;
+        e = hipEventRecord(c->ev_fork, c->stream);
+        if (e == hipSuccess)
+          e = hipStreamWaitEvent(s_res, c->ev_fork, 0);
+        if (e != hipSuccess)
+          return hipfail(c, e, "fork");
+      }
+    // zero the outputs (cracks.cc:2133-2137); the row-owner kernels of the cartesian path
+    // write every entry exactly once and need no zeroing pass
+    if (!cart)
+      e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
+    if (!cart && e == hipSuccess && residual_only)
+      e = hipMemsetAsync(d_res_tot, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
+    if (e == hipSuccess && !residual_only)
+      for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
+        {
+          if (!d_values[b])
+            return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
+          // the row-owner kernels write every value once; only the structurally zero (u,phi)
+          // block of the blocked layout has no kernel and is cleared here
+          if (!cart || (c->n_blocks == 4 && b == 1))
+            e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), cart ? s_res : c->stream);
+        }
+    if (e != hipSuccess)
+      return hipfail(c, e, "zero outputs");
+    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res)
                   : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+    if (fork)
+      {
+        e = hipEventRecord(c->ev_join, s_res);
+        if (e == hipSuccess)
+          e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        if (e != hipSuccess)
+          return hipfail(c, e, "join");
+      }
     if (rc == PFM_OK && overlay_uu)
       rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream);
     if (ev1)

@@ -58,7 +58,8 @@ namespace pfm
   int launch_halo_unpack(const DevView &v, const int32_t *d_nodes, int64_t n, const double *d_buf,
                          hipStream_t s);
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
-                           double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s);
+                           double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
+                           hipStream_t s_residual);
   bool cart_matrix_supported(int dim);
   int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s);
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
@@ -72,6 +73,8 @@ struct pfm_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side_stream = nullptr;            // residual + clearing of the (u,phi) block, concurrent with the Jacobian
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   pfm::DevView v{};
   pfm_params prm{};
   bool have_params = false;
