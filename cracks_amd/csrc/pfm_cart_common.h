@@ -26,6 +26,15 @@ namespace pfm
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
+    // local node id of lattice node (i,j,k): arithmetic for owned nodes when they are numbered lexicographically
+    // (checked at context creation), table look-up otherwise (ghost layers, arbitrary numberings)
+    __device__ __forceinline__ int cart_local_id(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.owned_lex && i >= cv.o0[0] && i <= cv.o1[0] && j >= cv.o0[1] && j <= cv.o1[1] && k >= cv.o0[2] && k <= cv.o1[2])
+        return (i - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((j - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (k - cv.o0[2]));
+      return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+    }
+
     template <int N, class F>
     __device__ __forceinline__ __attribute__((always_inline)) void static_for(F &&f)
     {

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 namespace pfm
@@ -360,7 +361,7 @@ namespace pfm
           {
             const long long now = clock64();
             if (threadIdx.x == 0 && phase >= 0)
-              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+              dbg[(size_t)blockIdx.x * 16 + phase] += (unsigned long long)(now - tclk); // one slot per workgroup
             tclk = now;
           }
       };
@@ -394,7 +395,7 @@ namespace pfm
             const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
             if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
               {
-                const int n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                const int n = cart_local_id(cv, gi, gj, kz);
                 pv[0] = v.u[0][n];
                 pv[1] = v.u[1][n];
                 pv[2] = v.u[2][n];
@@ -428,7 +429,7 @@ namespace pfm
             const int gi = i0 + nx, gj = j0 + ny;
             if (gi <= cv.o1[0] && gj <= cv.o1[1])
               {
-                r_row = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                r_row = cart_local_id(cv, gi, gj, kz);
                 r_off = v.nadj_ptr[r_row];
                 r_deg = (int)(v.nadj_ptr[r_row + 1] - r_off);
                 if (!cv.row_regular[r_row])
@@ -578,7 +579,7 @@ namespace pfm
           if constexpr (CLK == 2)
             {
               if (lane == 0)
-                atomicAdd(dbg + 4 + role, (unsigned long long)(clock64() - tclk));
+                dbg[(size_t)blockIdx.x * 16 + 4 + role] += (unsigned long long)(clock64() - tclk);
             }
           stamp(1);
           lds_barrier();
@@ -689,8 +690,19 @@ namespace pfm
                 }
               else
                 {
-                  // boundary plane (rows with fewer than 27 neighbours, or slot order != lattice order):
-                  // same thread <-> element mapping, the lattice offset of CSR slot sl comes from inv27
+                  // boundary plane (rows with fewer than 27 neighbours, or slot order != lattice order): same
+                  // thread <-> element mapping, the lattice offset of CSR slot sl comes from inv27.  The slot maps of
+                  // the 49 rows are staged in the nodal ring slot of plane ck, which is dead until the next step.
+                  unsigned char *s_inv = reinterpret_cast<unsigned char *>(&s.U[lo][0][0]);
+                  for (int idx = t; idx < NPN * 27; idx += NT4)
+                    {
+                      const int nl = idx / 27, sl = idx - nl * 27;
+                      unsigned char o = 0xff;
+                      if (s.off[cp][nl] >= 0 && sl < (s.deg[cp][nl] & 0xffff))
+                        o = cv.inv27[(long long)s.row[cp][nl] * 27 + sl];
+                      s_inv[idx] = o;
+                    }
+                  lds_barrier();
                   if (t < 2 * 108)
                     {
                       int tq = t;
@@ -699,58 +711,43 @@ namespace pfm
                       const bool gpp = ge >= 81;
                       const int sl = gpp ? ge - 81 : ge / 3, gd = gpp ? 3 : ge % 3; // CSR slot, column component
 #pragma unroll 1
-                      for (int n0 = gsub; n0 < NPN; n0 += 10)
+                      for (int nl = gsub; nl < NPN; nl += 2)
                         {
-                          long long offb[5];
-                          int degb[5];
-                          unsigned char ob[5];
-#pragma unroll
-                          for (int i = 0; i < 5; ++i)
+                          const int o = s_inv[nl * 27 + sl];
+                          if (o == 0xff)
+                            continue;
+                          const long long off = s.off[cp][nl];
+                          const int oz = o / 9, o9 = o - 9 * oz;
+                          double *src = gpp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nl * 9 + o9)
+                                            : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nl * 27 + o9 * 3 + gd);
+                          double val = *src;
+                          *src = 0.0;
+                          if (masked)
                             {
-                              const int nl = min(n0 + 2 * i, NPN - 1);
-                              offb[i] = (n0 + 2 * i < NPN) ? s.off[cp][nl] : -1;
-                              degb[i] = s.deg[cp][nl] & 0xffff;
-                              ob[i] = 0xff;
-                              if (offb[i] >= 0 && sl < degb[i])
-                                ob[i] = cv.inv27[(long long)s.row[cp][nl] * 27 + sl];
+                              const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
+                              const int oy = o9 / 3, ox = o9 - 3 * oy;
+                              const unsigned row_flag = s.flag[ck & 3][hn];
+                              const unsigned nflag = s.flag[(ck + oz - 1) & 3][hn + (ox - 1) + PH * (oy - 1)];
+                              const bool rcon = (row_flag >> 3) & 1u;
+                              if (gpp)
+                                {
+                                  if (rcon)
+                                    val = (o == 13) ? s.ex[cp][nl][0] : 0.0;
+                                  else if ((nflag >> 3) & 1u)
+                                    val = 0.0;
+                                }
+                              else if (rcon || ((nflag >> gd) & 1u))
+                                val = 0.0;
                             }
-#pragma unroll
-                          for (int i = 0; i < 5; ++i)
-                            if (ob[i] != 0xff)
-                              {
-                                const int nl = n0 + 2 * i, o = ob[i];
-                                const int oz = o / 9, o9 = o - 9 * oz;
-                                double *src = gpp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nl * 9 + o9)
-                                                  : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nl * 27 + o9 * 3 + gd);
-                                double val = *src;
-                                *src = 0.0;
-                                if (masked)
-                                  {
-                                    const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
-                                    const int oy = o9 / 3, ox = o9 - 3 * oy;
-                                    const unsigned row_flag = s.flag[ck & 3][hn];
-                                    const unsigned nflag = s.flag[(ck + oz - 1) & 3][hn + (ox - 1) + PH * (oy - 1)];
-                                    const bool rcon = (row_flag >> 3) & 1u;
-                                    if (gpp)
-                                      {
-                                        if (rcon)
-                                          val = (o == 13) ? s.ex[cp][nl][0] : 0.0;
-                                        else if ((nflag >> 3) & 1u)
-                                          val = 0.0;
-                                      }
-                                    else if (rcon || ((nflag >> gd) & 1u))
-                                      val = 0.0;
-                                  }
-                                if constexpr (NCOL == 3)
-                                  {
-                                    if (gpp)
-                                      vals_pp[offb[i] + sl] = val;
-                                    else
-                                      vals_pu[3 * offb[i] + sl * 3 + gd] = val;
-                                  }
-                                else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
-                                  vals_uu[16 * offb[i] + (long long)3 * 4 * degb[i] + sl * 4 + gd] = val;
-                              }
+                          if constexpr (NCOL == 3)
+                            {
+                              if (gpp)
+                                vals_pp[off + sl] = val;
+                              else
+                                vals_pu[3 * off + sl * 3 + gd] = val;
+                            }
+                          else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
+                            vals_uu[16 * off + (long long)3 * 4 * (s.deg[cp][nl] & 0xffff) + sl * 4 + gd] = val;
                         }
                     }
                   lds_barrier(); // placeholders are read above, cleared below
@@ -801,17 +798,21 @@ namespace pfm
     else if (getenv("PFM_PHI_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
-        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+        const size_t nd = (size_t)nb * 16;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
-        (void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
         if (atoi(getenv("PFM_PHI_CLK")) == 2)
           hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], zc, d_dbg);
         else
           hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], zc, d_dbg);
-        unsigned long long h[16];
-        (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> hall(nd);
+        (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long h[16] = {};
+        for (size_t i = 0; i < nd; ++i)
+          h[i % 16] += hall[i];
         const char *names[4] = {"load+barrier", "entries+push", "barrier", "copy-out"};
         fprintf(stderr, "[k_cart_phi4 phase clock, wave 0, cycles per workgroup (%d planes)]", zc);
         for (int i = 0; i < 4; ++i)

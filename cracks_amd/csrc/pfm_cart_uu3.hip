@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 namespace pfm
@@ -203,7 +204,7 @@ namespace pfm
           {
             const long long now = clock64();
             if (threadIdx.x == 0 && phase >= 0)
-              atomicAdd(dbg + phase, (unsigned long long)(now - tclk));
+              dbg[(size_t)blockIdx.x * 8 + phase] += (unsigned long long)(now - tclk); // one slot per tile: no contention
             tclk = now;
           }
       };
@@ -428,7 +429,7 @@ namespace pfm
             uu3_dispatch<1>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
           else
             uu3_dispatch<2>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
-          __syncthreads();
+          lds_barrier();
           stamp(3);
           if (regular_tile)
             {
@@ -455,7 +456,7 @@ namespace pfm
                   vals[base + (long long)c * NCOL * deg + s * NCOL + d] = val;
                 }
             }
-          __syncthreads();
+          lds_barrier();
           stamp(4);
         }
       (void)owned;
@@ -476,12 +477,16 @@ namespace pfm
     else if (getenv("PFM_UU_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
-        if (!d_dbg && hipMalloc((void **)&d_dbg, 16 * sizeof(unsigned long long)) != hipSuccess)
+        const size_t nd = (size_t)nb * 8;
+        if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
-        (void)hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
         hipLaunchKernelGGL((k_cart_uu3<3, true>), dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, d_dbg);
-        unsigned long long h[16];
-        (void)hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> hall(nd);
+        (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long h[8] = {};
+        for (size_t i = 0; i < nd; ++i)
+          h[i % 8] += hall[i];
         const char *names[5] = {"phase0", "w*g", "moments", "node(x3)", "copy-out(x3)"};
         fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per tile]");
         for (int i = 0; i < 5; ++i)

@@ -194,6 +194,17 @@ namespace
     cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
     cv.inv27 = dev_upload(c, inv.data(), inv.size());
     cv.row_regular = dev_upload(c, regular.data(), regular.size());
+    cv.owned_lex = 1;
+    {
+      const int64_t OWX = o1[0] - o0[0] + 1, OWY = o1[1] - o0[1] + 1;
+      for (int32_t n = 0; n < NO && cv.owned_lex; ++n)
+        {
+          const int64_t b = box_of_local[n];
+          const int64_t i = b % NX, j = (b / NX) % NY, k = b / ((int64_t)NX * NY);
+          if ((i - o0[0]) + OWX * ((j - o0[1]) + OWY * (k - o0[2])) != n)
+            cv.owned_lex = 0;
+        }
+    }
     return true;
   }
 } // namespace
