@@ -331,6 +331,15 @@ namespace pfm
     // adds its 4 cell columns in a fixed order and writes its rows exactly once.  Nodal values live in a
     // two-plane LDS ring: every plane is read from HBM/L2 once per tile.
     // =====================================================================================
+    // local node id of lattice node (i,j,k): arithmetic for lexicographically numbered owned nodes (checked at
+    // context creation), table look-up otherwise (ghost layers)
+    __device__ __forceinline__ int cart_local_id3(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.owned_lex && i >= cv.o0[0] && i <= cv.o1[0] && j >= cv.o0[1] && j <= cv.o1[1] && k >= cv.o0[2] && k <= cv.o1[2])
+        return (i - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((j - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (k - cv.o0[2]));
+      return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+    }
+
     constexpr int RTX = 16, RTY = 16;           // cell columns per workgroup = threads
     constexpr int RNX = RTX - 1, RNY = RTY - 1; // owned nodes per tile plane
     constexpr int RHX = RTX + 1, RHY = RTY + 1; // nodal halo per plane
@@ -367,7 +376,7 @@ namespace pfm
             double val[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
               {
-                const int n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * kz)];
+                const int n = cart_local_id3(cv, gi, gj, kz);
                 val[0] = v.u[0][n];
                 val[1] = v.u[1][n];
                 val[2] = v.u[2][n];
@@ -531,7 +540,7 @@ namespace pfm
           __syncthreads();
           if (emit && node_ok)
             {
-              const int row = cv.local_of_box[(i0 + cx) + (long long)cv.NX * ((j0 + cy) + (long long)cv.NY * ck)];
+              const int row = cart_local_id3(cv, i0 + cx, j0 + cy, ck);
               const unsigned fl = v.node_flags[row];
 #pragma unroll
               for (int c = 0; c < 4; ++c)

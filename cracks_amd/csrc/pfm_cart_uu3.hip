@@ -241,7 +241,7 @@ namespace pfm
           unsigned char f = 0;
           if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ)
             {
-              n = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * gk)];
+              n = cart_local_id(cv, gi, gj, gk);
               a = v.phi_old[n];
               b = v.phi_oldold[n];
               f = v.node_flags[n];
@@ -262,7 +262,7 @@ namespace pfm
           bool regular = false;
           if (gi <= cv.o1[0] && gj <= cv.o1[1])
             {
-              const int r = cv.local_of_box[gi + (long long)cv.NX * (gj + (long long)cv.NY * k)];
+              const int r = cart_local_id(cv, gi, gj, k);
               const long long off = v.nadj_ptr[r];
               deg = (int)(v.nadj_ptr[r + 1] - off);
               base = (long long)NCOL * NCOL * off;
