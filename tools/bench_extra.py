@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Measurements of SURVEY.md §8(d) that are not the headline bench line (run on the GPU box):
+
+  config5  Miehe-shear-like adaptive sequence (cracks.cc:4137-4174 rebuilds everything after refine_mesh):
+           unit-slit squares, one-block (direct solver) layout, stress split active
+           (decompose_stress_rhs = decompose_stress_matrix = 1, timestep_number > 0), a refined band with hanging
+           nodes that grows with the crack.  Per mesh: context rebuild time (pfm_ctx_create + pattern +
+           pfm_set_constraints) and assembly times.  Single GPU: the sub-box partition of cracks_amd/partition.py
+           covers uniform boxes only.
+  pcie     what the host round trip of today's Trilinos solve would add to config 3: device->host copy of the
+           CSR values and residuals over PCIe (never part of bench.py's value).
+
+  python tools/bench_extra.py config5 [--levels 7] [--out profiles/rNN/config5_miehe_amr.json]
+  python tools/bench_extra.py pcie    [--n 216]    [--out profiles/rNN/pcie_216cube.json]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def config5(args):
+    import torch
+
+    from cracks_amd import mesh as M
+    from cracks_amd.assembler import Assembler, node_flags_from_dof_flags
+    from cracks_amd.capi import PfmParams
+
+    rows = []
+    base = M.slit_mesh(args.levels)  # 2^(levels+1) cells per edge
+    n = 2 ** (args.levels + 1)
+    h = 1.0 / n
+    for step in range(args.meshes):
+        tip = 0.5 - 0.08 * step  # the band follows a crack growing to the left
+        cc = base.coords[base.cells].mean(axis=1)
+        flags = (np.abs(cc[:, 1] - 0.5) < 6 * h) & (cc[:, 0] > tip - 4 * h)
+        t0 = time.perf_counter()
+        mesh = M.refine_cells(base, flags)
+        t_refine = time.perf_counter() - t0
+        lay = M.DofLayout(mesh.n_nodes, 2, blocked=False)
+        hfine = 0.5 * h
+        dt = 1.0e-4
+        prm = PfmParams(lambda_=121.15e3, mu=80.77e3, G_c=2.7, alpha_eps=2.0 * hfine * np.sqrt(2.0),
+                        constant_k=1.0e-10 * hfine, pressure=0.0, alpha_biot=0.0, gamma_penal=0.0, timestep=dt,
+                        time=5 * dt, old_timestep=dt, old_old_timestep=dt, decompose_stress_rhs=1.0,
+                        decompose_stress_matrix=1.0, timestep_number=5, outer_solver=0, use_old_timestep_pf=0,
+                        reserved=0)
+        ch = M.hanging_constraints(mesh, lay)
+        cu = M.update_constraints(mesh, lay, M.miehe_shear_dirichlet_dofs(mesh, lay))
+        # state: shear ramp + noise, phase field with a smeared crack along the slit line
+        rng = np.random.default_rng(1234 + step)
+        x, y = mesh.coords[:, 0], mesh.coords[:, 1]
+        u = np.stack([-5 * dt * y + 1e-6 * rng.standard_normal(x.size), 1e-6 * rng.standard_normal(x.size)], axis=1)
+        phi = np.clip(1.0 - np.exp(-np.abs(y - 0.5) / (4 * hfine)) * (x > tip), 0.0, 1.0)
+        sol = ch.distribute(lay.pack(u, phi))
+        old = ch.distribute(lay.pack(0.9 * u, np.clip(phi + 0.01 * rng.random(x.size), 0, 1)))
+        oldold = ch.distribute(lay.pack(0.8 * u, np.clip(phi + 0.02 * rng.random(x.size), 0, 1)))
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        asm = Assembler(mesh, blocked=False)
+        asm.allocate_matrix()
+        t_ctx = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        asm.set_params(prm)
+        asm.set_constraints(node_flags_from_dof_flags(lay, cu.flag, ch.flag))
+        t_con = time.perf_counter() - t0
+        asm.set_vectors(sol, old, oldold)
+
+        def timed(residual_only, reps=20):
+            for _ in range(3):
+                asm.assemble_system(residual_only)
+            asm.synchronize()
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                asm.assemble_system(residual_only)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t)
+            asm.synchronize()
+            return 1e3 * float(np.median(ts))
+
+        t_jac, t_res = timed(False), timed(True)
+        rows.append({"mesh": step, "cells": int(mesh.n_cells), "nodes": int(mesh.n_nodes), "dofs": int(lay.n_dofs),
+                     "hanging_nodes": int(mesh.hn_nodes.size), "refine_host_s": round(t_refine, 3),
+                     "context_rebuild_s": round(t_ctx, 4), "set_params_constraints_s": round(t_con, 4),
+                     "assemble_jacobian_ms": round(t_jac, 4), "assemble_residual_ms": round(t_res, 4),
+                     "dofs_per_s_jacobian": lay.n_dofs / (t_jac * 1e-3), "kernel_path": asm.ctx.kernel_path})
+        print(rows[-1], flush=True)
+        del asm
+    out = {"config": "SURVEY §8(d) config 5 stand-in: unit slit, %d^2 base cells, refined band, one-block layout, "
+                     "stress split active, single MI355X" % n, "rows": rows}
+    if args.out:
+        json.dump(out, open(os.path.join(ROOT, args.out), "w"), indent=1)
+
+
+def pcie(args):
+    import torch
+
+    n = args.n
+    nodes = (n + 1) ** 3
+    nbytes_values = nodes * 27 * 16 * 8
+    nbytes_res = nodes * 4 * 8 * 2
+    dev = torch.device("cuda", 0)
+    chunk = 1 << 30  # copy 1 GiB pieces through one pinned buffer: what a host solver hand-over would do
+    src = torch.empty(chunk // 8, dtype=torch.float64, device=dev).normal_()
+    dst = torch.empty(chunk // 8, dtype=torch.float64).pin_memory()
+    for _ in range(2):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(8):
+        t = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    gbs = chunk / float(np.median(ts)) / 1e9
+    out = {"workload": f"Sneddon 3D {n}^3: {nbytes_values / 1e9:.2f} GB of CSR values + {nbytes_res / 1e9:.3f} GB of residuals",
+           "d2h_pinned_GBps": gbs, "d2h_seconds_for_one_jacobian": (nbytes_values + nbytes_res) / (gbs * 1e9)}
+    print(out, flush=True)
+    if args.out:
+        json.dump(out, open(os.path.join(ROOT, args.out), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["config5", "pcie"])
+    ap.add_argument("--levels", type=int, default=7)
+    ap.add_argument("--meshes", type=int, default=5)
+    ap.add_argument("--n", type=int, default=216)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    config5(a) if a.what == "config5" else pcie(a)
