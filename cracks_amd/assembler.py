@@ -129,6 +129,11 @@ class Context:
         self._check(self.lib.pfm_state_set(self._h, C.c_void_p(sol_ptr), C.c_void_p(old_ptr),
                                            C.c_void_p(oldold_ptr), 1), "pfm_state_set")
 
+    def state_set_host(self, sol: np.ndarray, old: np.ndarray, oldold: np.ndarray):
+        a = [np.ascontiguousarray(x, np.float64) for x in (sol, old, oldold)]
+        self._check(self.lib.pfm_state_set(self._h, capi.np_ptr(a[0], np.float64), capi.np_ptr(a[1], np.float64),
+                                           capi.np_ptr(a[2], np.float64), 0), "pfm_state_set")
+
     def halo_register(self, send_ptr, send_nodes, recv_ptr, recv_nodes):
         sp = np.ascontiguousarray(send_ptr, np.int64)
         sn = np.ascontiguousarray(send_nodes, np.int32)
@@ -193,6 +198,31 @@ class Context:
     @property
     def device_bytes(self) -> int:
         return int(self.lib.pfm_ctx_device_bytes(self._h))
+
+    # ---- include/pfm_newton.h
+    def diag_mass_device(self, mass_ptr: int):
+        """cracks.cc:2514-2562 into a device vector over the owned nodes."""
+        self._check(self.lib.pfm_diag_mass_device(self._h, C.c_void_p(mass_ptr)), "pfm_diag_mass_device")
+
+    def active_set_device(self, res_tot_ptr: int, mass_ptr: int, c: float, sol_ptr: int, old_ptr: int, cycle_ptr: int):
+        """cracks.cc:2837-2909; returns (active, cycling, changed)."""
+        counts = (C.c_int64 * 3)()
+        self._check(self.lib.pfm_active_set_device(self._h, C.c_void_p(res_tot_ptr), C.c_void_p(mass_ptr), C.c_double(c),
+                                                   C.c_void_p(sol_ptr), C.c_void_p(old_ptr), C.c_void_p(cycle_ptr), counts),
+                    "pfm_active_set_device")
+        return int(counts[0]), int(counts[1]), int(counts[2])
+
+    def get_constraints(self) -> np.ndarray:
+        flags = np.empty(self.n_nodes, np.uint8)
+        self._check(self.lib.pfm_get_constraints(self._h, capi.np_ptr(flags, np.uint8)), "pfm_get_constraints")
+        return flags
+
+    def functionals(self, cell_owned: Optional[np.ndarray] = None):
+        """(bulk energy, crack energy, TCV) of the node state in the context (cracks.cc:3553-3701)."""
+        out = (C.c_double * 3)()
+        mask = None if cell_owned is None else np.ascontiguousarray(cell_owned, np.uint8)
+        self._check(self.lib.pfm_functionals(self._h, None if mask is None else capi.np_ptr(mask, np.uint8), out), "pfm_functionals")
+        return float(out[0]), float(out[1]), float(out[2])
 
 
 class Assembler:

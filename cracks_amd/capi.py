@@ -25,6 +25,8 @@ EXPORTS = [
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_assemble_device",
     "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms",
+    # include/pfm_newton.h
+    "pfm_diag_mass_device", "pfm_active_set_device", "pfm_get_constraints", "pfm_functionals",
 ]
 
 
@@ -104,6 +106,10 @@ def load():
     lib.pfm_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.pfm_ctx_device_bytes.argtypes = [vp]
     lib.pfm_ctx_device_bytes.restype = i64
+    lib.pfm_diag_mass_device.argtypes = [vp, vp]
+    lib.pfm_active_set_device.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, C.POINTER(i64)]
+    lib.pfm_get_constraints.argtypes = [vp, vp]
+    lib.pfm_functionals.argtypes = [vp, vp, C.POINTER(C.c_double)]
     _LIB = lib
     return lib
 

@@ -94,6 +94,11 @@ struct pfm_ctx
   double *d_stage_res[2] = {nullptr, nullptr};
   double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<pfm::HaloPeer> peers;
+  // scratch of the Newton-side sweeps (pfm_newton.hip)
+  unsigned long long *d_counts = nullptr;
+  double *d_partial = nullptr;
+  int64_t n_partial = 0;
+  uint8_t *d_cell_owned = nullptr;
   // measurement (pfm_timing_enable)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -53,6 +53,7 @@ class StepRecord:
     bulk_energy: float = 0.0
     crack_energy: float = 0.0
     load: Optional[float] = None
+    tcv: Optional[float] = None  # total crack volume (cracks.cc:3553-3611), device sweep only
 
 
 def lumped_phase_mass(mesh: M.Mesh, layout: M.DofLayout) -> np.ndarray:
@@ -332,8 +333,12 @@ class ActiveSetDriver:
             self.solution = self.ch.distribute(self.solution)
             self.timestep = tmp_timestep
             p = s.params
-            rec.bulk_energy, rec.crack_energy = compute_energy(s.mesh, s.layout, self.solution, p.lambda_, p.mu,
-                                                               p.G_c, p.alpha_eps, p.constant_k)
+            if hasattr(self.asm, "functionals"):  # device sweep (pfm_functionals), cracks.cc:3553-3701
+                rec.bulk_energy, rec.crack_energy, rec.tcv = self.asm.functionals(self.solution, self.old_solution,
+                                                                                  self.old_old_solution, self._params())
+            else:
+                rec.bulk_energy, rec.crack_energy = compute_energy(s.mesh, s.layout, self.solution, p.lambda_, p.mu,
+                                                                   p.G_c, p.alpha_eps, p.constant_k)
             if s.compute_load:
                 rec.load = compute_load_2d(s.mesh, s.layout, self.solution, p.lambda_, p.mu)
             self.log(f"No {self.timestep_number} time {self.time:g} bulk energy: {rec.bulk_energy:g} "
@@ -378,3 +383,9 @@ class GpuAssembler:
         self.ctx.set_constraints(node_flags_from_dof_flags(self.layout, cu.flag, ch.flag))
         values, res_pde, res_tot = self.ctx.assemble_host(sol, old, oldold, residual_only)
         return (None if residual_only else self._global_matrix(values)), res_pde, res_tot
+
+    def functionals(self, sol, old, oldold, params):
+        """(bulk energy, crack energy, TCV) on the device (include/pfm_newton.h)."""
+        self.ctx.set_params(params)
+        self.ctx.state_set_host(sol, old, oldold)
+        return self.ctx.functionals()

@@ -8,6 +8,10 @@
 //   decompose_stress           cracks.cc:1923-2120
 //   Tensors::get_divergence_u  cracks.cc:331-347
 //   Tensors::get_Identity      cracks.cc:290-301
+// and of the Newton-side sweeps that share its data
+//   assemble_diag_mass_matrix  cracks.cc:2514-2562
+//   active-set update          cracks.cc:2837-2886, 2903-2909
+//   compute_energy, compute_tcv cracks.cc:3615-3701, 3553-3611
 // and a textbook restatement of the deal.II pieces the reference leans on and
 // that are NOT under /root/reference (deal.II >= 9.5, CMakeLists.txt:14):
 //   FE_Q<dim>(1) x (dim+1) FESystem, local dof i <-> (vertex i/(dim+1), comp i%(dim+1))
@@ -23,7 +27,9 @@
 //
 // Parity pin: the oracle is checked against the reference's golden Newton
 // tables (tests/golden/kat.json) to all 7 printed digits and
-// against the six Catch eigen-decomposition cases (cracks.cc:1740-1919).
+// against the six Catch eigen-decomposition cases (cracks.cc:1740-1919); the energy functionals are
+// pinned by the bulk/crack energies of the reference's *.statistics files (tests/test_newton_goldens.py,
+// tests/test_newton_sweeps.py).  compute_tcv has no golden in the reference's tests: parity unpinned for TCV.
 // The reference binary itself cannot be built here (deal.II, Trilinos and p4est
 // are absent), so there is no oracle/_ref.
 //
@@ -956,6 +962,137 @@ namespace
   }
 } // namespace
 
+
+  // ------------------------------------------------------------------------------------
+  // Newton-side sweeps over the same mesh data
+  // ------------------------------------------------------------------------------------
+
+  // assemble_diag_mass_matrix, cracks.cc:2514-2562.  QGaussLobatto<dim>(2) (deal.II): the 2^dim
+  // vertices of the reference cell with weight 2^-dim each, so shape_value(i,q) = delta(vertex(i), q)
+  // and the phase-field dof of vertex a receives JxW(vertex a) = det J(a) 2^-dim.
+  template <int dim>
+  void diag_mass(int64_t n_cells, int32_t n_dofs, const int32_t *cell_nodes, const double *coords,
+                 const int32_t *cell_dofs, double *diag)
+  {
+    constexpr int nv = 1 << dim, dpc = nv * (dim + 1);
+    for (int32_t i = 0; i < n_dofs; ++i)
+      diag[i] = 0.0; // diag_mass = 0, cracks.cc:2518
+    for (int64_t cell = 0; cell < n_cells; ++cell)
+      {
+        double xv[nv][dim];
+        for (int v = 0; v < nv; ++v)
+          for (int d = 0; d < dim; ++d)
+            xv[v][d] = coords[(int64_t)cell_nodes[cell * nv + v] * dim + d];
+        double local_rhs[dpc] = {};
+        for (int q = 0; q < nv; ++q) // Lobatto point q = vertex q
+          {
+            double J[dim][dim];
+            for (int i = 0; i < dim; ++i)
+              for (int j = 0; j < dim; ++j)
+                {
+                  double s = 0.0;
+                  for (int v = 0; v < nv; ++v)
+                    {
+                      double g = 1.0;
+                      for (int d = 0; d < dim; ++d)
+                        {
+                          const double x = (q >> d) & 1;
+                          if (d == j)
+                            g *= ((v >> d) & 1) ? 1.0 : -1.0;
+                          else
+                            g *= ((v >> d) & 1) ? x : (1.0 - x);
+                        }
+                      s += xv[v][i] * g;
+                    }
+                  J[i][j] = s;
+                }
+            double det;
+            if constexpr (dim == 2)
+              det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+            else
+              det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                    J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+            const double JxW = det / (double)nv;
+            for (int i = 0; i < dpc; ++i)
+              {
+                if (i % (dim + 1) != dim)
+                  continue; // only look at phase field, cracks.cc:2548
+                const double N = (i / (dim + 1) == q) ? 1.0 : 0.0;
+                local_rhs[i] += N * N * JxW;
+              }
+          }
+        for (int i = 0; i < dpc; ++i)
+          diag[cell_dofs[cell * dpc + i]] += local_rhs[i]; // cracks.cc:2555-2556
+      }
+  }
+
+  // compute_energy (cracks.cc:3615-3701) and compute_tcv (cracks.cc:3553-3611) over the owned cells
+  template <int dim>
+  void functionals(int64_t n_cells, const int32_t *cell_nodes, const double *coords, const int32_t *cell_dofs,
+                   const double *cell_lambda, const double *cell_mu, const pfm_params &prm, const double *sol,
+                   const uint8_t *cell_owned, double *out)
+  {
+    constexpr int nv = 1 << dim, dpc = nv * (dim + 1);
+    FEValues<dim> fe_values;
+    double local_bulk_energy = 0.0, local_crack_energy = 0.0, local_integral = 0.0;
+    for (int64_t cell = 0; cell < n_cells; ++cell)
+      {
+        if (cell_owned && !cell_owned[cell])
+          continue; // cell->is_locally_owned()
+        double xv[nv][dim];
+        for (int v = 0; v < nv; ++v)
+          for (int d = 0; d < dim; ++d)
+            xv[v][d] = coords[(int64_t)cell_nodes[cell * nv + v] * dim + d];
+        fe_values.reinit(xv);
+        const double lame_coefficient_lambda = cell_lambda ? cell_lambda[cell] : prm.lambda;
+        const double lame_coefficient_mu = cell_mu ? cell_mu[cell] : prm.mu;
+        for (int q = 0; q < FEValues<dim>::nq; ++q)
+          {
+            T2<dim> grad_u;
+            double grad_pf[dim] = {}, u[dim] = {}, pf = 0.0;
+            for (int i = 0; i < dpc; ++i)
+              {
+                const int v = i / (dim + 1), c = i % (dim + 1);
+                const double val = sol[cell_dofs[cell * dpc + i]];
+                if (c < dim)
+                  {
+                    u[c] += val * fe_values.N[q][v];
+                    for (int d = 0; d < dim; ++d)
+                      grad_u[c][d] += val * fe_values.dN[q][v][d];
+                  }
+                else
+                  {
+                    pf += val * fe_values.N[q][v];
+                    for (int d = 0; d < dim; ++d)
+                      grad_pf[d] += val * fe_values.dN[q][v][d];
+                  }
+              }
+            T2<dim> E;
+            for (int a = 0; a < dim; ++a)
+              for (int b = 0; b < dim; ++b)
+                E[a][b] = 0.5 * (grad_u[a][b] + grad_u[b][a]);
+            const double tr_E = trace(E);
+            double tr_e_2 = 0.0; // trace(E*E)
+            for (int a = 0; a < dim; ++a)
+              for (int b = 0; b < dim; ++b)
+                tr_e_2 += E[a][b] * E[b][a];
+            const double psi_e = 0.5 * lame_coefficient_lambda * tr_E * tr_E + lame_coefficient_mu * tr_e_2;
+            double gg = 0.0, ug = 0.0;
+            for (int d = 0; d < dim; ++d)
+              {
+                gg += grad_pf[d] * grad_pf[d];
+                ug += u[d] * grad_pf[d];
+              }
+            local_bulk_energy += ((1 + prm.constant_k) * pf * pf + prm.constant_k) * psi_e * fe_values.JxW[q];
+            local_crack_energy += prm.G_c / 2.0 * ((pf - 1) * (pf - 1) / prm.alpha_eps + prm.alpha_eps * gg) * fe_values.JxW[q];
+            local_integral += ug * fe_values.JxW[q]; // cracks.cc:3587
+          }
+      }
+    out[0] = local_bulk_energy;
+    out[1] = local_crack_energy;
+    out[2] = local_integral;
+  }
+
 extern "C"
 {
   // Full assembly (cracks.cc:2133-2475 on one rank: compress() is a no-op then).
@@ -1076,5 +1213,77 @@ extern "C"
           stress_minus[2 * i + j] = sm[i][j];
         }
     return err;
+  }
+
+  // assemble_diag_mass_matrix (cracks.cc:2514-2562); diag has one entry per dof (zero for displacement dofs).
+  int oracle_diag_mass(int dim, int64_t n_cells, int32_t n_dofs, const int32_t *cell_nodes, const double *coords,
+                       const int32_t *cell_dofs, double *diag)
+  {
+    if (dim == 2)
+      diag_mass<2>(n_cells, n_dofs, cell_nodes, coords, cell_dofs, diag);
+    else if (dim == 3)
+      diag_mass<3>(n_cells, n_dofs, cell_nodes, coords, cell_dofs, diag);
+    else
+      return ORACLE_BAD_ARG;
+    return ORACLE_OK;
+  }
+
+  // out[0] = bulk energy, out[1] = crack energy (cracks.cc:3615-3701), out[2] = TCV (cracks.cc:3553-3611)
+  int oracle_functionals(int dim, int64_t n_cells, const int32_t *cell_nodes, const double *coords,
+                         const int32_t *cell_dofs, const double *cell_lambda, const double *cell_mu,
+                         const pfm_params *prm, const double *sol, const uint8_t *cell_owned, double *out)
+  {
+    if (!prm || !out)
+      return ORACLE_BAD_ARG;
+    if (dim == 2)
+      functionals<2>(n_cells, cell_nodes, coords, cell_dofs, cell_lambda, cell_mu, *prm, sol, cell_owned, out);
+    else if (dim == 3)
+      functionals<3>(n_cells, cell_nodes, coords, cell_dofs, cell_lambda, cell_mu, *prm, sol, cell_owned, out);
+    else
+      return ORACLE_BAD_ARG;
+    return ORACLE_OK;
+  }
+
+  // Active-set update of newton_active_set (cracks.cc:2837-2886) and the cycle counter (cracks.cc:2903-2909),
+  // written over dofs (the reference's cell loop visits every phase-field dof once: "already processed").
+  //   is_phi / hanging: per dof flags;  active: in = active_set_old, out = active_set
+  //   counts[0] = active dofs, counts[1] = cycling dofs, counts[2] = 1 if the set changed
+  int oracle_active_set(int32_t n_dofs, const uint8_t *is_phi, const uint8_t *hanging, const double *residual_relevant,
+                        const double *diag_mass_relevant, double c, double *solution, const double *old_solution_relevant,
+                        int32_t *cycle_counter, uint8_t *active, int64_t *counts)
+  {
+    const unsigned int n_cycling_threshold = 5; // cracks.cc:2866
+    int64_t n_active = 0, n_cycling_dofs = 0, changed = 0;
+    for (int32_t idx = 0; idx < n_dofs; ++idx)
+      {
+        const uint8_t was = active[idx];
+        uint8_t now = 0;
+        if (is_phi[idx] && !hanging[idx])
+          {
+            const double old_value = old_solution_relevant[idx];
+            const double new_value = solution[idx];
+            const double massm = diag_mass_relevant[idx];
+            const double gap = new_value - old_value;
+            const double active_set_tolarance = 0.0;
+            if (!(residual_relevant[idx] / massm + c * (gap) <= active_set_tolarance &&
+                  ((unsigned int)cycle_counter[idx] < n_cycling_threshold)))
+              {
+                if ((unsigned int)cycle_counter[idx] >= n_cycling_threshold)
+                  ++n_cycling_dofs;
+                now = 1; // constraints_update.add_line(idx); inhomogeneity 0
+                solution[idx] = old_value;
+                ++n_active;
+              }
+          }
+        if (was && !now)
+          ++cycle_counter[idx]; // cracks.cc:2905-2908
+        if (was != now)
+          changed = 1;
+        active[idx] = now;
+      }
+    counts[0] = n_active;
+    counts[1] = n_cycling_dofs;
+    counts[2] = changed;
+    return ORACLE_OK;
   }
 }

@@ -64,6 +64,8 @@ def lib():
         _LIB.oracle_cell_local.restype = C.c_int
         _LIB.oracle_eigen_2x2.restype = C.c_int
         _LIB.oracle_decompose_stress_2d.restype = C.c_int
+        for name in ("oracle_diag_mass", "oracle_functionals", "oracle_active_set"):
+            getattr(_LIB, name).restype = C.c_int
     return _LIB
 
 
@@ -153,3 +155,46 @@ def decompose_stress_2d(E, E_LinU, lam, mu, derivative: bool):
                                            C.c_double(mu), C.c_int(1 if derivative else 0),
                                            _p(sp, np.float64), _p(sm, np.float64))
     return err, sp.reshape(2, 2), sm.reshape(2, 2)
+
+
+# ---- Newton-side sweeps (oracle.cpp: diag_mass, functionals, oracle_active_set) -----------------------------
+def diag_mass(mesh, layout) -> np.ndarray:
+    """assemble_diag_mass_matrix, cracks.cc:2514-2562; one entry per dof."""
+    cells = np.ascontiguousarray(mesh.cells, np.int32)
+    coords = np.ascontiguousarray(mesh.coords, np.float64)
+    cell_dofs = layout.cell_dofs(cells)
+    diag = np.zeros(layout.n_dofs)
+    err = lib().oracle_diag_mass(C.c_int(mesh.dim), C.c_int64(mesh.n_cells), C.c_int32(layout.n_dofs),
+                                 _p(cells, np.int32), _p(coords, np.float64), _p(cell_dofs, np.int32), _p(diag, np.float64))
+    assert err == 0
+    return diag
+
+
+def functionals(mesh, layout, params: PfmParams, sol, cell_lambda=None, cell_mu=None, cell_owned=None):
+    """(bulk energy, crack energy, TCV): compute_energy cracks.cc:3615-3701, compute_tcv cracks.cc:3553-3611."""
+    cells = np.ascontiguousarray(mesh.cells, np.int32)
+    coords = np.ascontiguousarray(mesh.coords, np.float64)
+    cell_dofs = layout.cell_dofs(cells)
+    out = np.zeros(3)
+    own = None if cell_owned is None else np.ascontiguousarray(cell_owned, np.uint8)
+    err = lib().oracle_functionals(C.c_int(mesh.dim), C.c_int64(mesh.n_cells), _p(cells, np.int32), _p(coords, np.float64),
+                                   _p(cell_dofs, np.int32), _p(cell_lambda, np.float64), _p(cell_mu, np.float64),
+                                   C.byref(params), _p(np.ascontiguousarray(sol, np.float64), np.float64),
+                                   _p(own, np.uint8), _p(out, np.float64))
+    assert err == 0
+    return float(out[0]), float(out[1]), float(out[2])
+
+
+def active_set(is_phi, hanging, residual_relevant, diag_mass_relevant, c, solution, old_solution, cycle_counter, active):
+    """cracks.cc:2837-2886, 2903-2909 over dofs; solution, cycle_counter, active are updated in place.
+    Returns (n_active, n_cycling, changed)."""
+    n = solution.size
+    counts = np.zeros(3, np.int64)
+    err = lib().oracle_active_set(C.c_int32(n), _p(np.ascontiguousarray(is_phi, np.uint8), np.uint8),
+                                  _p(np.ascontiguousarray(hanging, np.uint8), np.uint8),
+                                  _p(np.ascontiguousarray(residual_relevant, np.float64), np.float64),
+                                  _p(np.ascontiguousarray(diag_mass_relevant, np.float64), np.float64), C.c_double(c),
+                                  _p(solution, np.float64), _p(np.ascontiguousarray(old_solution, np.float64), np.float64),
+                                  _p(cycle_counter, np.int32), _p(active, np.uint8), _p(counts, np.int64))
+    assert err == 0
+    return int(counts[0]), int(counts[1]), int(counts[2])

@@ -1,0 +1,149 @@
+"""Newton-side sweeps: diag_mass, energies / TCV, active-set update.
+
+CPU part: the oracle restatements (oracle.cpp) against the independent numpy versions of the harness
+(cracks_amd/newton.py, which reproduce the reference's *.statistics goldens in tests/test_newton_goldens.py).
+GPU part: pfm_diag_mass_device / pfm_functionals / pfm_active_set_device through the C ABI against the oracle."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_api as O
+from cracks_amd import mesh as M
+from cracks_amd import newton as N
+
+
+def _cases():
+    return [cases.perturbed(cases.kat_sneddon_2d()), cases.perturbed(cases.kat_sneddon_3d()),
+            cases.perturbed(cases.kat_miehe_shear_1())]
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c.name)
+def test_oracle_diag_mass_matches_numpy(case):
+    d = O.diag_mass(case.mesh, case.layout)
+    ref = N.lumped_phase_mass(case.mesh, case.layout)
+    assert np.abs(d - ref).max() <= 1e-14 * np.abs(ref).max()
+    node, comp = case.layout.node_comp_of_dof()
+    assert np.all(d[comp < case.mesh.dim] == 0.0)
+    # the lumped masses add up to the volume of the domain
+    x = case.mesh.coords
+    vol = np.prod(x.max(axis=0) - x.min(axis=0))
+    assert abs(d.sum() - vol) <= 1e-12 * vol
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c.name)
+def test_oracle_functionals_match_numpy(case):
+    p = case.params
+    bulk, crack, tcv = O.functionals(case.mesh, case.layout, p, case.sol)
+    b2, c2 = N.compute_energy(case.mesh, case.layout, case.sol, p.lambda_, p.mu, p.G_c, p.alpha_eps, p.constant_k)
+    assert abs(bulk - b2) <= 1e-12 * max(1.0, abs(b2))
+    assert abs(crack - c2) <= 1e-12 * max(1.0, abs(c2))
+    assert np.isfinite(tcv)
+
+
+def _active_set_inputs(case, seed=7):
+    rng = np.random.default_rng(seed)
+    lay = case.layout
+    node, comp = lay.node_comp_of_dof()
+    is_phi = (comp == lay.dim).astype(np.uint8)
+    hanging = case.ch.flag.astype(np.uint8)
+    mass = O.diag_mass(case.mesh, lay)
+    res = rng.standard_normal(lay.n_dofs) * mass.max()
+    sol = case.sol.copy()
+    old = case.old.copy()
+    cyc = rng.integers(0, 7, lay.n_dofs).astype(np.int32)
+    active = (rng.random(lay.n_dofs) < 0.3).astype(np.uint8) * is_phi * (1 - hanging)
+    return is_phi, hanging, res, mass, sol, old, cyc, active
+
+
+def test_oracle_active_set_matches_harness_logic():
+    case = cases.perturbed(cases.kat_sneddon_2d())
+    is_phi, hanging, res, mass, sol, old, cyc, active = _active_set_inputs(case)
+    c = 10.0
+    # numpy statement of newton.py's loop body
+    with np.errstate(divide="ignore", invalid="ignore"):
+        crit = res / mass + c * (sol - old)
+    cand = is_phi.astype(bool) & ~hanging.astype(bool)
+    inactive = (crit <= 0.0) & (cyc < 5)
+    act_ref = cand & ~inactive
+    sol_ref = sol.copy()
+    sol_ref[act_ref] = old[act_ref]
+    cyc_ref = cyc.copy()
+    cyc_ref[active.astype(bool) & ~act_ref] += 1
+    n_cyc_ref = int(np.sum(act_ref & (cyc >= 5)))
+    counts = O.active_set(is_phi, hanging, res, mass, c, sol, old, cyc, active)
+    assert counts == (int(act_ref.sum()), n_cyc_ref, 1)
+    assert np.array_equal(active.astype(bool), act_ref)
+    assert np.array_equal(sol, sol_ref) and np.array_equal(cyc, cyc_ref)
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _gpu_assembler(case):
+    from cracks_amd.assembler import Assembler, node_flags_from_dof_flags
+
+    asm = Assembler(case.mesh, case.layout.blocked, cell_lambda=case.cell_lambda, cell_mu=case.cell_mu)
+    asm.set_params(case.params)
+    asm.set_constraints(node_flags_from_dof_flags(case.layout, case.cu.flag, case.ch.flag))
+    asm.set_vectors(case.sol, case.old, case.oldold)
+    return asm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases() + [cases.perturbed(cases.kat_miehe_tension())], ids=lambda c: c.name)
+def test_gpu_diag_mass_and_functionals(case):
+    import torch
+
+    asm = _gpu_assembler(case)
+    lay, dim = case.layout, case.mesh.dim
+    mass = torch.zeros(case.mesh.n_nodes, dtype=torch.float64, device=asm.dev)
+    asm.ctx.set_stream(torch.cuda.current_stream(asm.dev).cuda_stream)
+    asm.ctx.diag_mass_device(mass.data_ptr())
+    ref = O.diag_mass(case.mesh, lay)[lay.dof(np.arange(case.mesh.n_nodes), dim)]
+    got = mass.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    # functionals use the node state of the context: upload it the way an assembly does
+    asm.ctx.state_set_device(asm.solution.data_ptr(), asm.old_solution.data_ptr(), asm.old_old_solution.data_ptr())
+    got = asm.ctx.functionals()
+    want = O.functionals(case.mesh, lay, case.params, case.sol, case.cell_lambda, case.cell_mu)
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-12 * max(1.0, abs(w)), (got, want)
+    # owned-cell mask (what a rank of a partitioned run passes)
+    mask = (np.arange(case.mesh.n_cells) % 3 != 0).astype(np.uint8)
+    got = asm.ctx.functionals(mask)
+    want = O.functionals(case.mesh, lay, case.params, case.sol, case.cell_lambda, case.cell_mu, mask)
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-12 * max(1.0, abs(w)), (got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c.name)
+def test_gpu_active_set(case):
+    import torch
+
+    from cracks_amd.assembler import node_flags_from_dof_flags
+
+    asm = _gpu_assembler(case)
+    lay, dim, nn = case.layout, case.mesh.dim, case.mesh.n_nodes
+    is_phi, hanging, res, mass, sol, old, cyc, active = _active_set_inputs(case)
+    phi_dof = lay.dof(np.arange(nn), dim)
+    # start from the flags of the previous active set
+    cu_flag = case.cu.flag.copy()
+    cu_flag[phi_dof] = active[phi_dof]
+    asm.set_constraints(node_flags_from_dof_flags(lay, cu_flag, case.ch.flag))
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(asm.dev, dt)
+    d_res, d_mass, d_sol, d_old = t(res), t(mass[phi_dof]), t(sol), t(old)
+    d_cyc = t(cyc[phi_dof], torch.int32)
+    asm.ctx.set_stream(torch.cuda.current_stream(asm.dev).cuda_stream)
+    got = asm.ctx.active_set_device(d_res.data_ptr(), d_mass.data_ptr(), 10.0, d_sol.data_ptr(), d_old.data_ptr(),
+                                    d_cyc.data_ptr())
+    want = O.active_set(is_phi, hanging, res, mass, 10.0, sol, old, cyc, active)
+    sol = case.ch.distribute(sol)  # cracks.cc:2888-2890
+    assert got == want
+    assert np.array_equal(d_cyc.cpu().numpy(), cyc[phi_dof])
+    assert np.abs(d_sol.cpu().numpy() - sol).max() <= 1e-15
+    flags = asm.ctx.get_constraints()
+    assert np.array_equal((flags >> dim) & 1, active[phi_dof])
+    # the displacement bits are untouched
+    want_flags = node_flags_from_dof_flags(lay, cu_flag, case.ch.flag)
+    assert np.array_equal(flags & ((1 << dim) - 1), want_flags & ((1 << dim) - 1))
