@@ -596,6 +596,54 @@ namespace pfm
                 {
                   // interior plane: slot order = lattice order, all rows full.  Thread <-> one of the 108 elements
                   // of a row, two rows at a time; consecutive lanes store consecutive addresses.
+                  if (NCOL == 3 && !masked && (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1])
+                    {
+                      // Blocked layout, interior plane without constraint flags (the common case): the 7 rows of a
+                      // y-line of the tile are ONE contiguous run of 7*81 (phi,u) + 7*27 (phi,phi) values.  Thread <->
+                      // up to 3 fixed positions of that run; per y-line 3 LDS reads and 3 fully coalesced stores.
+                      int tq = t;
+                      asm volatile("" : "+v"(tq));
+                      double *srck[3];
+                      double *dstk[3];
+                      int rstride[3], mul[3];
+                      bool act[3];
+#pragma unroll
+                      for (int q = 0; q < 3; ++q)
+                        {
+                          const int f = tq + NT4 * q;
+                          act[q] = f < PN * 108;
+                          const bool is_pp = f >= PN * 81;
+                          const int g = is_pp ? f - PN * 81 : f;
+                          const int per = is_pp ? 27 : 81;
+                          const int nx = g / per, e = g - nx * per;
+                          const int o = is_pp ? e : e / 3, d = is_pp ? 0 : e - 3 * (e / 3);
+                          const int oz = o / 9, o9 = o - 9 * oz;
+                          double *slab = is_pp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1));
+                          srck[q] = slab + (is_pp ? nx * 9 + o9 : nx * 27 + o9 * 3 + d);
+                          rstride[q] = is_pp ? PN * 9 : PN * 27;
+                          dstk[q] = (is_pp ? vals_pp : vals_pu) + g;
+                          mul[q] = is_pp ? 1 : 3;
+                        }
+                      long long off0[PN];
+                      double val[PN][3];
+#pragma unroll
+                      for (int ny = 0; ny < PN; ++ny)
+                        {
+                          off0[ny] = s.off[cp][ny * PN];
+#pragma unroll
+                          for (int q = 0; q < 3; ++q)
+                            val[ny][q] = act[q] ? srck[q][ny * rstride[q]] : 0.0;
+                        }
+#pragma unroll
+                      for (int ny = 0; ny < PN; ++ny)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                          if (act[q])
+                            {
+                              dstk[q][mul[q] * off0[ny]] = val[ny][q];
+                              srck[q][ny * rstride[q]] = 0.0; // these slabs are the next planes' accumulators
+                            }
+                    }
                   if (t < 2 * 108)
                     {
                       // thread <-> element fe_e of a row (0..80 (phi,u), 81..107 (phi,phi)); recomputed per plane
@@ -615,7 +663,9 @@ namespace pfm
                       const unsigned char *nfl = &s.flag[(ck + fe_oz - 1) & 3][fe_nbo];
                       double *dstp = (NCOL == 3) ? (fe_pp ? vals_pp : vals_pu) : vals_uu;
                       const bool tile_full = (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1];
-                      if (!masked && tile_full)
+                      if (NCOL == 3 && !masked && tile_full)
+                        ; // handled by the row-run copy below (all 256 threads)
+                      else if (!masked && tile_full)
                         {
                           // the common case is free of control flow so that the LDS reads of several rows are in
                           // flight together
