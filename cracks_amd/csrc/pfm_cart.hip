@@ -607,8 +607,6 @@ namespace pfm
     const unsigned nb = (unsigned)((n_waves + 3) / 4);
     if (v.dim == 2)
       hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
-    else if (getenv("PFM_RES_V1")) // previous generation, kept for A/B profiling
-      hipLaunchKernelGGL(k_cart_residual<3>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
     else
       {
         const int ntx = (int)((OWX + RNX - 1) / RNX), nty = (int)((OWY + RNY - 1) / RNY);

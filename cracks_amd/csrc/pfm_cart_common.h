@@ -1,5 +1,5 @@
 // pfm_cart_common.h — tile geometry, 1-D Gauss tables and per-launch scalars shared by the
-// row-owner Jacobian kernels (pfm_cart_matrix.hip, pfm_cart_phi.hip).  Everything lives in
+// row-owner Jacobian kernels (pfm_cart_uu3.hip, pfm_cart_phi4.hip).  Everything lives in
 // an anonymous namespace: each translation unit owns its copy of the __constant__ table.
 #pragma once
 #include "pfm_internal.h"
@@ -11,13 +11,7 @@ namespace pfm
 {
   namespace
   {
-    constexpr int TX = 8, TY = 8, NTHREADS = 512;
-    constexpr int HX = TX + 2, HY = TY + 2;      // nodal halo (10 x 10 x 3)
-    constexpr int NH = HX * HY * 3;              // 300 halo nodes
-    constexpr int CX = TX + 1, CY = TY + 1;      // cells per layer (9 x 9)
-    constexpr int CS = CX * CY * 2;              // 162 cell slots (two layers)
-    constexpr int NNUM_UU = 64;                  // 27 A + 36 T + 1 spare
-    constexpr int STG = 81;                      // staged row width (27 slots x 3), odd => conflict-free
+    constexpr int STG = 81; // staged row width (27 slots x 3), odd => conflict-free
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e.
     // every wave would sit out the full HBM write latency of the rows it has just streamed out; the kernels
     // here never exchange data through global memory inside a launch, so outstanding stores may stay in flight.
@@ -45,7 +39,7 @@ namespace pfm
         }
     }
 
-    // third-generation tiles (pfm_cart_uu3.hip, pfm_cart_phi3.hip): 8 x 4 nodes, 512 threads
+    // tiles of pfm_cart_uu3.hip: 8 x 4 nodes, 512 threads
     constexpr int T3X = 8, T3Y = 4, NT3 = 512;
     constexpr int H3X = T3X + 2, H3Y = T3Y + 2, NH3 = H3X * H3Y * 3; // nodal halo 10 x 6 x 3
     constexpr int C3X = T3X + 1, C3Y = T3Y + 1, CL3 = C3X * C3Y;     // 45 cells per layer

@@ -877,4 +877,17 @@ namespace pfm
                          nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
+  bool cart_matrix_supported(int dim) { return dim == 3; }
+
+  // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
+  // (same stream); the structurally zero (u,phi) block (cracks.cc:2333-2337) is cleared by the host side
+  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s)
+  {
+    if (v.dim != 3)
+      return PFM_ERR_UNSUPPORTED;
+    const int rc = launch_cart_uu_only(v, cv, p, d_values[0], s);
+    if (rc)
+      return rc;
+    return launch_cart_phi4(v, cv, p, d_values, s);
+  }
 } // namespace pfm

@@ -1,9 +1,9 @@
 // pfm_cart_uu3.hip — (u,u) block, row-owner kernel, third generation ("mirrored half-waves").
 //
-// Mathematics: 63 moment tables per cell, see the header of pfm_cart.hip / pfm_cart_matrix.hip.
+// Mathematics: 63 moment tables per cell, see the header of pfm_cart.hip.
 //
-// Why a third generation.  k_cart_uu (tile 8x8 nodes, both cell layers + a row staging buffer in
-// LDS = 130 KB) runs ONE workgroup per CU; its phases (halo load, cell phase, node phase, copy-out)
+// Why a third generation.  The first one (k_cart_uu, removed; tile 8x8 nodes, both cell layers + a row
+// staging buffer in LDS = 130 KB) ran ONE workgroup per CU; its phases (halo load, cell phase, node phase, copy-out)
 // are serialised by barriers and every phase's latency is exposed (profiles/r01: VALU active 38 %
 // of the wave cycles, copy-out alone at the HBM write floor).  Forcing the same code to 16 waves
 // per CU gave 1.6x; keeping one cell layer resident and the partial sums in registers did not pay
@@ -496,5 +496,10 @@ namespace pfm
     else
       hipLaunchKernelGGL(k_cart_uu3<3>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+  // entry point used by the debug overlay (pfm_ctx_force_path(ctx, 2)) and by launch_cart_matrix
+  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
+  {
+    return launch_cart_uu3(v, cv, p, vals_uu, s);
   }
 } // namespace pfm
