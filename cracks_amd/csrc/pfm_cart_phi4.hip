@@ -60,6 +60,14 @@ namespace pfm
 
     __host__ __device__ constexpr int idxC4(int al, int gi, int gj) { return al * 9 + gi * 3 + gj; }
 
+    // d/dy of one nodal field at x-vertex 0/1: depends on the z-level only, evaluated once per qz
+    __device__ __forceinline__ void dy_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double nz0,
+                                                double nz1, double ihy, double (&Dy)[2])
+    {
+      Dy[0] = (nz0 * (lo[PH] - lo[0]) + nz1 * (hi[PH] - hi[0])) * ihy;
+      Dy[1] = (nz0 * (lo[PH + 1] - lo[1]) + nz1 * (hi[PH + 1] - hi[1])) * ihy;
+    }
+
     // values of one nodal field at the (qy,qz) line of a cell: L = value at x-vertex 0/1, Dy/Dz = d/dy, d/dz there
     template <bool DY, bool DZ>
     __device__ __forceinline__ void line_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double ny0,
@@ -112,18 +120,24 @@ namespace pfm
           const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
           if (cell_ok)
             {
+              double Dy[3][2]; // d/dy depends on the z-level only
+              static_for<3>([&](auto F) __attribute__((always_inline)) {
+                constexpr int f = decltype(F)::value;
+                if constexpr ((f == D) || (D == 1) || (f == 1))
+                  dy_of_field(Ulo + f * NPH, Uhi + f * NPH, nz0, nz1, S.ih[1], Dy[f]);
+              });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
                 {
                   const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
                   const double wyz = S.vww[qy][qz];
-                  double L[4][2], Dy[3][2], Dz[3][2];
+                  double L[4][2], Dz[3][2];
                   static_for<3>([&](auto F) __attribute__((always_inline)) {
                     constexpr int f = decltype(F)::value;
-                    constexpr bool need_dy = (f == D) || (D == 1) || (f == 1);
                     constexpr bool need_dz = (f == D) || (D == 2) || (f == 2);
-                    line_of_field<need_dy, need_dz>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f],
-                                                    Dy[f], Dz[f]);
+                    double dummy_dy[2];
+                    line_of_field<false, need_dz>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f],
+                                                  dummy_dy, Dz[f]);
                     __builtin_amdgcn_sched_barrier(0);
                   });
                   {
@@ -247,16 +261,21 @@ namespace pfm
           const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
           if (cell_ok)
             {
+              double Dy[3][2]; // d/dy depends on the z-level only
+              static_for<3>([&](auto F) __attribute__((always_inline)) {
+                constexpr int f = decltype(F)::value;
+                dy_of_field(Ulo + f * NPH, Uhi + f * NPH, nz0, nz1, S.ih[1], Dy[f]);
+              });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
                 {
                   const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
                   const double wyz = S.vww[qy][qz];
-                  double L[5][2], Dy[3][2], Dz[3][2], dummy[2];
+                  double L[5][2], Dz[3][2], dummy[2];
                   static_for<3>([&](auto F) __attribute__((always_inline)) {
                     constexpr int f = decltype(F)::value;
-                    line_of_field<true, true>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], Dy[f],
-                                              Dz[f]);
+                    line_of_field<false, true>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], dummy,
+                                               Dz[f]);
                     __builtin_amdgcn_sched_barrier(0);
                   });
                   line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
