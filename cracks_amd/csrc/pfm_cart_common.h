@@ -29,6 +29,14 @@ namespace pfm
       return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
     }
 
+    // x += v on an LDS double, done by the LDS unit (ds_add_f64, no return value): one LDS instruction and no
+    // read -> wait -> add -> write round trip.  Used where a wave's lanes hit distinct addresses and the order of
+    // the adds is the program order of that wave, so the result is the same as a plain read-modify-write.
+    __device__ __forceinline__ void lds_add(double *p, double v)
+    {
+      unsafeAtomicAdd(p, v);
+    }
+
     template <int N, class F>
     __device__ __forceinline__ __attribute__((always_inline)) void static_for(F &&f)
     {

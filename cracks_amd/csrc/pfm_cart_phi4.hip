@@ -232,7 +232,7 @@ namespace pfm
                   const double txy = (bx ? t0 : -t0) + (by ? t1 : -t1);
                   const double e = txy * mz[gz] + (bz ? nza : -nza) * t2;
                   double *slab = (az == 0) ? (oz == 0 ? dst.lo_z0 : dst.lo_p1) : (oz == -1 ? dst.hi_m1 : dst.hi_z0);
-                  slab[nb + o9 * 3] += e;
+                  lds_add(&slab[nb + o9 * 3], e);
                 });
               }
           });
@@ -357,7 +357,7 @@ namespace pfm
               constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
               constexpr int o9 = (ox + 1) + 3 * (oy + 1);
               double *slab = (az == 0) ? (oz == 0 ? pp_lo_z0 : pp_lo_p1) : (oz == -1 ? pp_hi_m1 : pp_hi_z0);
-              slab[nb + o9] += M[(ax + bx) + 3 * (ay + by) + 9 * (az + bz)];
+              lds_add(&slab[nb + o9], M[(ax + bx) + 3 * (ay + by) + 9 * (az + bz)]);
             });
           }
       });
@@ -590,8 +590,8 @@ namespace pfm
                   {
                     const double dg = fabs(Mdiag[ax + 2 * ay + 4 * az]);
                     double *ex = &s.ex[az == 0 ? cp : np][nl0 + ax + PN * ay][0];
-                    ex[0] += (dg != 0.0) ? dg : avg;
-                    ex[1] += patch;
+                    lds_add(&ex[0], (dg != 0.0) ? dg : avg);
+                    lds_add(&ex[1], patch);
                   }
               });
             }
