@@ -266,13 +266,10 @@ namespace pfm
               const long long off = v.nadj_ptr[r];
               deg = (int)(v.nadj_ptr[r + 1] - off);
               base = (long long)NCOL * NCOL * off;
-              regular = deg == 27;
+              regular = cv.row_regular[r] != 0;
+              // slot maps are only read by the copy-out of irregular tiles; a regular row's map is the identity
               for (int s = 0; s < 27; ++s)
-                {
-                  const unsigned char o = cv.inv27[(long long)r * 27 + s];
-                  s_inv[nl * 27 + s] = o;
-                  regular = regular && o == s;
-                }
+                s_inv[nl * 27 + s] = regular ? (unsigned char)s : cv.inv27[(long long)r * 27 + s];
             }
           s_rowbase[nl] = base;
           s_deg[nl] = deg;
