@@ -408,13 +408,24 @@ namespace pfm
           if (col_ok && ck >= 0 && ck < cv.NZ - 1)
             {
               const double *Ulo = &s_U[lo][0][hb], *Uhi = &s_U[hi][0][hb];
+              double Dy[4][2]; // d/dy at x-vertex 0/1: depends on the z-level only
 #pragma unroll 1
               for (int p = 0; p < 9; ++p)
                 {
                   const int qy = p % 3, qz = p / 3;
                   const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy], nz0 = c_t1.n[0][qz], nz1 = c_t1.n[1][qz];
                   const double wyz = vol * c_t1.w[qy] * c_t1.w[qz];
-                  double L[6][2], Dy[4][2], Dz[4][2], Dx[4];
+                  if (qy == 0)
+                    {
+#pragma unroll
+                      for (int f = 0; f < 4; ++f)
+                        {
+                          Dy[f][0] = (nz0 * (Ulo[f * RPL + RHX] - Ulo[f * RPL]) + nz1 * (Uhi[f * RPL + RHX] - Uhi[f * RPL])) * ihy;
+                          Dy[f][1] = (nz0 * (Ulo[f * RPL + RHX + 1] - Ulo[f * RPL + 1]) +
+                                      nz1 * (Uhi[f * RPL + RHX + 1] - Uhi[f * RPL + 1])) * ihy;
+                        }
+                    }
+                  double L[6][2], Dz[4][2], Dx[4];
 #pragma unroll
                   for (int f = 0; f < 6; ++f)
                     {
@@ -430,8 +441,6 @@ namespace pfm
                         {
                           Dz[f][0] = (hi0 - lo0) * ihz;
                           Dz[f][1] = (hi1 - lo1) * ihz;
-                          Dy[f][0] = (nz0 * (a01 - a00) + nz1 * (b01 - b00)) * ihy;
-                          Dy[f][1] = (nz0 * (a11 - a10) + nz1 * (b11 - b10)) * ihy;
                           Dx[f] = (L[f][1] - L[f][0]) * ihx;
                         }
                       __builtin_amdgcn_sched_barrier(0); // one field at a time: keeps the 8 nodal values short-lived
