@@ -92,6 +92,7 @@ namespace pfm
       double omk, gc_eps, aB1p2, lap;  // 1-kappa, G_c/eps, 2(alpha_B-1) p, G_c eps vol
       double vww[3][3];                // vol w(a) w(b)
       double lapP[3][3], lapQ[3][3];   // Laplace moments [g_x][g_y]: in-plane part (times mbar_gz), d/dz part (times s(g_z))
+      double lapM[27];                 // G_c eps sum_q w grad N_a . grad N_b by moment index g_x + 3 g_y + 9 g_z
     };
 
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
@@ -199,6 +200,10 @@ namespace pfm
             s.lapP[a][b] = s.lap * (sa * s.ih[0] * s.ih[0] * g.mb[b] + sb * s.ih[1] * s.ih[1] * g.mb[a]);
             s.lapQ[a][b] = s.lap * s.ih[2] * s.ih[2] * g.mb[a] * g.mb[b];
           }
+      for (int gz = 0; gz < 3; ++gz)
+        for (int gy = 0; gy < 3; ++gy)
+          for (int gx = 0; gx < 3; ++gx) // sign = -1 where a_k != b_k, i.e. where the moment index is 1
+            s.lapM[gx + 3 * gy + 9 * gz] = g.mb[gz] * s.lapP[gx][gy] + ((gz == 1) ? -1.0 : 1.0) * s.lapQ[gx][gy];
       return s;
     }
   } // namespace

@@ -245,12 +245,11 @@ namespace pfm
                                             double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
                                             double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
     {
+      const bool use_pen = S.gamma_fac != 0.0;
       double M[27]; // M[g_x + 3 g_y + 9 g_z]
 #pragma unroll
       for (int m = 0; m < 27; ++m)
         M[m] = 0.0;
-      // G_c eps sum_q w grad N_a . grad N_b = mbar_gz P[g_x][g_y] + s(g_z)/h_z^2 G_c eps vol Q[g_x][g_y]
-      // (s = -1 where a_k != b_k), mbar_g = sum_q w m_g(q): added as sum_qz w(qz) [ m_gz(qz) P + s(g_z) ... Q ]
 #pragma unroll 1
       for (int qz = 0; qz < 3; ++qz)
         {
@@ -280,8 +279,10 @@ namespace pfm
                   });
                   line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
                                               dummy);
-                  line_of_field<false, false>(Ulo + 4 * NPH, Uhi + 4 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy,
-                                              dummy);
+                  L[4][0] = L[4][1] = 0.0;
+                  if (use_pen) // phi_old enters only through the penalisation term (gamma != 0: monolithic runs)
+                    line_of_field<false, false>(Ulo + 4 * NPH, Uhi + 4 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4],
+                                                dummy, dummy);
                   double Dx[3];
 #pragma unroll
                   for (int f = 0; f < 3; ++f)
@@ -307,12 +308,12 @@ namespace pfm
                           pfo = fmax(0.0, pfo);
                         }
                       const double trE = gu[0][0] + gu[1][1] + gu[2][2];
-                      const double e01 = 0.5 * (gu[0][1] + gu[1][0]), e02 = 0.5 * (gu[0][2] + gu[2][0]),
-                                   e12 = 0.5 * (gu[1][2] + gu[2][1]);
-                      const double EE = gu[0][0] * gu[0][0] + gu[1][1] * gu[1][1] + gu[2][2] * gu[2][2] +
-                                        2.0 * (e01 * e01 + e02 * e02 + e12 * e12);
+                      // E : E = sum_a E_aa^2 + 2 sum_{a<b} E_ab^2,  2 E_ab^2 = (g_ab + g_ba)^2 / 2
+                      const double s01 = gu[0][1] + gu[1][0], s02 = gu[0][2] + gu[2][0], s12 = gu[1][2] + gu[2][1];
+                      const double EE = (gu[0][0] * gu[0][0] + gu[1][1] * gu[1][1] + gu[2][2] * gu[2][2]) +
+                                        0.5 * (s01 * s01 + s02 * s02 + s12 * s12);
                       const double spE = S.lam * trE * trE + 2 * S.mu * EE;       // sigma+ : E
-                      const double pen = ((pf - pfo) < 0.0) ? 0.0 : S.gamma_fac; // cracks.cc:2311-2315, 2370
+                      const double pen = (!use_pen || (pf - pfo) < 0.0) ? 0.0 : S.gamma_fac; // cracks.cc:2311-2315, 2370
                       const double cq = S.omk * spE + S.gc_eps - S.aB1p2 * trE + pen;
                       const double wc = (wyz * c_g1.w[qx]) * cq;
                       X[0] += wc * c_g1.m[0][qx];
@@ -327,23 +328,20 @@ namespace pfm
                 }
             }
           const double mz[3] = {c_g1.m[0][qz], c_g1.m[1][qz], c_g1.m[2][qz]};
-          const double wz = cell_ok ? c_g1.w[qz] : 0.0;
-          double Qz[3][3]; // this z-level's share of the d/dz d/dz Laplace moment
-#pragma unroll
-          for (int gx = 0; gx < 3; ++gx)
-#pragma unroll
-            for (int gy = 0; gy < 3; ++gy)
-              {
-                Y[gx][gy] += wz * S.lapP[gx][gy];
-                Qz[gx][gy] = wz * S.lapQ[gx][gy];
-              }
 #pragma unroll
           for (int gz = 0; gz < 3; ++gz)
 #pragma unroll
             for (int gy = 0; gy < 3; ++gy)
 #pragma unroll
               for (int gx = 0; gx < 3; ++gx)
-                M[gx + 3 * gy + 9 * gz] += Y[gx][gy] * mz[gz] + (gz == 1 ? -Qz[gx][gy] : Qz[gx][gy]);
+                M[gx + 3 * gy + 9 * gz] += Y[gx][gy] * mz[gz];
+        }
+      // G_c eps sum_q w grad N_a . grad N_b is the same for every cell of the box: host-precomputed (MatScal::lapM)
+      if (cell_ok)
+        {
+#pragma unroll
+          for (int m = 0; m < 27; ++m)
+            M[m] += S.lapM[m];
         }
       // one push per cell: the 27 moments fit in registers (unlike the 54 numbers of a (phi,u) role)
       static_for<8>([&](auto A) __attribute__((always_inline)) {
