@@ -29,6 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6  # vector FP64 (= 1/2 of the guide's 157.3 TF FP32 figure), SURVEY.md §8(d)
+
+
+def algorithmic_flops_per_cell(dim: int, residual_only: bool) -> float:
+    """Second bound of SURVEY.md §8(d): flops of a tight constant-geometry formulation (FMA = 2)."""
+    if dim == 3:
+        return 1.9e4 if residual_only else 2.75e4  # midpoint of the 2-3.5e4 range quoted there
+    return 2.0e3 if residual_only else 4.0e3
 
 
 def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
@@ -254,12 +262,17 @@ def main():
             "dtype": "f64",
             "data": "synthetic (uniform hex mesh on [-10,10]^d, interpolated Sneddon crack + seeded perturbation)",
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
-                                   f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (108 nnz/row-node-comp)'}",
+                                   f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (%d nnz/row-node-comp)' % (4 * 3 ** dim)}",
                        "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
                        "setup_s": round(t_setup, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": abytes,
+                         # second bound: the kernels are FP64-issue bound, not HBM bound
+                         "fp64": {"achieved": algorithmic_flops_per_cell(dim, residual_only) * lp.mesh.n_cells /
+                                              (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
+                                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "algorithmic_flops_per_cell": algorithmic_flops_per_cell(dim, residual_only)},
                          "kernel_ms": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
         }
