@@ -43,7 +43,10 @@ def oracle(c, residual_only):
     return r, rp, ci
 
 
+# (5, 4, 61): 62 node planes = several z-chunks of the marching kernels (start-up layer, carry across steps,
+# chunk seams); (16, 9, 30): more than one tile in x and y with partial tiles at the high faces
 BOXES = [(3, (6, 6, 6), -10.0, 10.0), (3, (9, 5, 11), (-1.0, 0.0, 2.0), (2.0, 1.5, 2.7)),
+         (3, (5, 4, 61), -10.0, 10.0), (3, (16, 9, 30), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0)),
          (2, (12, 7), (-3.0, 1.0), (1.0, 2.0)), (2, (17, 17), -10.0, 10.0)]
 
 

@@ -23,6 +23,7 @@ def _global_problem(dim, n):
 
 
 @pytest.mark.parametrize("dim,n,world,path", [(3, (12, 11, 10), 2, 1), (3, (12, 11, 10), 8, 1), (3, (9, 9, 9), 4, 0),
+                                              (3, (17, 9, 70), 8, 1),  # ranks with several z-chunks and partial tiles
                                               (2, (20, 14), 4, 1)])
 def test_owned_rows_match_single_rank(dim, n, world, path):
     import torch
