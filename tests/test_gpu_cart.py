@@ -142,3 +142,15 @@ def test_cart_is_the_default_full_path_for_boxes():
     for a, b in zip(values, values_g):
         assert linf_scaled(a, b) < TOL
     assert linf_scaled(res_pde, res_g) < TOL
+
+
+@pytest.mark.parametrize("dim,n", [(3, (1, 1, 1)), (3, (2, 1, 3)), (3, (1, 8, 1)), (2, (1, 1)), (2, (3, 1))])
+def test_cart_degenerate_boxes(dim, n):
+    """Smallest lattices: every node is a boundary node, tiles and z-chunks are mostly empty."""
+    c = box_case(dim, n, -1.0, 1.0, True)
+    ctx = make_context(c)
+    _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(res_pde, r.residual_pde) < TOL
+    assert linf_scaled(res_tot, r.residual_total) < TOL
+    _full(c, path=ctx.kernel_path)
