@@ -594,11 +594,11 @@ namespace pfm
   } // namespace
 
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values,
-                         hipStream_t s);
+                         hipStream_t s, void *d_scal);
 
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
-                           hipStream_t s_residual)
+                           hipStream_t s_residual, void *d_scal)
   {
     // the residual and the Jacobian only read the node state: on different streams they overlap
     // (s_residual == s: plain stream order)
@@ -631,7 +631,7 @@ namespace pfm
     if (hipGetLastError() != hipSuccess)
       return PFM_ERR_HIP;
     if (!residual_only)
-      return launch_cart_matrix(v, cv, p, d_values, s_jac);
+      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal);
     return PFM_OK;
   }
 } // namespace pfm

@@ -366,12 +366,13 @@ namespace pfm
 
     // =====================================================================================
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */>
-    __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, MatScal S, double *__restrict__ vals_pu,
+    __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
                                                           int zc /* node planes per chunk */,
                                                           unsigned long long *__restrict__ dbg)
     {
       __shared__ Lds4 s;
+      const MatScal &S = *Sp; // per-launch scalars live in device memory: loaded where used, not pinned in SGPRs
       long long tclk = 0;
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK == 1)
@@ -845,14 +846,24 @@ namespace pfm
     }
   } // namespace
 
-  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s)
+  int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s)
   {
+    static_assert(sizeof(MatScal) <= PFM_SCAL_BYTES, "scalar buffer too small");
+    const MatScal Sh = make_mat_scal(p, cv);
+    // pageable source: the runtime stages it before returning, Sh may go out of scope
+    return hipMemcpyAsync(d_scal, &Sh, sizeof(MatScal), hipMemcpyHostToDevice, s) == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+
+  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
+                       const void *d_scal)
+  {
+    const MatScal *S = static_cast<const MatScal *>(d_scal);
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
     int rc = ensure_g1();
     if (rc)
       return rc;
-    const MatScal S = make_mat_scal(p, cv);
+    (void)p;
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
     // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
@@ -898,13 +909,17 @@ namespace pfm
 
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
   // (same stream); the structurally zero (u,phi) block (cracks.cc:2333-2337) is cleared by the host side
-  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s)
+  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
+                         void *d_scal)
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    const int rc = launch_cart_uu_only(v, cv, p, d_values[0], s);
+    int rc = upload_mat_scal(p, cv, d_scal, s); // one upload serves both Jacobian kernels
     if (rc)
       return rc;
-    return launch_cart_phi4(v, cv, p, d_values, s);
+    rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal);
+    if (rc)
+      return rc;
+    return launch_cart_phi4(v, cv, p, d_values, s, d_scal);
   }
 } // namespace pfm

@@ -195,9 +195,10 @@ namespace pfm
 
     // =====================================================================================
     template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */>
-    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, MatScal S, double *__restrict__ vals,
+    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
                                                          unsigned long long *__restrict__ dbg)
     {
+      const MatScal &S = *Sp; // per-launch scalars in device memory (see pfm_internal.h)
       long long tclk = 0;
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
@@ -460,12 +461,14 @@ namespace pfm
     }
   } // namespace
 
-  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
+  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                      const void *d_scal)
   {
     int rc = ensure_g1();
     if (rc)
       return rc;
-    const MatScal S = make_mat_scal(p, cv);
+    (void)p;
+    const MatScal *S = static_cast<const MatScal *>(d_scal);
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
@@ -495,8 +498,10 @@ namespace pfm
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   // entry point used by the debug overlay (pfm_ctx_force_path(ctx, 2)) and by launch_cart_matrix
-  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s)
+  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                          void *d_scal)
   {
-    return launch_cart_uu3(v, cv, p, vals_uu, s);
+    const int rc = upload_mat_scal(p, cv, d_scal, s);
+    return rc ? rc : launch_cart_uu3(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -419,6 +419,7 @@ extern "C"
     try
       {
         c->cart_ok = build_cart(c, m);
+        c->d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
       }
     catch (const HipFail &f)
       {
@@ -705,7 +706,7 @@ extern "C"
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
-    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res)
+    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal)
                   : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
     if (fork)
       {
@@ -716,7 +717,7 @@ extern "C"
           return hipfail(c, e, "join");
       }
     if (rc == PFM_OK && overlay_uu)
-      rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream);
+      rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream, c->d_scal);
     if (ev1)
       hipEventRecord(ev1, c->stream);
     if (rc)

@@ -58,13 +58,22 @@ namespace pfm
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
   int launch_halo_unpack(const DevView &v, const int32_t *d_nodes, int64_t n, const double *d_buf,
                          hipStream_t s);
+  // d_scal: the context's device buffer (PFM_SCAL_BYTES) for per-launch scalar tables.  Kernels read them through
+  // a pointer instead of by-value kernel arguments: a 900-byte argument struct pins so many SGPRs that the
+  // compiler spills them into VGPR lanes (12 % of the instructions of the phase-field kernel were such moves).
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
-                           hipStream_t s_residual);
+                           hipStream_t s_residual, void *d_scal);
   bool cart_matrix_supported(int dim);
-  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s);
-  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
-  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s);
+  constexpr size_t PFM_SCAL_BYTES = 4096;
+  // the Jacobian launchers expect the MatScal of this assembly at d_scal (upload_mat_scal, stream ordered)
+  int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s);
+  int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
+                       const void *d_scal);
+  int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                      const void *d_scal);
+  int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                          void *d_scal);
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
                               hipStream_t s);
@@ -94,6 +103,7 @@ struct pfm_ctx
   double *d_stage_res[2] = {nullptr, nullptr};
   double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<pfm::HaloPeer> peers;
+  void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;
   double *d_partial = nullptr;
