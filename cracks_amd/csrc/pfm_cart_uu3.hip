@@ -87,32 +87,31 @@ namespace pfm
       return r;
     }
 
-    // one slot (given by its in-plane offset and OZ in {-1, 0}) of row component C for both half-waves
-    template <int C, int OX, int OY, int OZ>
+    // one slot (given by its in-plane offset and OZ in {-1, 0}) of row component C for both half-waves.
+    // stage_half = the lane's staged row, shifted by 18 slots for the upper half: a slot with OZ = -1 completed by the
+    // lower half is the slot o_lo, its mirror completed by the upper half is o_lo + 18.  Slots with OZ = 0 are summed
+    // over the halves; both halves then hold the same value and store it to the same address (no exec masking).
+    // flag_half = flags of the node plane the half looks at for OZ = -1 (below / above), flag_own = own plane.
+    template <int C, int OX, int OY, int OZ, bool MASKED>
     __device__ __forceinline__ void uu3_slot(const double *__restrict__ lane_base, const MatScal &S, double *__restrict__ stage_row,
-                                             bool upper, bool masked, unsigned row_flag, const unsigned char *__restrict__ s_flag, int hc)
+                                             double *__restrict__ stage_half, unsigned row_flag,
+                                             const unsigned char *__restrict__ flag_own, const unsigned char *__restrict__ flag_half)
     {
       double v0 = uu3_lower<C, 0, OX, OY, OZ>(lane_base, S);
       double v1 = uu3_lower<C, 1, OX, OY, OZ>(lane_base, S);
       double v2 = uu3_lower<C, 2, OX, OY, OZ>(lane_base, S);
       constexpr int o_lo = (OX + 1) + 3 * (OY + 1) + 9 * (OZ + 1);
-      constexpr int o_up = (OX + 1) + 3 * (OY + 1) + 9 * (-OZ + 1);
       if constexpr (OZ == 0)
         {
-          // both layers contribute: add the two halves
           v0 += __shfl_xor(v0, 32);
           v1 += __shfl_xor(v1, 32);
           v2 += __shfl_xor(v2, 32);
-          if (upper)
-            return; // the lower half stores
         }
-      const int o = upper ? o_up : o_lo; // the upper half has completed the mirror slot
-      if (masked)
+      if constexpr (MASKED)
         {
-          const int oz = upper ? -OZ : OZ;
-          const unsigned cf = s_flag[hc + OX + H3X * OY + H3X * H3Y * oz];
+          const unsigned cf = (OZ == 0 ? flag_own : flag_half)[OX + H3X * OY];
           const bool rcon = (row_flag >> C) & 1u;
-          const bool centre = (OX == 0 && OY == 0 && OZ == 0);
+          constexpr bool centre = (OX == 0 && OY == 0 && OZ == 0);
           if (rcon || (cf & 1u))
             v0 = (rcon && centre && C == 0) ? v0 : 0.0;
           if (rcon || (cf & 2u))
@@ -120,17 +119,18 @@ namespace pfm
           if (rcon || (cf & 4u))
             v2 = (rcon && centre && C == 2) ? v2 : 0.0;
         }
-      stage_row[o * 3 + 0] = v0;
-      stage_row[o * 3 + 1] = v1;
-      stage_row[o * 3 + 2] = v2;
+      double *dst = (OZ == 0 ? stage_row : stage_half) + o_lo * 3;
+      dst[0] = v0;
+      dst[1] = v1;
+      dst[2] = v2;
     }
 
     // z-symmetric slot sets, 4 lower-layer cell visits per (row, column component) each
-    template <int C, int W>
-    __device__ __forceinline__ void uu3_wave(const double *lane_base, const MatScal &S, double *stage_row, bool upper, bool masked,
-                                             unsigned row_flag, const unsigned char *s_flag, int hc)
+    template <int C, int W, bool MASKED>
+    __device__ __forceinline__ void uu3_wave(const double *lane_base, const MatScal &S, double *stage_row, double *stage_half,
+                                             unsigned row_flag, const unsigned char *flag_own, const unsigned char *flag_half)
     {
-#define PFM_S(OX, OY, OZ) uu3_slot<C, OX, OY, OZ>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc)
+#define PFM_S(OX, OY, OZ) uu3_slot<C, OX, OY, OZ, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half)
       if constexpr (W == 0)
         {
           PFM_S(0, 0, 0);
@@ -176,20 +176,21 @@ namespace pfm
 #undef PFM_S
     }
 
-    template <int C>
-    __device__ __forceinline__ void uu3_dispatch(int wave, const double *lane_base, const MatScal &S, double *stage_row, bool upper,
-                                                 bool masked, unsigned row_flag, const unsigned char *s_flag, int hc)
+    template <int C, bool MASKED>
+    __device__ __forceinline__ void uu3_dispatch(int wave, const double *lane_base, const MatScal &S, double *stage_row,
+                                                 double *stage_half, unsigned row_flag, const unsigned char *flag_own,
+                                                 const unsigned char *flag_half)
     {
       switch (wave)
         {
-          case 0: uu3_wave<C, 0>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 1: uu3_wave<C, 1>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 2: uu3_wave<C, 2>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 3: uu3_wave<C, 3>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 4: uu3_wave<C, 4>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 5: uu3_wave<C, 5>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          case 6: uu3_wave<C, 6>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
-          default: uu3_wave<C, 7>(lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc); break;
+          case 0: uu3_wave<C, 0, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 1: uu3_wave<C, 1, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 2: uu3_wave<C, 2, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 3: uu3_wave<C, 3, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 4: uu3_wave<C, 4, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 5: uu3_wave<C, 5, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          case 6: uu3_wave<C, 6, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
+          default: uu3_wave<C, 7, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
         }
     }
 
@@ -416,17 +417,28 @@ namespace pfm
       // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
       const double *lane_base = s_tab + (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1);
       double *stage_row = s_stage + nl_lane * STG;
+      double *stage_half = stage_row + (upper ? 18 * 3 : 0);
+      const unsigned char *flag_own = s_flag + hc, *flag_half = s_flag + hc + (upper ? H3X * H3Y : -H3X * H3Y);
 
 #pragma unroll 1
       for (int c = 0; c < 3; ++c)
         {
           // all 64 lanes take part (cross-half adds); stores of tiles' non-owned nodes are dropped at copy-out
-          if (c == 0)
-            uu3_dispatch<0>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+          if (masked)
+            {
+              if (c == 0)
+                uu3_dispatch<0, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
+              else if (c == 1)
+                uu3_dispatch<1, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
+              else
+                uu3_dispatch<2, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
+            }
+          else if (c == 0)
+            uu3_dispatch<0, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
           else if (c == 1)
-            uu3_dispatch<1>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+            uu3_dispatch<1, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
           else
-            uu3_dispatch<2>(wave, lane_base, S, stage_row, upper, masked, row_flag, s_flag, hc);
+            uu3_dispatch<2, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
           lds_barrier();
           stamp(3);
           if (regular_tile)
