@@ -154,3 +154,15 @@ def test_cart_degenerate_boxes(dim, n):
     assert linf_scaled(res_pde, r.residual_pde) < TOL
     assert linf_scaled(res_tot, r.residual_total) < TOL
     _full(c, path=ctx.kernel_path)
+
+
+def test_cart_assembly_is_bitwise_reproducible():
+    """Row-owner kernels: no atomics on global memory, fixed summation order => identical bits on every run."""
+    c = box_case(3, (16, 9, 30), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0), True)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    v0, r0, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    for _ in range(3):
+        v1, r1, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+        assert all(np.array_equal(a, b) for a, b in zip(v0, v1))
+        assert np.array_equal(r0, r1)
