@@ -27,6 +27,8 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace pfm
@@ -596,6 +598,29 @@ namespace pfm
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values,
                          hipStream_t s, void *d_scal);
 
+  int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu)
+  {
+    static int n_cu = 0;
+    if (!n_cu)
+      {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+    // time model: workgroups are dispatched as slots free up, so the launch takes about (wgs / slots + 1/2) workgroup
+    // durations, and a workgroup's duration is proportional to its zc + 1 cell layers
+    const double slots = (double)per_cu * n_cu;
+    const int lo = std::max(1, std::min(zc_min, planes)), hi = std::min(zc_max, planes);
+    double tmin = 1e300;
+    for (int zc = lo; zc <= hi; ++zc)
+      tmin = std::min(tmin, ((double)tiles * ((planes + zc - 1) / zc) / slots + 0.5) * (zc + 1));
+    int best = lo;
+    for (int zc = lo; zc <= hi; ++zc) // the longest chunk within 1 % of the optimum: fewest redundant layers
+      if (((double)tiles * ((planes + zc - 1) / zc) / slots + 0.5) * (zc + 1) <= 1.01 * tmin)
+        best = zc;
+    return best;
+  }
+
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
                            hipStream_t s_residual, void *d_scal)
@@ -619,12 +644,9 @@ namespace pfm
     else
       {
         const int ntx = (int)((OWX + RNX - 1) / RNX), nty = (int)((OWY + RNY - 1) / RNY);
-        // chunks of z-planes: enough workgroups to fill 256 CUs several times over, at most ~8 % redundant layers
-        int nch = (int)((OWZ + 11) / 12);
-        while (nch > 1 && (long long)ntx * nty * nch > 8192)
-          --nch;
-        const int zc = (int)((OWZ + nch - 1) / nch);
-        nch = (int)((OWZ + zc - 1) / zc);
+        // chunks of z-planes: fill the dispatch rounds of the chip (2 workgroups per CU) at few redundant layers
+        const int zc = choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
+        const int nch = (int)((OWZ + zc - 1) / zc);
         hipLaunchKernelGGL(k_cart_residual3, dim3((unsigned)(ntx * nty * nch)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
                            res_tot, residual_only, zc);
       }

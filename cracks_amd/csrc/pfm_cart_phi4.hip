@@ -867,9 +867,8 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
     // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
-    int nch = (OWZ + 26) / 27;
-    const int zc = (OWZ + nch - 1) / nch;
-    nch = (OWZ + zc - 1) / zc;
+    const int zc = choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
+    const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
       hipLaunchKernelGGL(k_cart_phi4<4>, dim3(nb), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], zc, nullptr);

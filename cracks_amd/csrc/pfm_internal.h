@@ -65,6 +65,9 @@ namespace pfm
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
                            hipStream_t s_residual, void *d_scal);
   bool cart_matrix_supported(int dim);
+  // z-chunk length of a marching kernel: `tiles` columns, `planes` node planes, one redundant cell layer per chunk,
+  // `per_cu` resident workgroups per CU.  Maximises (fill of the last dispatch round) x (useful layers per chunk).
+  int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu);
   constexpr size_t PFM_SCAL_BYTES = 4096;
   // the Jacobian launchers expect the MatScal of this assembly at d_scal (upload_mat_scal, stream ordered)
   int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s);
