@@ -358,7 +358,9 @@ namespace pfm
       const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + RNX - 1) / RNX, nty = (OWY + RNY - 1) / RNY;
-      const int bid = blockIdx.x;
+      const int bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); // XCD-aware launch, pfm_internal.h
+      if (bid >= ntx * nty * ((cv.o1[2] - cv.o0[2] + zc) / zc))
+        return;
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * RNX, j0 = cv.o0[1] + tiy * RNY;
       const int kA = cv.o0[2] + chunk * zc;
@@ -647,7 +649,7 @@ namespace pfm
         // chunks of z-planes: fill the dispatch rounds of the chip (2 workgroups per CU) at few redundant layers
         const int zc = choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
         const int nch = (int)((OWZ + zc - 1) / zc);
-        hipLaunchKernelGGL(k_cart_residual3, dim3((unsigned)(ntx * nty * nch)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
+        hipLaunchKernelGGL(k_cart_residual3, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
                            res_tot, residual_only, zc);
       }
     if (hipGetLastError() != hipSuccess)

@@ -12,6 +12,9 @@ namespace pfm
   namespace
   {
     constexpr int STG = 81; // staged row width (27 slots x 3), odd => conflict-free
+    // tile index of this workgroup under the XCD-aware launch (pfm_internal.h: xcd_grid)
+    __device__ __forceinline__ int xcd_tile_index() { return (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); }
+
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e.
     // every wave would sit out the full HBM write latency of the rows it has just streamed out; the kernels
     // here never exchange data through global memory inside a launch, so outstanding stores may stay in flight.

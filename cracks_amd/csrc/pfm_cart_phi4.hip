@@ -389,7 +389,9 @@ namespace pfm
       const int cx = lane % PT, cy = lane / PT;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
-      const int bid = blockIdx.x;
+      const int bid = xcd_tile_index();
+      if (bid >= ntx * nty * ((cv.o1[2] - cv.o0[2] + zc) / zc))
+        return; // padding of the XCD-aware grid
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * PN, j0 = cv.o0[1] + tiy * PN;
       const int kA = cv.o0[2] + chunk * zc;
@@ -871,19 +873,19 @@ namespace pfm
     const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(nb), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], zc, nullptr);
+      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], zc, nullptr);
     else if (getenv("PFM_PHI_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
-        const size_t nd = (size_t)nb * 16;
+        const size_t nd = (size_t)xcd_grid(nb) * 16;
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
         if (atoi(getenv("PFM_PHI_CLK")) == 2)
-          hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+          hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], zc, d_dbg);
         else
-          hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+          hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], zc, d_dbg);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -900,7 +902,7 @@ namespace pfm
         fprintf(stderr, "\n");
       }
     else
-      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(nb), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], zc,
+      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], zc,
                          nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }

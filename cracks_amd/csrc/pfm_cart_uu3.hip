@@ -225,7 +225,9 @@ namespace pfm
       const int t = threadIdx.x;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
-      const int bid = blockIdx.x;
+      const int bid = xcd_tile_index();
+      if (bid >= ntx * nty * (cv.o1[2] - cv.o0[2] + 1))
+        return; // padding of the XCD-aware grid
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
 
@@ -485,15 +487,15 @@ namespace pfm
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
     else if (getenv("PFM_UU_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
-        const size_t nd = (size_t)nb * 8;
+        const size_t nd = (size_t)xcd_grid(nb) * 8;
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_cart_uu3<3, true>), dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, d_dbg);
+        hipLaunchKernelGGL((k_cart_uu3<3, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, d_dbg);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[8] = {};
@@ -506,7 +508,7 @@ namespace pfm
         fprintf(stderr, "\n");
       }
     else
-      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(nb), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   // entry point used by the debug overlay (pfm_ctx_force_path(ctx, 2)) and by launch_cart_matrix

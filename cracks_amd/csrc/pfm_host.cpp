@@ -67,9 +67,16 @@ namespace
   {
     return fail(c, PFM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   }
-  // Detect a uniform Cartesian box and build the fast-path tables.
-  // Returns false (general path) whenever any check fails; never an error.
-  bool build_cart(pfm_ctx *c, const pfm_mesh_desc *m)
+  // Lattice of a uniform Cartesian box: node n <-> lattice index box_of_local[n] (x fastest), cells in deal.II
+  // vertex order, every lattice cell present exactly once.  false whenever any check fails.
+  struct Lattice
+  {
+    int NX = 0, NY = 0, NZ = 0, nc[3] = {0, 0, 0};
+    double h[3] = {1, 1, 1};
+    std::vector<int32_t> local_of_box, box_of_local;
+  };
+
+  bool detect_lattice(const pfm_mesh_desc *m, Lattice &L)
   {
     const int dim = m->dim, nv = 1 << dim;
     if (m->n_hanging > 0 || m->cell_lambda || m->cell_mu)
@@ -81,7 +88,7 @@ namespace
     const int64_t nn = (int64_t)NX * NY * NZ;
     if (nn != m->n_nodes || (int64_t)nc[0] * nc[1] * nc[2] != m->n_cells)
       return false;
-    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    const int32_t N = m->n_nodes;
     double x0[3] = {0, 0, 0}, x1[3] = {0, 0, 0}, h[3] = {1, 1, 1};
     for (int d = 0; d < dim; ++d)
       {
@@ -132,6 +139,28 @@ namespace
           return false;
         seen[cid] = 1;
       }
+    L.NX = NX;
+    L.NY = NY;
+    L.NZ = NZ;
+    for (int d = 0; d < 3; ++d)
+      {
+        L.nc[d] = nc[d];
+        L.h[d] = h[d];
+      }
+    L.local_of_box.swap(local_of_box);
+    L.box_of_local.swap(box_of_local);
+    return true;
+  }
+
+  // Build the fast-path tables of a lattice mesh.  Returns false (general path) whenever a
+  // check fails; never an error.
+  bool build_cart(pfm_ctx *c, const pfm_mesh_desc *m, const Lattice &L)
+  {
+    const int dim = m->dim;
+    const int NX = L.NX, NY = L.NY, NZ = L.NZ;
+    const int32_t NO = m->n_owned_nodes;
+    const double *h = L.h;
+    const std::vector<int32_t> &local_of_box = L.local_of_box, &box_of_local = L.box_of_local;
     // owned nodes must form a sub-box
     int o0[3] = {1 << 30, 1 << 30, 1 << 30}, o1[3] = {-1, -1, -1};
     for (int32_t n = 0; n < NO; ++n)
@@ -164,8 +193,8 @@ namespace
             if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
               continue;
             const int32_t q = local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
-            const int32_t *p = std::lower_bound(rb, re, q);
-            if (p == re || *p != q)
+            const int32_t *p = std::find(rb, re, q);
+            if (p == re)
               continue; // neighbour not coupled through a local cell (cannot happen for owned rows)
             inv[(size_t)n * no + (p - rb)] = (uint8_t)o;
             ++found;
@@ -268,6 +297,8 @@ extern "C"
       if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
         return fail(c, PFM_ERR_BAD_ARG, "cell_nodes out of range");
 
+    Lattice lattice;
+    bool lattice_ok = false;
     try
       {
         // ---- hanging table: node -> k
@@ -317,6 +348,10 @@ extern "C"
                 inc[fill[n]++] = cell;
             });
         }
+        // On a lattice the neighbours of a row are ordered by lattice offset (x fastest), not by local node id: a full
+        // row then has its 3^dim slots in the order the row-owner kernels produce them on EVERY rank (ghost nodes,
+        // which are numbered after the owned ones, would otherwise break the order next to partition faces).
+        lattice_ok = detect_lattice(m, lattice);
         c->h_nadj_ptr.assign((size_t)NO + 1, 0);
         std::vector<int32_t> &nadj = c->h_nadj;
         nadj.clear();
@@ -329,6 +364,11 @@ extern "C"
               for_each_resolved(inc[k], [&](int32_t q) { tmp.push_back(q); });
             std::sort(tmp.begin(), tmp.end());
             tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            if (lattice_ok)
+              {
+                const std::vector<int32_t> &bol = lattice.box_of_local;
+                std::sort(tmp.begin(), tmp.end(), [&](int32_t p, int32_t q) { return bol[p] < bol[q]; });
+              }
             if (tmp.size() > 254)
               return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
             nadj.insert(nadj.end(), tmp.begin(), tmp.end());
@@ -349,7 +389,7 @@ extern "C"
               for (int b = 0; b < nv; ++b)
                 {
                   const int32_t B = m->cell_nodes[cell * nv + b];
-                  const int32_t *p = std::lower_bound(rb, re, B);
+                  const int32_t *p = std::find(rb, re, B);
                   cslot[(cell * nv + a) * nv + b] = (uint8_t)(p - rb);
                 }
             }
@@ -418,7 +458,7 @@ extern "C"
       }
     try
       {
-        c->cart_ok = build_cart(c, m);
+        c->cart_ok = lattice_ok && build_cart(c, m, lattice);
         c->d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
       }
     catch (const HipFail &f)

@@ -68,6 +68,12 @@ namespace pfm
   // z-chunk length of a marching kernel: `tiles` columns, `planes` node planes, one redundant cell layer per chunk,
   // `per_cu` resident workgroups per CU.  Maximises (fill of the last dispatch round) x (useful layers per chunk).
   int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu);
+  // XCD-aware launch: workgroup i runs on XCD i % 8.  The kernels are launched with a grid rounded up to a multiple
+  // of 8 and map blockIdx to (blockIdx % 8) * (grid / 8) + blockIdx / 8, so that every XCD works on one contiguous
+  // range of tiles (neighbouring tiles share their halo in that XCD's L2) and the slow boundary tiles are spread over
+  // all XCDs — with the plain mapping a tile count per row that is a multiple of 8 (e.g. the 109-node edge of an
+  // 8-rank sub-box) put every boundary tile on the same two XCDs (+30 % kernel time).
+  constexpr unsigned xcd_grid(unsigned n_tiles) { return ((n_tiles + 7u) / 8u) * 8u; }
   constexpr size_t PFM_SCAL_BYTES = 4096;
   // the Jacobian launchers expect the MatScal of this assembly at d_scal (upload_mat_scal, stream ordered)
   int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s);

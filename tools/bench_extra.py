@@ -12,6 +12,7 @@
 
   python tools/bench_extra.py config5 [--levels 7] [--out profiles/rNN/config5_miehe_amr.json]
   python tools/bench_extra.py pcie    [--n 216]    [--out profiles/rNN/pcie_216cube.json]
+  python tools/bench_extra.py rank    [--n 216 --world 8]   one rank's share of the strong-scaling run, no exchange
 """
 from __future__ import annotations
 
@@ -131,12 +132,59 @@ def pcie(args):
         json.dump(out, open(os.path.join(ROOT, args.out), "w"), indent=1)
 
 
+def rank_share(args):
+    """Assembly time of ONE rank's sub-box of an N-rank run (no exchange): what a GPU of the strong-scaling run
+    computes per step.  Lets the per-rank efficiency be measured on a single-GPU box."""
+    import torch
+
+    import bench
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler
+
+    n, world = args.n, args.world
+    p = P.factor_ranks(world, 3)
+    rows = []
+    for rank in ([0, world - 1] if world > 1 else [0]):
+        lp = P.build_local_problem(3, (n,) * 3, p, rank)
+        h = (20.0 / n) * np.sqrt(3.0)
+        u, phi, po, poo, flags = bench.synthetic_state(lp.mesh, lp.global_ids, h, 3)
+        asm = Assembler(lp.mesh, blocked=True, n_owned_nodes=lp.n_owned)
+        asm.set_params(bench.sneddon_params(h, 3))
+        asm.set_constraints(flags)
+        no = lp.n_owned
+
+        def pack(uu, pp):
+            v = np.empty(no * 4)
+            v[:no * 3] = uu[:no].reshape(-1)
+            v[no * 3:] = pp[:no]
+            return v
+        asm.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
+        for _ in range(3):
+            asm.assemble_system(False)
+        asm.synchronize()
+        ts = []
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            asm.assemble_system(False)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t)
+        rows.append({"rank": rank, "of": world, "partition": "x".join(map(str, p)), "local_cells": int(lp.mesh.n_cells),
+                     "owned_nodes": int(no), "assemble_ms": round(1e3 * float(np.median(ts)), 4)})
+        print(rows[-1], flush=True)
+        del asm
+    if args.out:
+        json.dump({"config": f"one rank of a {world}-rank strong-scaling run of Sneddon 3D {n}^3, no exchange", "rows": rows},
+                  open(os.path.join(ROOT, args.out), "w"), indent=1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["config5", "pcie"])
+    ap.add_argument("what", choices=["config5", "pcie", "rank"])
+    ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--levels", type=int, default=7)
     ap.add_argument("--meshes", type=int, default=5)
     ap.add_argument("--n", type=int, default=216)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    config5(a) if a.what == "config5" else pcie(a)
+    {"config5": config5, "pcie": pcie, "rank": rank_share}[a.what](a)
