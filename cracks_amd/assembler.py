@@ -149,6 +149,12 @@ class Context:
     def halo_unpack(self, peer: int, buf_ptr: int):
         self._check(self.lib.pfm_halo_unpack(self._h, peer, C.c_void_p(buf_ptr)), "pfm_halo_unpack")
 
+    def halo_pack_all(self, buf_ptr: int):
+        self._check(self.lib.pfm_halo_pack_all(self._h, C.c_void_p(buf_ptr)), "pfm_halo_pack_all")
+
+    def halo_unpack_all(self, buf_ptr: int):
+        self._check(self.lib.pfm_halo_unpack_all(self._h, C.c_void_p(buf_ptr)), "pfm_halo_unpack_all")
+
     def assemble_device(self, residual_only: bool, value_ptrs: Sequence[int], res_pde_ptr: int, res_tot_ptr: int):
         arr = (C.c_void_p * 4)(*[C.c_void_p(p) for p in list(value_ptrs) + [0] * (4 - len(value_ptrs))])
         self._check(self.lib.pfm_assemble_device(self._h, 1 if residual_only else 0, arr,

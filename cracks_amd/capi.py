@@ -22,7 +22,8 @@ LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 EXPORTS = [
     "pfm_ctx_create", "pfm_ctx_destroy", "pfm_last_error", "pfm_ctx_set_stream", "pfm_set_params",
     "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_state_set",
-    "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_assemble_device",
+    "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
+    "pfm_assemble_device",
     "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms",
     # include/pfm_newton.h
@@ -97,6 +98,8 @@ def load():
     lib.pfm_halo_register.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pfm_halo_pack.argtypes = [vp, i32, vp]
     lib.pfm_halo_unpack.argtypes = [vp, i32, vp]
+    lib.pfm_halo_pack_all.argtypes = [vp, vp]
+    lib.pfm_halo_unpack_all.argtypes = [vp, vp]
     lib.pfm_assemble_device.argtypes = [vp, i32, vp, vp, vp]
     lib.pfm_sync_status.argtypes = [vp]
     lib.pfm_assemble.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]

@@ -484,6 +484,9 @@ extern "C"
         if (p.d_recv)
           hipFree(p.d_recv);
       }
+    for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr})
+      if (q)
+        hipFree(q);
     if (c->side_stream)
       {
         hipStreamDestroy(c->side_stream);
@@ -660,7 +663,58 @@ extern "C"
         if (e != hipSuccess)
           return hipfail(c, e, "halo_register");
       }
+    // concatenated lists for the one-launch pack / unpack
+    for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr})
+      if (q)
+        hipFree(q);
+    c->d_send_all = c->d_recv_all = nullptr;
+    c->d_send_ptr = c->d_recv_ptr = nullptr;
+    c->n_send_all = n_peers ? send_ptr[n_peers] - send_ptr[0] : 0;
+    c->n_recv_all = n_peers ? recv_ptr[n_peers] - recv_ptr[0] : 0;
+    if (n_peers > 0)
+      {
+        std::vector<long long> sp((size_t)n_peers + 1), rp((size_t)n_peers + 1);
+        for (int k = 0; k <= n_peers; ++k)
+          {
+            sp[k] = send_ptr[k] - send_ptr[0];
+            rp[k] = recv_ptr[k] - recv_ptr[0];
+          }
+        hipError_t e = hipMalloc((void **)&c->d_send_all, std::max<size_t>(4, sizeof(int32_t) * c->n_send_all));
+        if (e == hipSuccess)
+          e = hipMalloc((void **)&c->d_recv_all, std::max<size_t>(4, sizeof(int32_t) * c->n_recv_all));
+        if (e == hipSuccess)
+          e = hipMalloc((void **)&c->d_send_ptr, sizeof(long long) * sp.size());
+        if (e == hipSuccess)
+          e = hipMalloc((void **)&c->d_recv_ptr, sizeof(long long) * rp.size());
+        if (e == hipSuccess && c->n_send_all)
+          e = hipMemcpy(c->d_send_all, send_nodes + send_ptr[0], sizeof(int32_t) * c->n_send_all, hipMemcpyHostToDevice);
+        if (e == hipSuccess && c->n_recv_all)
+          e = hipMemcpy(c->d_recv_all, recv_nodes + recv_ptr[0], sizeof(int32_t) * c->n_recv_all, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+          e = hipMemcpy(c->d_send_ptr, sp.data(), sizeof(long long) * sp.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+          e = hipMemcpy(c->d_recv_ptr, rp.data(), sizeof(long long) * rp.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+          return hipfail(c, e, "halo_register (concatenated lists)");
+      }
     return PFM_OK;
+  }
+
+  int pfm_halo_pack_all(pfm_ctx *c, double *d_buf_all)
+  {
+    if (!c || (!d_buf_all && c->n_send_all))
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    return launch_halo_all(c->v, c->d_send_all, c->d_send_ptr, (int)c->peers.size(), c->n_send_all, d_buf_all, 0, c->stream);
+  }
+
+  int pfm_halo_unpack_all(pfm_ctx *c, const double *d_buf_all)
+  {
+    if (!c || (!d_buf_all && c->n_recv_all))
+      return PFM_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    return launch_halo_all(c->v, c->d_recv_all, c->d_recv_ptr, (int)c->peers.size(), c->n_recv_all,
+                           const_cast<double *>(d_buf_all), 1, c->stream);
   }
 
   int pfm_halo_pack(pfm_ctx *c, int peer, double *d_buf)

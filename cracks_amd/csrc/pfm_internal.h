@@ -56,6 +56,9 @@ namespace pfm
   int launch_state_set(const DevView &v, const double *d_sol, const double *d_old,
                        const double *d_oldold, hipStream_t s);
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
+  // all peers at once: d_nodes = concatenated lists, d_ptr[n_peers + 1] = their offsets (device)
+  int launch_halo_all(const DevView &v, const int32_t *d_nodes, const long long *d_ptr, int n_peers, int64_t n_total,
+                      double *d_buf, int unpack, hipStream_t s);
   int launch_halo_unpack(const DevView &v, const int32_t *d_nodes, int64_t n, const double *d_buf,
                          hipStream_t s);
   // d_scal: the context's device buffer (PFM_SCAL_BYTES) for per-launch scalar tables.  Kernels read them through
@@ -112,6 +115,9 @@ struct pfm_ctx
   double *d_stage_res[2] = {nullptr, nullptr};
   double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<pfm::HaloPeer> peers;
+  int32_t *d_send_all = nullptr, *d_recv_all = nullptr; // concatenated halo lists and their per-peer offsets
+  long long *d_send_ptr = nullptr, *d_recv_ptr = nullptr;
+  int64_t n_send_all = 0, n_recv_all = 0;
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;

@@ -760,6 +760,46 @@ namespace pfm
       v.phi_oldold[node] = buf[(dim + 2) * n + i];
     }
 
+    // all peers in one launch: entry j of the concatenated list belongs to the peer k with ptr[k] <= j < ptr[k+1]
+    template <int dim, bool UNPACK>
+    __global__ void k_halo_all(DevView v, const int32_t *__restrict__ nodes, const long long *__restrict__ ptr, int n_peers,
+                               long long n_total, double *__restrict__ buf)
+    {
+      const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (j >= n_total)
+        return;
+      int lo = 0, hi = n_peers; // largest k with ptr[k] <= j
+      while (hi - lo > 1)
+        {
+          const int mid = (lo + hi) >> 1;
+          if (ptr[mid] <= j)
+            lo = mid;
+          else
+            hi = mid;
+        }
+      const long long base = ptr[lo], n = ptr[lo + 1] - base, i = j - base;
+      double *b = buf + (dim + 3) * base; // this peer's message, field-major
+      const int node = nodes[j];
+      if constexpr (UNPACK)
+        {
+#pragma unroll
+          for (int d = 0; d < dim; ++d)
+            v.u[d][node] = b[d * n + i];
+          v.phi[node] = b[(dim + 0) * n + i];
+          v.phi_old[node] = b[(dim + 1) * n + i];
+          v.phi_oldold[node] = b[(dim + 2) * n + i];
+        }
+      else
+        {
+#pragma unroll
+          for (int d = 0; d < dim; ++d)
+            b[d * n + i] = v.u[d][node];
+          b[(dim + 0) * n + i] = v.phi[node];
+          b[(dim + 1) * n + i] = v.phi_old[node];
+          b[(dim + 2) * n + i] = v.phi_oldold[node];
+        }
+    }
+
     bool g_tables_ready[16] = {};
 
     int ensure_tables()
@@ -816,6 +856,30 @@ namespace pfm
       hipLaunchKernelGGL(k_halo_unpack<2>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
     else
       hipLaunchKernelGGL(k_halo_unpack<3>, dim3(nb), dim3(bs), 0, s, v, nodes, (long long)n, buf);
+    return check_launch();
+  }
+
+  int launch_halo_all(const DevView &v, const int32_t *nodes, const long long *ptr, int n_peers, int64_t n_total, double *buf,
+                      int unpack, hipStream_t s)
+  {
+    if (n_total == 0)
+      return PFM_OK;
+    const int bs = 256;
+    const unsigned nb = (unsigned)((n_total + bs - 1) / bs);
+    if (v.dim == 2)
+      {
+        if (unpack)
+          hipLaunchKernelGGL((k_halo_all<2, true>), dim3(nb), dim3(bs), 0, s, v, nodes, ptr, n_peers, (long long)n_total, buf);
+        else
+          hipLaunchKernelGGL((k_halo_all<2, false>), dim3(nb), dim3(bs), 0, s, v, nodes, ptr, n_peers, (long long)n_total, buf);
+      }
+    else
+      {
+        if (unpack)
+          hipLaunchKernelGGL((k_halo_all<3, true>), dim3(nb), dim3(bs), 0, s, v, nodes, ptr, n_peers, (long long)n_total, buf);
+        else
+          hipLaunchKernelGGL((k_halo_all<3, false>), dim3(nb), dim3(bs), 0, s, v, nodes, ptr, n_peers, (long long)n_total, buf);
+      }
     return check_launch();
   }
 

@@ -5,7 +5,7 @@ Import => MPI point-to-point).  Pattern = neighbour halo exchange, not a reducti
 peer one packed message of ``(dim+3)`` doubles per interface node (u, phi, phi_old,
 phi_oldold), all peers posted together with ``batch_isend_irecv`` so that every xGMI link
 of the GPU carries its own pair concurrently.  Packing/unpacking are HIP kernels behind
-the C ABI (``pfm_halo_pack`` / ``pfm_halo_unpack``); ``torch.distributed`` (backend
+the C ABI (``pfm_halo_pack_all`` / ``pfm_halo_unpack_all``: one launch each for all peers); ``torch.distributed`` (backend
 ``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests) only moves the buffers.
 """
 from __future__ import annotations
@@ -32,8 +32,13 @@ class HaloExchange:
         self.rec = dim + 3  # PFM_HALO_DOUBLES_PER_NODE
         ns = np.diff(self.send_ptr)
         nr = np.diff(self.recv_ptr)
-        self.send_bufs = [torch.empty(int(k) * self.rec, dtype=torch.float64, device=device) for k in ns]
-        self.recv_bufs = [torch.empty(int(k) * self.rec, dtype=torch.float64, device=device) for k in nr]
+        # one contiguous buffer per direction; peer k's message is the slice [rec * ptr[k], rec * ptr[k + 1])
+        self.send_all = torch.empty(int(ns.sum()) * self.rec, dtype=torch.float64, device=device)
+        self.recv_all = torch.empty(int(nr.sum()) * self.rec, dtype=torch.float64, device=device)
+        so = (self.send_ptr - self.send_ptr[0]) * self.rec
+        ro = (self.recv_ptr - self.recv_ptr[0]) * self.rec
+        self.send_bufs = [self.send_all[int(so[k]):int(so[k + 1])] for k in range(len(self.peers))]
+        self.recv_bufs = [self.recv_all[int(ro[k]):int(ro[k + 1])] for k in range(len(self.peers))]
         self._registered = None
 
     @property
@@ -61,13 +66,11 @@ class HaloExchange:
         """pack (HIP) -> RCCL send/recv -> unpack (HIP), all on torch's current stream."""
         if self._registered is not ctx:
             self.register(ctx)
-        for k in range(len(self.peers)):
-            if self.send_bufs[k].numel():
-                ctx.halo_pack(k, self.send_bufs[k].data_ptr())
+        if self.send_all.numel():
+            ctx.halo_pack_all(self.send_all.data_ptr())  # one launch for all peers
         self._post()
-        for k in range(len(self.peers)):
-            if self.recv_bufs[k].numel():
-                ctx.halo_unpack(k, self.recv_bufs[k].data_ptr())
+        if self.recv_all.numel():
+            ctx.halo_unpack_all(self.recv_all.data_ptr())
 
     def exchange_with(self, pack: Callable[[int, np.ndarray], "object"], unpack: Callable[[int, np.ndarray, "object"], None]):
         """Same exchange with caller-supplied pack/unpack (CPU/gloo tests of the lists)."""

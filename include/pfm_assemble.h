@@ -128,6 +128,11 @@ int pfm_halo_register(pfm_ctx *ctx, int n_peers, const int64_t *send_ptr, const 
                       const int64_t *recv_ptr, const int32_t *recv_nodes);
 int pfm_halo_pack(pfm_ctx *ctx, int peer, double *d_buf);         /* device buffer */
 int pfm_halo_unpack(pfm_ctx *ctx, int peer, const double *d_buf); /* device buffer */
+/* All peers with one launch: d_buf_all holds the messages back to back in peer order, the message of peer k starts at
+ * PFM_HALO_DOUBLES_PER_NODE(dim) * send_ptr[k] (pack) resp. * recv_ptr[k] (unpack) and has the same layout as the
+ * per-peer calls produce. */
+int pfm_halo_pack_all(pfm_ctx *ctx, double *d_buf_all);
+int pfm_halo_unpack_all(pfm_ctx *ctx, const double *d_buf_all);
 
 /* -- the hot path --------------------------------------------------------------------- */
 /* assemble_system(residual_only) on the current state.  Output pointers are DEVICE

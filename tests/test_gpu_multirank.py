@@ -68,19 +68,31 @@ def test_owned_rows_match_single_rank(dim, n, world, path):
         a.ctx.state_set_device(a.solution.data_ptr(), a.old_solution.data_ptr(), a.old_old_solution.data_ptr())
         a.ctx.halo_register(lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes)
         asms.append(a)
-    # "exchange": pack on the sender, unpack on the receiver (same device)
+    # "exchange": pack on the sender, unpack on the receiver (same device).  Senders pack all peers with one launch
+    # (pfm_halo_pack_all), which must equal the per-peer packs; receivers unpack everything with one launch.
     rec = dim + 3
+    recv_all = [torch.zeros(int(lp.recv_ptr[-1] - lp.recv_ptr[0]) * rec, dtype=torch.float64, device="cuda") for lp in lps]
     for r, lp in enumerate(lps):
+        send_all = torch.empty(int(lp.send_ptr[-1] - lp.send_ptr[0]) * rec, dtype=torch.float64, device="cuda")
+        if send_all.numel():
+            asms[r].ctx.halo_pack_all(send_all.data_ptr())
         for k, s in enumerate(lp.peers):
             nsend = int(lp.send_ptr[k + 1] - lp.send_ptr[k])
             if nsend == 0:
                 continue
             buf = torch.empty(nsend * rec, dtype=torch.float64, device="cuda")
             asms[r].ctx.halo_pack(k, buf.data_ptr())
+            torch.cuda.synchronize()
+            o = int(lp.send_ptr[k] - lp.send_ptr[0]) * rec
+            assert torch.equal(buf, send_all[o:o + nsend * rec])
             ko = lps[s].peers.index(r)
             assert int(lps[s].recv_ptr[ko + 1] - lps[s].recv_ptr[ko]) == nsend
-            asms[s].ctx.halo_unpack(ko, buf.data_ptr())
-            torch.cuda.synchronize()
+            oo = int(lps[s].recv_ptr[ko] - lps[s].recv_ptr[0]) * rec
+            recv_all[s][oo:oo + nsend * rec] = buf
+    for s, lp in enumerate(lps):
+        if recv_all[s].numel():
+            asms[s].ctx.halo_unpack_all(recv_all[s].data_ptr())
+        torch.cuda.synchronize()
     for r, (lp, a) in enumerate(zip(lps, asms)):
         for residual_only in (False, True):
             a.ctx.assemble_device(residual_only, [m.data_ptr() for m in a.system_pde_matrix] if not residual_only
