@@ -166,3 +166,31 @@ def test_cart_assembly_is_bitwise_reproducible():
         v1, r1, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
         assert all(np.array_equal(a, b) for a, b in zip(v0, v1))
         assert np.array_equal(r0, r1)
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("kappa_zero", [False, True])
+def test_cart_random_constraints_stress(blocked, kappa_zero):
+    """Random homogeneous constraints on displacement and phase-field dofs (interior ones included), pressure and
+    Biot terms on, kappa = 0 (placeholder fall-back reachable): every matrix entry and both residuals."""
+    c = box_case(3, (23, 9, 31), (-1.0, 0.0, 0.0), (1.5, 1.0, 4.0), blocked, seed=11)
+    rng = np.random.default_rng(5)
+    lay = c.layout
+    node, comp = lay.node_comp_of_dof()
+    pick = np.where(comp == 3, rng.random(lay.n_dofs) < 0.2, rng.random(lay.n_dofs) < 0.05)
+    dd = np.union1d(M.sneddon_dirichlet_dofs(c.mesh, lay), np.nonzero(pick)[0])
+    c.cu = M.update_constraints(c.mesh, lay, dd)
+    c.params.pressure = 3.0e-3
+    if kappa_zero:
+        c.params.constant_k = 0.0
+        # a patch of exactly vanishing old phase field: g(q) = 0 in whole cells
+        far = c.mesh.coords[:, 2] > 3.0
+        for v in (c.old, c.oldold):
+            v[lay.dof(np.nonzero(far)[0], 3)] = 0.0
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(res_pde, r.residual_pde) < TOL
+    assert linf_scaled(res_tot, r.residual_total) < TOL
+    _full(c, path=1)
