@@ -51,8 +51,7 @@ namespace pfm
       double pp[5][SLAB_PP]; // staged (phi,phi) rows, same slabs; [node][o9]
       double ex[2][NPN][2];  // per node: placeholder sum, (u,u) placeholder patch
       long long off[2][NPN]; // node-graph offset of the row, -1 = not an owned node of this tile
-      int deg[2][NPN];
-      int row[2][NPN];       // local node id of the row
+      int deg[2][NPN];       // neighbour mask of the row (bit o: lattice offset o exists)
       int irregular[2];
       int anyflag[4];
       unsigned char flag[4][NPH];
@@ -451,9 +450,7 @@ namespace pfm
               {
                 r_row = cart_local_id(cv, gi, gj, kz);
                 r_off = v.nadj_ptr[r_row];
-                r_deg = (int)(v.nadj_ptr[r_row + 1] - r_off);
-                if (!cv.row_regular[r_row])
-                  r_deg |= 1 << 16;
+                r_deg = (int)cv.nbr_mask[r_row]; // neighbour mask of the row (27 bits)
               }
           }
       };
@@ -462,12 +459,11 @@ namespace pfm
         if (role == 2)
           {
             const bool mine = t < 128 + NPN;
-            const unsigned long long irr = __ballot(mine && (r_deg >> 16));
+            const unsigned long long irr = __ballot(mine && r_off >= 0 && r_deg != 0x7ffffff);
             if (mine)
               {
                 s.off[par][t - 128] = r_off;
                 s.deg[par][t - 128] = r_deg;
-                s.row[par][t - 128] = r_row;
               }
             if (lane == 0)
               s.irregular[par] = irr != 0;
@@ -612,234 +608,161 @@ namespace pfm
               const bool masked = (s.anyflag[(ck - 1) & 3] | s.anyflag[ck & 3] | s.anyflag[(ck + 1) & 3]) != 0;
               double *pu_m1 = s.pu[cp], *pu_z0 = s.pu[2 + cp], *pu_p1 = s.pu[4];
               double *pp_m1 = s.pp[cp], *pp_z0 = s.pp[2 + cp], *pp_p1 = s.pp[4];
-              if (regular)
+              const bool tile_full = (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1];
+              const bool fast = regular && !masked && tile_full; // all rows full, owned and free of constraint flags
+              // Rows are in lattice order: the CSR slot of lattice offset o is its rank among the offsets that exist
+              // (popcount of the row's neighbour mask below bit o); interior rows have all 27.
+              if (NCOL == 3 && fast)
                 {
-                  // interior plane: slot order = lattice order, all rows full.  Thread <-> one of the 108 elements
-                  // of a row, two rows at a time; consecutive lanes store consecutive addresses.
-                  if (NCOL == 3 && !masked && (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1])
+                  // Blocked layout, interior plane without constraint flags (the common case): the 7 rows of a
+                  // y-line of the tile are ONE contiguous run of 7*81 (phi,u) + 7*27 (phi,phi) values.  Thread <->
+                  // up to 3 fixed positions of that run; per y-line 3 LDS reads and 3 fully coalesced stores.
+                  int tq = t;
+                  asm volatile("" : "+v"(tq));
+                  double *srck[3];
+                  double *dstk[3];
+                  int rstride[3], mul[3];
+                  bool act[3];
+#pragma unroll
+                  for (int q = 0; q < 3; ++q)
                     {
-                      // Blocked layout, interior plane without constraint flags (the common case): the 7 rows of a
-                      // y-line of the tile are ONE contiguous run of 7*81 (phi,u) + 7*27 (phi,phi) values.  Thread <->
-                      // up to 3 fixed positions of that run; per y-line 3 LDS reads and 3 fully coalesced stores.
-                      int tq = t;
-                      asm volatile("" : "+v"(tq));
-                      double *srck[3];
-                      double *dstk[3];
-                      int rstride[3], mul[3];
-                      bool act[3];
+                      const int f = tq + NT4 * q;
+                      act[q] = f < PN * 108;
+                      const bool is_pp = f >= PN * 81;
+                      const int g = is_pp ? f - PN * 81 : f;
+                      const int per = is_pp ? 27 : 81;
+                      const int nx = g / per, e = g - nx * per;
+                      const int o = is_pp ? e : e / 3, d = is_pp ? 0 : e - 3 * (e / 3);
+                      const int oz = o / 9, o9 = o - 9 * oz;
+                      double *slab = is_pp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1));
+                      srck[q] = slab + (is_pp ? nx * 9 + o9 : nx * 27 + o9 * 3 + d);
+                      rstride[q] = is_pp ? PN * 9 : PN * 27;
+                      dstk[q] = (is_pp ? vals_pp : vals_pu) + g;
+                      mul[q] = is_pp ? 1 : 3;
+                    }
+                  long long off0[PN];
+                  double val[PN][3];
+#pragma unroll
+                  for (int ny = 0; ny < PN; ++ny)
+                    {
+                      off0[ny] = s.off[cp][ny * PN];
 #pragma unroll
                       for (int q = 0; q < 3; ++q)
-                        {
-                          const int f = tq + NT4 * q;
-                          act[q] = f < PN * 108;
-                          const bool is_pp = f >= PN * 81;
-                          const int g = is_pp ? f - PN * 81 : f;
-                          const int per = is_pp ? 27 : 81;
-                          const int nx = g / per, e = g - nx * per;
-                          const int o = is_pp ? e : e / 3, d = is_pp ? 0 : e - 3 * (e / 3);
-                          const int oz = o / 9, o9 = o - 9 * oz;
-                          double *slab = is_pp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1));
-                          srck[q] = slab + (is_pp ? nx * 9 + o9 : nx * 27 + o9 * 3 + d);
-                          rstride[q] = is_pp ? PN * 9 : PN * 27;
-                          dstk[q] = (is_pp ? vals_pp : vals_pu) + g;
-                          mul[q] = is_pp ? 1 : 3;
-                        }
-                      long long off0[PN];
-                      double val[PN][3];
-#pragma unroll
-                      for (int ny = 0; ny < PN; ++ny)
-                        {
-                          off0[ny] = s.off[cp][ny * PN];
-#pragma unroll
-                          for (int q = 0; q < 3; ++q)
-                            val[ny][q] = act[q] ? srck[q][ny * rstride[q]] : 0.0;
-                        }
-#pragma unroll
-                      for (int ny = 0; ny < PN; ++ny)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                          if (act[q])
-                            {
-                              dstk[q][mul[q] * off0[ny]] = val[ny][q];
-                              srck[q][ny * rstride[q]] = 0.0; // these slabs are the next planes' accumulators
-                            }
+                        val[ny][q] = act[q] ? srck[q][ny * rstride[q]] : 0.0;
                     }
-                  if (t < 2 * 108)
-                    {
-                      // thread <-> element fe_e of a row (0..80 (phi,u), 81..107 (phi,phi)); recomputed per plane
-                      // rather than kept live across the whole march
-                      int tq = t;
-                      asm volatile("" : "+v"(tq));
-                      const int fe_e = tq % 108, fe_sub = tq / 108;
-                      const bool fe_pp = fe_e >= 81;
-                      const int fe_o = fe_pp ? fe_e - 81 : fe_e / 3, fe_d = fe_pp ? 3 : fe_e % 3; // lattice offset index, column component
-                      const int fe_oz = fe_o / 9, fe_o9 = fe_o % 9;
-                      const int fe_stride = fe_pp ? 9 : 27, fe_src = fe_pp ? fe_o9 : fe_o9 * 3 + fe_d;
-                      const int fe_nbo = (fe_o9 % 3 - 1) + PH * (fe_o9 / 3 - 1); // halo offset of the neighbour node
-                      const int fe_mul = (NCOL == 3) ? (fe_pp ? 1 : 3) : 16;
-                      const int fe_dst = (NCOL == 3) ? (fe_pp ? fe_e - 81 : fe_e) : 3 * 4 * 27 + fe_o * 4 + fe_d;
-                      double *src = (fe_oz == 0) ? (fe_pp ? pp_m1 : pu_m1) : (fe_oz == 1 ? (fe_pp ? pp_z0 : pu_z0) : (fe_pp ? pp_p1 : pu_p1));
-                      src += fe_src;
-                      const unsigned char *nfl = &s.flag[(ck + fe_oz - 1) & 3][fe_nbo];
-                      double *dstp = (NCOL == 3) ? (fe_pp ? vals_pp : vals_pu) : vals_uu;
-                      const bool tile_full = (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1];
-                      if (NCOL == 3 && !masked && tile_full)
-                        ; // handled by the row-run copy below (all 256 threads)
-                      else if (!masked && tile_full)
-                        {
-                          // the common case is free of control flow so that the LDS reads of several rows are in
-                          // flight together
-#pragma unroll 1
-                          for (int n0 = fe_sub; n0 < NPN; n0 += 10)
-                            {
-                              long long offb[5];
-                              double valb[5];
 #pragma unroll
-                              for (int i = 0; i < 5; ++i)
-                                {
-                                  const int nl = min(n0 + 2 * i, NPN - 1); // clamped duplicates are dropped below
-                                  offb[i] = s.off[cp][nl];
-                                  valb[i] = src[nl * fe_stride];
-                                }
+                  for (int ny = 0; ny < PN; ++ny)
 #pragma unroll
-                              for (int i = 0; i < 5; ++i)
-                                if (n0 + 2 * i < NPN)
-                                  {
-                                    dstp[fe_mul * offb[i] + fe_dst] = valb[i];
-                                    src[(n0 + 2 * i) * fe_stride] = 0.0; // these slabs are the next planes' accumulators
-                                  }
-                            }
-                        }
-                      else
+                    for (int q = 0; q < 3; ++q)
+                      if (act[q])
                         {
-#pragma unroll 1
-                          for (int nl = fe_sub; nl < NPN; nl += 2)
-                            {
-                              const long long off = s.off[cp][nl];
-                              double val = src[nl * fe_stride];
-                              src[nl * fe_stride] = 0.0;
-                              if (masked)
-                                {
-                                  const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
-                                  const unsigned row_flag = s.flag[ck & 3][hn], nflag = nfl[hn];
-                                  const bool rcon = (row_flag >> 3) & 1u;
-                                  if (fe_pp)
-                                    {
-                                      if (rcon)
-                                        val = (fe_o == 13) ? s.ex[cp][nl][0] : 0.0;
-                                      else if ((nflag >> 3) & 1u)
-                                        val = 0.0;
-                                    }
-                                  else if (rcon || ((nflag >> fe_d) & 1u))
-                                    val = 0.0; // constrained row (active set) or eliminated column
-                                }
-                              if (off >= 0) // owned node (partial tiles at the high faces)
-                                dstp[fe_mul * off + fe_dst] = val;
-                            }
+                          dstk[q][mul[q] * off0[ny]] = val[ny][q];
+                          srck[q][ny * rstride[q]] = 0.0; // these slabs are the next planes' accumulators
                         }
-                    }
-                  stamp(8);
-                  lds_barrier(); // placeholders are read above, cleared below
-                  stamp(9);
-                  if (t < NPN)
-                    {
-                      const int nl = t;
-                      const double patch = s.ex[cp][nl][1];
-                      s.ex[cp][nl][0] = 0.0;
-                      s.ex[cp][nl][1] = 0.0;
-                      const long long off = s.off[cp][nl];
-                      if (masked && off >= 0 && patch != 0.0)
-                        {
-                          // constrained displacement rows whose element diagonal vanished in some cell
-                          const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
-                          for (int c = 0; c < 3; ++c)
-                            if ((row_flag >> c) & 1u)
-                              vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * 27 + 13 * NCOL + c] += patch;
-                        }
-                    }
                 }
-              else
+              else if (t < 2 * 108)
                 {
-                  // boundary plane (rows with fewer than 27 neighbours, or slot order != lattice order): same
-                  // thread <-> element mapping, the lattice offset of CSR slot sl comes from inv27.  The slot maps of
-                  // the 49 rows are staged in the nodal ring slot of plane ck, which is dead until the next step.
-                  unsigned char *s_inv = reinterpret_cast<unsigned char *>(&s.U[lo][0][0]);
-                  for (int idx = t; idx < NPN * 27; idx += NT4)
+                  // thread <-> element fe_e of a row (0..80 (phi,u), 81..107 (phi,phi)), two rows at a time;
+                  // recomputed per plane rather than kept live across the whole march
+                  int tq = t;
+                  asm volatile("" : "+v"(tq));
+                  const int fe_e = tq % 108, fe_sub = tq / 108;
+                  const bool fe_pp = fe_e >= 81;
+                  const int fe_o = fe_pp ? fe_e - 81 : fe_e / 3, fe_d = fe_pp ? 3 : fe_e % 3; // lattice offset index, column component
+                  const int fe_oz = fe_o / 9, fe_o9 = fe_o % 9;
+                  const int fe_stride = fe_pp ? 9 : 27, fe_src = fe_pp ? fe_o9 : fe_o9 * 3 + fe_d;
+                  const int fe_nbo = (fe_o9 % 3 - 1) + PH * (fe_o9 / 3 - 1); // halo offset of the neighbour node
+                  double *src = (fe_oz == 0) ? (fe_pp ? pp_m1 : pu_m1) : (fe_oz == 1 ? (fe_pp ? pp_z0 : pu_z0) : (fe_pp ? pp_p1 : pu_p1));
+                  src += fe_src;
+                  if (fast)
                     {
-                      const int nl = idx / 27, sl = idx - nl * 27;
-                      unsigned char o = 0xff;
-                      if (s.off[cp][nl] >= 0 && sl < (s.deg[cp][nl] & 0xffff))
-                        o = cv.inv27[(long long)s.row[cp][nl] * 27 + sl];
-                      s_inv[idx] = o;
-                    }
-                  lds_barrier();
-                  if (t < 2 * 108)
-                    {
-                      int tq = t;
-                      asm volatile("" : "+v"(tq));
-                      const int ge = tq % 108, gsub = tq / 108;
-                      const bool gpp = ge >= 81;
-                      const int sl = gpp ? ge - 81 : ge / 3, gd = gpp ? 3 : ge % 3; // CSR slot, column component
+                      // interleaved layout, interior plane: free of control flow so that the LDS reads of several
+                      // rows are in flight together
+                      const int fe_dst = 3 * 4 * 27 + fe_o * 4 + fe_d;
 #pragma unroll 1
-                      for (int nl = gsub; nl < NPN; nl += 2)
+                      for (int n0 = fe_sub; n0 < NPN; n0 += 10)
                         {
-                          const int o = s_inv[nl * 27 + sl];
-                          if (o == 0xff)
-                            continue;
+                          long long offb[5];
+                          double valb[5];
+#pragma unroll
+                          for (int i = 0; i < 5; ++i)
+                            {
+                              const int nl = min(n0 + 2 * i, NPN - 1); // clamped duplicates are dropped below
+                              offb[i] = s.off[cp][nl];
+                              valb[i] = src[nl * fe_stride];
+                            }
+#pragma unroll
+                          for (int i = 0; i < 5; ++i)
+                            if (n0 + 2 * i < NPN)
+                              {
+                                vals_uu[16 * offb[i] + fe_dst] = valb[i];
+                                src[(n0 + 2 * i) * fe_stride] = 0.0; // these slabs are the next planes' accumulators
+                              }
+                        }
+                    }
+                  else
+                    {
+                      // constraint flags near the plane, partial tiles at the high faces, boundary rows with fewer
+                      // than 27 neighbours
+                      const unsigned char *nfl = &s.flag[(ck + fe_oz - 1) & 3][fe_nbo];
+                      const unsigned below = (1u << fe_o) - 1u;
+#pragma unroll 1
+                      for (int nl = fe_sub; nl < NPN; nl += 2)
+                        {
                           const long long off = s.off[cp][nl];
-                          const int oz = o / 9, o9 = o - 9 * oz;
-                          double *src = gpp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nl * 9 + o9)
-                                            : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nl * 27 + o9 * 3 + gd);
-                          double val = *src;
-                          *src = 0.0;
+                          const unsigned nmask = (unsigned)s.deg[cp][nl];
+                          double val = src[nl * fe_stride];
+                          src[nl * fe_stride] = 0.0;
                           if (masked)
                             {
                               const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
-                              const int oy = o9 / 3, ox = o9 - 3 * oy;
-                              const unsigned row_flag = s.flag[ck & 3][hn];
-                              const unsigned nflag = s.flag[(ck + oz - 1) & 3][hn + (ox - 1) + PH * (oy - 1)];
+                              const unsigned row_flag = s.flag[ck & 3][hn], nflag = nfl[hn];
                               const bool rcon = (row_flag >> 3) & 1u;
-                              if (gpp)
+                              if (fe_pp)
                                 {
                                   if (rcon)
-                                    val = (o == 13) ? s.ex[cp][nl][0] : 0.0;
+                                    val = (fe_o == 13) ? s.ex[cp][nl][0] : 0.0;
                                   else if ((nflag >> 3) & 1u)
                                     val = 0.0;
                                 }
-                              else if (rcon || ((nflag >> gd) & 1u))
-                                val = 0.0;
+                              else if (rcon || ((nflag >> fe_d) & 1u))
+                                val = 0.0; // constrained row (active set) or eliminated column
                             }
-                          if constexpr (NCOL == 3)
+                          if (off >= 0 && ((nmask >> fe_o) & 1u)) // owned node, neighbour inside the mesh
                             {
-                              if (gpp)
-                                vals_pp[off + sl] = val;
-                              else
-                                vals_pu[3 * off + sl * 3 + gd] = val;
+                              const int sl = __popc(nmask & below);
+                              if constexpr (NCOL == 3)
+                                {
+                                  if (fe_pp)
+                                    vals_pp[off + sl] = val;
+                                  else
+                                    vals_pu[3 * off + sl * 3 + fe_d] = val;
+                                }
+                              else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
+                                vals_uu[16 * off + (long long)3 * 4 * __popc(nmask) + sl * 4 + fe_d] = val;
                             }
-                          else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
-                            vals_uu[16 * off + (long long)3 * 4 * (s.deg[cp][nl] & 0xffff) + sl * 4 + gd] = val;
                         }
                     }
-                  lds_barrier(); // placeholders are read above, cleared below
-                  if (t < NPN)
+                }
+              stamp(8);
+              lds_barrier(); // placeholders are read above, cleared below
+              stamp(9);
+              if (t < NPN)
+                {
+                  const int nl = t;
+                  const double patch = s.ex[cp][nl][1];
+                  s.ex[cp][nl][0] = 0.0;
+                  s.ex[cp][nl][1] = 0.0;
+                  const long long off = s.off[cp][nl];
+                  if (masked && off >= 0 && patch != 0.0)
                     {
-                      const int nl = t;
-                      const double patch = s.ex[cp][nl][1];
-                      s.ex[cp][nl][0] = 0.0;
-                      s.ex[cp][nl][1] = 0.0;
-                      const long long off = s.off[cp][nl];
-                      if (masked && off >= 0 && patch != 0.0)
-                        {
-                          const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
-                          const int deg = s.deg[cp][nl] & 0xffff, row = s.row[cp][nl];
-                          int sself = 0;
-                          for (int q = 0; q < deg; ++q)
-                            if (cv.inv27[(long long)row * 27 + q] == 13)
-                              sself = q;
-                          for (int c = 0; c < 3; ++c)
-                            if ((row_flag >> c) & 1u)
-                              vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += patch;
-                        }
+                      // constrained displacement rows whose element diagonal vanished in some cell
+                      const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
+                      const unsigned nmask = (unsigned)s.deg[cp][nl];
+                      const int deg = __popc(nmask), sself = __popc(nmask & ((1u << 13) - 1u));
+                      for (int c = 0; c < 3; ++c)
+                        if ((row_flag >> c) & 1u)
+                          vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += patch;
                     }
                 }
             }

@@ -203,12 +203,21 @@ namespace
           return false;
       }
     std::vector<uint8_t> regular((size_t)NO, 0);
+    std::vector<uint32_t> nbr_mask((size_t)NO, 0); // bit o: the neighbour at lattice offset o exists in the row
     for (int32_t n = 0; n < NO; ++n)
       {
-        bool reg = (c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]) == no;
+        const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
+        bool reg = deg == no;
         for (int o = 0; reg && o < no; ++o)
           reg = inv[(size_t)n * no + o] == (uint8_t)o;
         regular[n] = reg ? 1 : 0;
+        for (int sl = 0; sl < deg; ++sl)
+          {
+            // rows are in lattice order (pfm_ctx_create): slot sl = rank of its offset among the existing ones
+            if (sl > 0 && inv[(size_t)n * no + sl] <= inv[(size_t)n * no + sl - 1])
+              return false;
+            nbr_mask[n] |= 1u << inv[(size_t)n * no + sl];
+          }
       }
     CartView &cv = c->cv;
     cv.NX = NX;
@@ -223,6 +232,7 @@ namespace
     cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
     cv.inv27 = dev_upload(c, inv.data(), inv.size());
     cv.row_regular = dev_upload(c, regular.data(), regular.size());
+    cv.nbr_mask = dev_upload(c, nbr_mask.data(), nbr_mask.size());
     cv.owned_lex = 1;
     {
       const int64_t OWX = o1[0] - o0[0] + 1, OWY = o1[1] - o0[1] + 1;
