@@ -46,20 +46,35 @@ namespace pfm
 
     struct Lds4
     {
+      // destinations of the global -> LDS transfers first: M0 carries a 16-bit LDS offset
       double U[2][6][NPH];   // nodal ring: u_x u_y u_z phi phi_old phi_oldold
+      long long off[2][NPN]; // node-graph offset of the row, -1 = not an owned node of this tile
+      int deg[2][NPN];       // neighbour mask of the row (bit o: lattice offset o exists)
+      unsigned char flag[4][NPH];
+      int irregular[2];
+      int anyflag[4];
       double pu[5][SLAB_PU]; // staged (phi,u) rows: [0,1] oz=-1 ring, [2,3] oz=0 ring, [4] oz=+1; [node][o9][d]
       double pp[5][SLAB_PP]; // staged (phi,phi) rows, same slabs; [node][o9]
       double ex[2][NPN][2];  // per node: placeholder sum, (u,u) placeholder patch
-      long long off[2][NPN]; // node-graph offset of the row, -1 = not an owned node of this tile
-      int deg[2][NPN];       // neighbour mask of the row (bit o: lattice offset o exists)
-      int irregular[2];
-      int anyflag[4];
-      unsigned char flag[4][NPH];
     };
 
     __host__ __device__ constexpr int idxC4(int al, int gi, int gj) { return al * 9 + gi * 3 + gj; }
 
     // d/dy of one nodal field at x-vertex 0/1: depends on the z-level only, evaluated once per qz
+    // global -> LDS without staging registers: LDS address = (wave-uniform) lds + lane * size.  Written as asm so that
+    // the compiler does not track the transfer: it would otherwise wait vmcnt(0) at every later LDS access of the
+    // same __shared__ object (no alias information inside one struct), serialising the requests.  The consumer waits
+    // with an explicit s_waitcnt vmcnt(0) before the workgroup barrier.
+    // address = uniform base (SGPR pair) + per-lane byte offset (one VGPR shared by all fields of a plane)
+    __device__ __forceinline__ void dma_b32(const void *base, unsigned byte_off, void *lds)
+    {
+      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(byte_off), "s"(base), "s"(l)
+                   : "memory");
+    }
     __device__ __forceinline__ void dy_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double nz0,
                                                 double nz1, double ihy, double (&Dy)[2])
     {
@@ -367,6 +382,7 @@ namespace pfm
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */>
     __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
+                                                          double *__restrict__ vals_up /* blocked layout: structurally zero (u,phi) block, cleared here */,
                                                           int zc /* node planes per chunk */,
                                                           unsigned long long *__restrict__ dbg)
     {
@@ -400,73 +416,72 @@ namespace pfm
       const int hb = cy * PH + cx;               // halo index of the cell's (0,0) vertex
       const int nl0 = (cx - 1) + PN * (cy - 1);  // owned-node index of that vertex (may be out of range)
 
-      // nodal plane / row info of a plane: global memory -> registers -> LDS
-      double pv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // plane in flight (threads < NPH): nodal values, flags
-      unsigned pflag = 0;
-      auto fetch_plane = [&](int kz) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-          pv[c] = 0.0;
-        pflag = 0;
-        if (t < NPH)
+      // Nodal plane / row info of a plane: global memory -> LDS directly (global_load_lds: destination = wave-uniform
+      // base + 4 * lane, no staging registers), issued ahead of the copy-out stores of the previous step and waited for
+      // at the top of the step that consumes them.  Lanes without a source (outside the mesh / the owned box) write
+      // the neutral value themselves.  Waves 0..2: dwords [64 w, 64 w + 64) of each of the 6 nodal fields (81 doubles
+      // = 162 dwords), one node id per lane; their even lanes also fetch the node's flag byte, which goes through a
+      // register (sub-dword transfers to LDS would still occupy one dword per lane) and is stored at the end of the
+      // step.  Wave 3: value offset (64-bit: 98 dwords) and neighbour mask of the 49 rows.
+      unsigned pf = 0u; // flag byte in flight
+      auto dma_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+        if (role < 3)
           {
-            const int hx = t % PH, hy = t / PH;
-            const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
-            if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
+            int lq = lane;
+            asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
+            const int dw = 64 * role + lq, hn = dw >> 1;
+            const int gi = i0 - 1 + hn % PH, gj = j0 - 1 + hn / PH;
+            const bool inside = dw < 2 * NPH;
+            const bool ok = inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
+            const unsigned n = ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
+            const unsigned boff = 8u * n + 4u * (dw & 1);
+            const double *const fld[6] = {v.u[0], v.u[1], v.u[2], v.phi, v.phi_old, v.phi_oldold};
+            pf = 0u;
+            if (ok)
               {
-                const int n = cart_local_id(cv, gi, gj, kz);
-                pv[0] = v.u[0][n];
-                pv[1] = v.u[1][n];
-                pv[2] = v.u[2][n];
-                pv[3] = v.phi[n];
-                pv[4] = v.phi_old[n];
-                pv[5] = v.phi_oldold[n];
-                pflag = v.node_flags[n];
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                  dma_b32(fld[c], boff, reinterpret_cast<uint32_t *>(&s.U[buf][c][0]) + 64 * role);
+                if ((dw & 1) == 0)
+                  pf = v.node_flags[n];
+              }
+            else if (inside)
+              {
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                  reinterpret_cast<uint32_t *>(&s.U[buf][c][0])[dw] = 0u;
               }
           }
       };
-      auto put_plane = [&](int kz, int buf) __attribute__((always_inline)) {
-        if (t == 0)
-          s.anyflag[kz & 3] = 0;
-        if (t < NPH)
-          {
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-              s.U[buf][c][t] = pv[c];
-            s.flag[kz & 3][t] = (unsigned char)pflag;
-          }
+      auto flags_put = [&](int kz) __attribute__((always_inline)) {
+        const int dw = 64 * role + lane;
+        if (role < 3 && (dw & 1) == 0 && dw < 2 * NPH)
+          s.flag[kz & 3][dw >> 1] = (unsigned char)pf;
       };
-      long long r_off = -1; // row info in flight (threads 128 .. 128 + NPN, all in wave 2)
-      int r_deg = 0, r_row = 0;
-      auto fetch_rows = [&](int kz) __attribute__((always_inline)) {
-        r_off = -1;
-        r_deg = 0;
-        r_row = 0;
-        if (t >= 128 && t < 128 + NPN)
-          {
-            const int nl = t - 128, nx = nl % PN, ny = nl / PN;
-            const int gi = i0 + nx, gj = j0 + ny;
-            if (gi <= cv.o1[0] && gj <= cv.o1[1])
-              {
-                r_row = cart_local_id(cv, gi, gj, kz);
-                r_off = v.nadj_ptr[r_row];
-                r_deg = (int)cv.nbr_mask[r_row]; // neighbour mask of the row (27 bits)
-              }
-          }
-      };
-      auto put_rows = [&](int kz) __attribute__((always_inline)) {
+      auto dma_rows = [&](int kz) __attribute__((always_inline)) {
         const int par = kz & 1;
-        if (role == 2)
+        if (role == 3)
           {
-            const bool mine = t < 128 + NPN;
-            const unsigned long long irr = __ballot(mine && r_off >= 0 && r_deg != 0x7ffffff);
-            if (mine)
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            const int gi = i0 + lq % PN, gj = j0 + lq / PN;
+            const bool ok = lq < NPN && gi <= cv.o1[0] && gj <= cv.o1[1];
+            const unsigned n = ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0xffffffffu;
+            if (ok)
+              dma_b32(cv.nbr_mask, 4u * n, &s.deg[par][0]);
+            else if (lq < NPN)
+              s.deg[par][lq] = 0x7ffffff;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&s.off[par][0]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
               {
-                s.off[par][t - 128] = r_off;
-                s.deg[par][t - 128] = r_deg;
+                const int dw = 64 * j + lq;
+                const unsigned nj = (unsigned)__shfl((int)n, dw >> 1); // lanes 2 nl, 2 nl + 1: the two halves of row nl
+                if (dw < 2 * NPN && nj != 0xffffffffu)
+                  dma_b32(v.nadj_ptr, 8u * nj + 4u * (dw & 1), dst + 64 * j);
+                else if (dw < 2 * NPN)
+                  dst[dw] = 0xffffffffu; // off = -1: not an owned node
               }
-            if (lane == 0)
-              s.irregular[par] = irr != 0;
           }
       };
 
@@ -477,8 +492,13 @@ namespace pfm
         (&s.pp[0][0])[i] = 0.0;
       for (int i = t; i < 2 * NPN * 2; i += NT4)
         (&s.ex[0][0][0])[i] = 0.0;
-      fetch_plane(kA - 1);
-      put_plane(kA - 1, 0);
+      if (t < 4)
+        s.anyflag[t] = 0;
+      dma_plane(kA - 1, 0);
+      flags_put(kA - 1);
+      dma_plane(kA, 1);
+      flags_put(kA);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t < NPH && s.flag[(kA - 1) & 3][t])
         s.anyflag[(kA - 1) & 3] = 1;
@@ -490,17 +510,19 @@ namespace pfm
           stamp(3);
           if constexpr (CLK == 2)
             tclk = clock64();
-          fetch_plane(ck + 1);
-          put_plane(ck + 1, hi);
-          if (ck >= kA)
+          // plane ck + 1 and the rows of plane ck were requested before the previous step's copy-out
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (t == 0)
             {
-              fetch_rows(ck);
-              put_rows(ck);
+              s.anyflag[(ck + 1) & 3] = 0;
+              s.irregular[cp] = 0;
             }
           lds_barrier();
           stamp(0);
           if (t < NPH && s.flag[(ck + 1) & 3][t])
             s.anyflag[(ck + 1) & 3] = 1;
+          if (ck >= kA && t >= 128 && t < 128 + NPN && s.off[cp][t - 128] >= 0 && s.deg[cp][t - 128] != 0x7ffffff)
+            s.irregular[cp] = 1;
 
           // ---- entries of layer ck, pushed into the rows of planes ck (lower vertices) and ck+1 (upper vertices)
           const bool cell_ok = col_ok && ck >= 0 && ck < cv.NZ - 1;
@@ -600,6 +622,13 @@ namespace pfm
           stamp(1);
           lds_barrier();
           stamp(2);
+          // next step's plane and row info: loads issued ahead of the copy-out stores, consumed after them
+          if (ck + 1 < kB)
+            {
+              dma_plane(ck + 2, lo); // slot lo (plane ck) is dead once the entries of layer ck are done
+              dma_rows(ck + 1);
+            }
+          stamp(10);
 
           // ---- plane ck is complete: constraints as masks, then stream the rows out
           if (ck >= kA)
@@ -615,50 +644,69 @@ namespace pfm
               if (NCOL == 3 && fast)
                 {
                   // Blocked layout, interior plane without constraint flags (the common case): the 7 rows of a
-                  // y-line of the tile are ONE contiguous run of 7*81 (phi,u) + 7*27 (phi,phi) values.  Thread <->
-                  // up to 3 fixed positions of that run; per y-line 3 LDS reads and 3 fully coalesced stores.
+                  // y-line of the tile are ONE contiguous run of 7*81 (phi,u) values, the same run of (u,phi) zeros
+                  // and a run of 7*27 (phi,phi) values.  Thread <-> fixed positions of the runs (3 of the 567, the
+                  // last one for t < 55; threads 64.. one of the 189); the run starts are wave-uniform (scalar base +
+                  // 32-bit lane offset), the LDS strides per y-line are immediates.  (Pairs of elements per lane
+                  // with 16-byte stores were measured slower: the runs are only 8-byte aligned.)
                   int tq = t;
                   asm volatile("" : "+v"(tq));
-                  double *srck[3];
-                  double *dstk[3];
-                  int rstride[3], mul[3];
-                  bool act[3];
+                  const bool act2 = tq < PN * 81 - 2 * NT4;
+                  const int gp = tq - 64;
+                  const bool actp = gp >= 0 && gp < PN * 27;
+                  double *spu[3];
 #pragma unroll
                   for (int q = 0; q < 3; ++q)
                     {
-                      const int f = tq + NT4 * q;
-                      act[q] = f < PN * 108;
-                      const bool is_pp = f >= PN * 81;
-                      const int g = is_pp ? f - PN * 81 : f;
-                      const int per = is_pp ? 27 : 81;
-                      const int nx = g / per, e = g - nx * per;
-                      const int o = is_pp ? e : e / 3, d = is_pp ? 0 : e - 3 * (e / 3);
+                      const int f = (q < 2 || act2) ? tq + NT4 * q : 0;
+                      const int nx = f / 81, e = f - nx * 81;
+                      const int o = e / 3, d = e - 3 * o;
                       const int oz = o / 9, o9 = o - 9 * oz;
-                      double *slab = is_pp ? (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) : (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1));
-                      srck[q] = slab + (is_pp ? nx * 9 + o9 : nx * 27 + o9 * 3 + d);
-                      rstride[q] = is_pp ? PN * 9 : PN * 27;
-                      dstk[q] = (is_pp ? vals_pp : vals_pu) + g;
-                      mul[q] = is_pp ? 1 : 3;
+                      spu[q] = (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nx * 27 + o9 * 3 + d);
                     }
+                  double *spp;
+                  {
+                    const int g = actp ? gp : 0;
+                    const int nx = g / 27, o = g - nx * 27;
+                    const int oz = o / 9, o9 = o - 9 * oz;
+                    spp = (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nx * 9 + o9);
+                  }
+                  double val[PN][4];
                   long long off0[PN];
-                  double val[PN][3];
 #pragma unroll
                   for (int ny = 0; ny < PN; ++ny)
                     {
-                      off0[ny] = s.off[cp][ny * PN];
-#pragma unroll
-                      for (int q = 0; q < 3; ++q)
-                        val[ny][q] = act[q] ? srck[q][ny * rstride[q]] : 0.0;
+                      const long long o = s.off[cp][ny * PN]; // same address for every lane
+                      off0[ny] = ((long long)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+                      val[ny][0] = spu[0][ny * (PN * 27)];
+                      val[ny][1] = spu[1][ny * (PN * 27)];
+                      val[ny][2] = act2 ? spu[2][ny * (PN * 27)] : 0.0;
+                      val[ny][3] = actp ? spp[ny * (PN * 9)] : 0.0;
                     }
+                  const unsigned uq = (unsigned)tq, up = (unsigned)(actp ? gp : 0);
 #pragma unroll
                   for (int ny = 0; ny < PN; ++ny)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                      if (act[q])
+                    {
+                      double *bpu = vals_pu + 3 * off0[ny], *bup = vals_up + 3 * off0[ny], *bpp = vals_pp + off0[ny];
+                      bpu[uq] = val[ny][0];
+                      bup[uq] = 0.0;
+                      bpu[uq + NT4] = val[ny][1];
+                      bup[uq + NT4] = 0.0;
+                      spu[0][ny * (PN * 27)] = 0.0; // these slabs are the next planes' accumulators
+                      spu[1][ny * (PN * 27)] = 0.0;
+                      if (act2)
                         {
-                          dstk[q][mul[q] * off0[ny]] = val[ny][q];
-                          srck[q][ny * rstride[q]] = 0.0; // these slabs are the next planes' accumulators
+                          bpu[uq + 2 * NT4] = val[ny][2];
+                          bup[uq + 2 * NT4] = 0.0;
+                          spu[2][ny * (PN * 27)] = 0.0;
                         }
+                      if (actp)
+                        {
+                          bpp[up] = val[ny][3];
+                          spp[ny * (PN * 9)] = 0.0;
+                        }
+                    }
                 }
               else if (t < 2 * 108)
                 {
@@ -736,7 +784,10 @@ namespace pfm
                                   if (fe_pp)
                                     vals_pp[off + sl] = val;
                                   else
-                                    vals_pu[3 * off + sl * 3 + fe_d] = val;
+                                    {
+                                      vals_pu[3 * off + sl * 3 + fe_d] = val;
+                                      vals_up[3 * off + sl * 3 + fe_d] = 0.0; // any bijection onto the node's 3 rows
+                                    }
                                 }
                               else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
                                 vals_uu[16 * off + (long long)3 * 4 * __popc(nmask) + sl * 4 + fe_d] = val;
@@ -766,6 +817,8 @@ namespace pfm
                     }
                 }
             }
+          if (ck + 1 < kB)
+            flags_put(ck + 2);
         }
       stamp(3);
     }
@@ -796,7 +849,7 @@ namespace pfm
     const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], zc, nullptr);
+      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr, zc, nullptr);
     else if (getenv("PFM_PHI_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
@@ -806,10 +859,10 @@ namespace pfm
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
         if (atoi(getenv("PFM_PHI_CLK")) == 2)
           hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
-                             d_values[0], zc, d_dbg);
+                             d_values[0], d_values[1], zc, d_dbg);
         else
           hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
-                             d_values[0], zc, d_dbg);
+                             d_values[0], d_values[1], zc, d_dbg);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[16] = {};
@@ -821,18 +874,18 @@ namespace pfm
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
         for (int i = 0; i < 4; ++i)
           fprintf(stderr, " role%d=%.0f", i, (double)h[4 + i] / nb);
-        fprintf(stderr, " copy-loop=%.0f copy-barrier=%.0f", (double)h[8] / nb, (double)h[9] / nb);
+        fprintf(stderr, " request-next=%.0f copy-loop=%.0f copy-barrier=%.0f", (double)h[10] / nb, (double)h[8] / nb, (double)h[9] / nb);
         fprintf(stderr, "\n");
       }
     else
-      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], zc,
-                         nullptr);
+      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], d_values[1],
+                         zc, nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   bool cart_matrix_supported(int dim) { return dim == 3; }
 
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
-  // (same stream); the structurally zero (u,phi) block (cracks.cc:2333-2337) is cleared by the host side
+  // (same stream) and clears the structurally zero (u,phi) block (cracks.cc:2333-2337) along with its (phi,u) stores
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
                          void *d_scal)
   {

@@ -771,8 +771,7 @@ extern "C"
         ++c->ev_used;
         hipEventRecord(ev0, c->stream);
       }
-    // Optional (PFM_SIDE_STREAM=1): residual kernel and clearing of the structurally zero (u,phi) block on a side
-    // stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
+    // Optional (PFM_SIDE_STREAM=1): residual kernel on a side stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
     // the kernels do not share CUs usefully; off by default.
     hipStream_t s_res = c->stream;
     const bool fork = cart && !residual_only && getenv("PFM_SIDE_STREAM");
@@ -803,10 +802,10 @@ extern "C"
         {
           if (!d_values[b])
             return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
-          // the row-owner kernels write every value once; only the structurally zero (u,phi)
-          // block of the blocked layout has no kernel and is cleared here
-          if (!cart || (c->n_blocks == 4 && b == 1))
-            e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), cart ? s_res : c->stream);
+          // the row-owner kernels write every value once, the structurally zero (u,phi) block
+          // of the blocked layout included (k_cart_phi4)
+          if (!cart)
+            e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");

@@ -194,3 +194,33 @@ def test_cart_random_constraints_stress(blocked, kappa_zero):
     assert linf_scaled(res_pde, r.residual_pde) < TOL
     assert linf_scaled(res_tot, r.residual_total) < TOL
     _full(c, path=1)
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+def test_cart_overwrites_every_output(blocked):
+    """`system_pde_matrix = 0` (cracks.cc:2133-2137) is part of the assembly: every value of every block, the
+    structurally zero (u,phi) block included, and both residuals are written whatever the buffers held before."""
+    import torch
+    from cracks_amd.assembler import Assembler
+
+    c = box_case(3, (16, 9, 30), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0), blocked)
+    asm = Assembler(c.mesh, blocked=blocked)
+    assert asm.ctx.kernel_path == 1
+    asm.set_params(c.params)
+    from cracks_amd.assembler import node_flags_from_dof_flags
+    asm.set_constraints(node_flags_from_dof_flags(c.layout, c.cu.flag, c.ch.flag))
+    asm.set_vectors(c.sol, c.old, c.oldold)
+    asm.allocate_matrix()
+    outs = []
+    for fill in (float("nan"), 0.0):
+        for m in asm.system_pde_matrix:
+            m.fill_(fill)
+        asm.system_pde_residual.fill_(fill)
+        asm.assemble_system(False)
+        asm.synchronize()
+        outs.append([m.clone() for m in asm.system_pde_matrix] + [asm.system_pde_residual.clone()])
+    for a, b in zip(*outs):
+        assert not torch.isnan(a).any()
+        assert torch.equal(a, b)
+    if blocked:
+        assert float(outs[0][1].abs().max()) == 0.0
