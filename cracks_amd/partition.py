@@ -19,7 +19,7 @@ rank ``r = ix + p0*(iy + p1*iz)``.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -125,7 +125,9 @@ class LocalProblem:
     send_nodes: np.ndarray  # local (owned) node indices, grouped by peer, ascending global id
     recv_ptr: np.ndarray
     recv_nodes: np.ndarray  # local (ghost) node indices
-    box: LocalBox
+    box: Optional[LocalBox] = None  # uniform-box partition only
+    cell_owned: Optional[np.ndarray] = None  # uint8 per local cell: 1 = cell->is_locally_owned() (functionals)
+    global_cells: Optional[np.ndarray] = None  # general partition: global index of each local cell
 
 
 def build_local_problem(dim: int, n: Sequence[int], p: Sequence[int], rank: int, lo=-10.0, hi=10.0) -> LocalProblem:
@@ -208,3 +210,106 @@ def build_local_problem(dim: int, n: Sequence[int], p: Sequence[int], rank: int,
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int32)
     return LocalProblem(mesh, n_owned, global_ids, peers, np.asarray(send_ptr, np.int64), cat(send_nodes),
                         np.asarray(recv_ptr, np.int64), cat(recv_nodes), box)
+
+
+# ------------------------------------------------------------------------------------------------
+# General meshes (adaptively refined, hanging nodes, slits): BASELINE config "Miehe shear with
+# predictor-corrector AMR on 4 GPUs".  p4est cuts its space-filling curve into equal pieces
+# (cracks.cc:1083, repartitioning inside execute_coarsening_and_refinement, cracks.cc:4137-4148); the
+# stand-in orders the active cells along a Morton curve of their centres.
+
+
+def morton_cell_ranks(mesh: Mesh, world: int) -> np.ndarray:
+    """Rank of every active cell: Morton order of the cell centres, cut into ``world`` equal pieces."""
+    c = mesh.coords[mesh.cells].mean(axis=1)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    q = np.minimum(((c - lo) / np.maximum(hi - lo, 1e-300) * (1 << 20)).astype(np.int64), (1 << 20) - 1)
+    key = np.zeros(mesh.n_cells, np.int64)
+    for b in range(20):
+        for d in range(mesh.dim):
+            key |= ((q[:, d] >> b) & 1) << (mesh.dim * b + d)
+    order = np.argsort(key, kind="stable")
+    rank = np.empty(mesh.n_cells, np.int64)
+    rank[order] = (np.arange(mesh.n_cells) * world) // mesh.n_cells
+    return rank
+
+
+def partition_general(mesh: Mesh, world: int, cell_rank: Optional[np.ndarray] = None) -> List[LocalProblem]:
+    """Owner-computes partition of an arbitrary Q1 mesh (hanging nodes allowed) into ``world`` rank-local problems.
+
+    * a node belongs to the lowest rank owning a cell that has it as a vertex (deal.II's rule for dofs);
+    * a rank's local cells are all cells that contribute to a row it owns: cells with an owned vertex, and cells
+      with a hanging vertex one of whose parents is owned (``distribute_local_to_global`` moves those
+      contributions to the parents' rows, cracks.cc:2440-2447) -- every owned row is complete locally and the
+      ``compress(add)`` exchange of the reference disappears, as for the box partition;
+    * local nodes = vertices of the local cells and the parents of their hanging vertices: owned first, then
+      ghosts, each group by ascending global id; the ghost values come from the owners (HaloExchange).
+    """
+    import scipy.sparse as sp
+
+    N, nc_cells, nv = mesh.n_nodes, mesh.n_cells, mesh.nv
+    if cell_rank is None:
+        cell_rank = morton_cell_ranks(mesh, world)
+    cell_rank = np.asarray(cell_rank, np.int64)
+    C = sp.csr_matrix((np.ones(nc_cells * nv, np.int32), (np.repeat(np.arange(nc_cells), nv), mesh.cells.ravel())),
+                      shape=(nc_cells, N))
+    if mesh.hn_nodes.size:
+        H = sp.csr_matrix((np.ones(mesh.hn_parents.size, np.int32),
+                           (np.repeat(mesh.hn_nodes, np.diff(mesh.hn_ptr)), mesh.hn_parents)), shape=(N, N))
+        C = (C + C @ H).tocsr()  # cell -> vertices and parents of hanging vertices
+    owner = np.full(N, world, np.int64)
+    np.minimum.at(owner, mesh.cells.ravel(), np.repeat(cell_rank, nv))
+    assert (owner < world).all(), "node without a cell"
+    hn_index = np.full(N, -1, np.int64)
+    hn_index[mesh.hn_nodes] = np.arange(mesh.hn_nodes.size)
+    parts = []
+    for r in range(world):
+        owned_mask = owner == r
+        lc = np.nonzero(C @ owned_mask.astype(np.int32) > 0)[0]
+        reach = np.zeros(N, bool)
+        sub = C[lc]
+        reach[sub.indices] = True
+        owned_ids = np.nonzero(owned_mask)[0]
+        ghost_ids = np.nonzero(reach & ~owned_mask)[0]
+        gids = np.concatenate([owned_ids, ghost_ids])
+        g2l = np.full(N, -1, np.int64)
+        g2l[gids] = np.arange(gids.size)
+        cells = g2l[mesh.cells[lc]]
+        assert (cells >= 0).all()
+        hsel = hn_index[gids]
+        hsel = hsel[hsel >= 0]
+        hsel.sort()
+        cnt = np.diff(mesh.hn_ptr)[hsel]
+        hptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        take = np.concatenate([np.arange(mesh.hn_ptr[k], mesh.hn_ptr[k + 1]) for k in hsel]) if hsel.size else np.zeros(0, np.int64)
+        hpar = g2l[mesh.hn_parents[take]]
+        # a hanging node that is only a ghost neighbour still needs its parents for the column resolution; they are
+        # local because the cell that brought the node in also brings its parents
+        assert (hpar >= 0).all()
+        bn = {b: g2l[nodes[reach[nodes] | owned_mask[nodes]]].astype(np.int32) for b, nodes in mesh.boundary_nodes.items()}
+        lmesh = Mesh(dim=mesh.dim, coords=np.ascontiguousarray(mesh.coords[gids]), cells=np.ascontiguousarray(cells.astype(np.int32)),
+                     boundary_nodes=bn, hn_nodes=g2l[mesh.hn_nodes[hsel]].astype(np.int32), hn_ptr=hptr,
+                     hn_parents=hpar.astype(np.int32), hn_weights=mesh.hn_weights[take].copy())
+        parts.append(dict(mesh=lmesh, n_owned=int(owned_ids.size), gids=gids, g2l=g2l, ghost_ids=ghost_ids, lc=lc))
+    out = []
+    for r, pr in enumerate(parts):
+        ghost_owner = owner[pr["ghost_ids"]]
+        peers = set(int(k) for k in np.unique(ghost_owner))
+        for s, ps in enumerate(parts):
+            if s != r and (owner[ps["ghost_ids"]] == r).any():
+                peers.add(s)
+        peers = sorted(peers)
+        send_ptr, recv_ptr, send_nodes, recv_nodes = [0], [0], [], []
+        for s in peers:
+            theirs = parts[s]["ghost_ids"]
+            mine = theirs[owner[theirs] == r]  # ascending global id = the order rank s receives in
+            send_nodes.append(pr["g2l"][mine].astype(np.int32))
+            send_ptr.append(send_ptr[-1] + mine.size)
+            sel = pr["ghost_ids"][ghost_owner == s]
+            recv_nodes.append(pr["g2l"][sel].astype(np.int32))
+            recv_ptr.append(recv_ptr[-1] + sel.size)
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int32)
+        out.append(LocalProblem(pr["mesh"], pr["n_owned"], pr["gids"], peers, np.asarray(send_ptr, np.int64), cat(send_nodes),
+                                np.asarray(recv_ptr, np.int64), cat(recv_nodes), None,
+                                (cell_rank[pr["lc"]] == r).astype(np.uint8), pr["lc"]))
+    return out

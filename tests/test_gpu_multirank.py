@@ -129,3 +129,106 @@ def test_owned_rows_match_single_rank(dim, n, world, path):
                     assert set(got) == set(want)
                     scale = max(1.0, max(abs(x) for x in want.values()))
                     assert max(abs(got[k] - want[k]) for k in want) < 1e-12 * scale
+
+
+@pytest.mark.parametrize("kind,world", [("slit2d", 4), ("slit2d", 3), ("box3d", 2)])
+def test_general_partition_owned_rows_match_single_rank(kind, world):
+    """BASELINE config 'Miehe shear with AMR on 4 GPUs': general partition (hanging nodes, slit), general kernel
+    family, stress split active in 2-D; every rank's context on cuda:0, ghost import through the HIP pack/unpack."""
+    import torch
+    from cracks_amd.assembler import Assembler, node_flags_from_dof_flags
+    from cracks_amd.capi import PfmParams
+    from test_partition_halo import amr_mesh, _amr_fields
+    import cases
+
+    g = amr_mesh(kind)
+    dim = g.dim
+    N = g.n_nodes
+    f = _amr_fields(g, dim)
+    for k, n in enumerate(g.hn_nodes):  # nodal fields with the hanging-node constraints distributed
+        sl = slice(g.hn_ptr[k], g.hn_ptr[k + 1])
+        f[n] = (g.hn_weights[sl, None] * f[g.hn_parents[sl]]).sum(axis=0)
+    base = cases.kat_sneddon_3d(4) if dim == 3 else cases.kat_miehe_shear_1()
+    prm = PfmParams.from_buffer_copy(bytes(base.params))
+    if dim == 2:
+        prm.decompose_stress_rhs = prm.decompose_stress_matrix = 1.0
+        prm.timestep_number = 3
+    glay = M.DofLayout(N, dim, blocked=True)
+    dirichlet = M.sneddon_dirichlet_dofs if dim == 3 else M.miehe_shear_dirichlet_dofs
+    gcu = M.update_constraints(g, glay, dirichlet(g, glay))
+    gch = M.hanging_constraints(g, glay)
+    gflags = node_flags_from_dof_flags(glay, gcu.flag, gch.flag)
+
+    def pack(no, ff):
+        v = np.empty(no * (dim + 1))
+        v[:no * dim] = ff[:no, :dim].reshape(-1)
+        return v
+
+    def vectors(no, ff):
+        sol, old, oo = pack(no, ff), pack(no, 0 * ff), pack(no, 0 * ff)
+        sol[no * dim:], old[no * dim:], oo[no * dim:] = ff[:no, dim], ff[:no, dim + 1], ff[:no, dim + 2]
+        return sol, old, oo
+
+    ref = Assembler(g, blocked=True)
+    assert ref.ctx.kernel_path == 0
+    ref.set_params(prm)
+    ref.set_constraints(gflags)
+    ref.set_vectors(*vectors(N, f))
+    ref.assemble_system()
+    ref.synchronize()
+    ref_vals = [m.cpu().numpy() for m in ref.system_pde_matrix]
+    ref_res = ref.system_pde_residual.cpu().numpy()
+    ref_pat = [ref.ctx.pattern(b) for b in range(4)]
+
+    lps = P.partition_general(g, world)
+    asms = []
+    for lp in lps:
+        a = Assembler(lp.mesh, blocked=True, n_owned_nodes=lp.n_owned)
+        a.set_params(prm)
+        a.set_constraints(gflags[lp.global_ids])
+        a.set_vectors(*vectors(lp.n_owned, f[lp.global_ids]))
+        a.ctx.state_set_device(a.solution.data_ptr(), a.old_solution.data_ptr(), a.old_old_solution.data_ptr())
+        a.ctx.halo_register(lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes)
+        asms.append(a)
+    rec = dim + 3
+    recv_all = [torch.zeros(int(lp.recv_ptr[-1]) * rec, dtype=torch.float64, device="cuda") for lp in lps]
+    for r, lp in enumerate(lps):
+        send_all = torch.empty(int(lp.send_ptr[-1]) * rec, dtype=torch.float64, device="cuda")
+        if send_all.numel():
+            asms[r].ctx.halo_pack_all(send_all.data_ptr())
+        torch.cuda.synchronize()
+        for k, s in enumerate(lp.peers):
+            ko = lps[s].peers.index(r)
+            o0, o1 = int(lp.send_ptr[k]) * rec, int(lp.send_ptr[k + 1]) * rec
+            q0 = int(lps[s].recv_ptr[ko]) * rec
+            recv_all[s][q0:q0 + (o1 - o0)] = send_all[o0:o1]
+    for s, lp in enumerate(lps):
+        if recv_all[s].numel():
+            asms[s].ctx.halo_unpack_all(recv_all[s].data_ptr())
+    torch.cuda.synchronize()
+    for lp, a in zip(lps, asms):
+        a.allocate_matrix()
+        a.ctx.assemble_device(False, [m.data_ptr() for m in a.system_pde_matrix], a.system_pde_residual.data_ptr(),
+                              a.system_total_residual.data_ptr())
+        a.synchronize()
+        gi, no = lp.global_ids, lp.n_owned
+        res = a.system_pde_residual.cpu().numpy()
+        gd_u = (gi[:no, None] * dim + np.arange(dim)[None, :]).ravel()
+        assert linf_scaled(res[:no * dim], ref_res[gd_u]) < 1e-12
+        assert linf_scaled(res[no * dim:], ref_res[N * dim + gi[:no]]) < 1e-12
+        for b in range(4):
+            rp, ci = a.ctx.pattern(b)
+            vals = a.system_pde_matrix[b].cpu().numpy()
+            grp, gci = ref_pat[b]
+            ncr = dim if b in (0, 1) else 1
+            ncc = dim if b in (0, 2) else 1
+            for lr in range(no * ncr):
+                node, c = divmod(lr, ncr)
+                grow = gi[node] * ncr + c
+                lcols = ci[rp[lr]:rp[lr + 1]]
+                gcols = gi[lcols // ncc] * ncc + lcols % ncc
+                want = dict(zip(gci[grp[grow]:grp[grow + 1]], ref_vals[b][grp[grow]:grp[grow + 1]]))
+                got = dict(zip(gcols, vals[rp[lr]:rp[lr + 1]]))
+                assert set(got) == set(want)
+                scale = max(1.0, max(abs(x) for x in want.values()))
+                assert max(abs(got[k] - want[k]) for k in want) < 1e-12 * scale

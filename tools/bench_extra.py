@@ -10,7 +10,8 @@
   pcie     what the host round trip of today's Trilinos solve would add to config 3: device->host copy of the
            CSR values and residuals over PCIe (never part of bench.py's value).
 
-  python tools/bench_extra.py config5 [--levels 7] [--out profiles/rNN/config5_miehe_amr.json]
+  python tools/bench_extra.py config5 [--levels 7] [--world 4] [--out profiles/rNN/config5_miehe_amr.json]
+  python -m torch.distributed.run --nproc-per-node 4 tools/bench_extra.py config5 --dist     (4 GPUs, RCCL ghost import)
   python tools/bench_extra.py pcie    [--n 216]    [--out profiles/rNN/pcie_216cube.json]
   python tools/bench_extra.py rank    [--n 216 --world 8]   one rank's share of the strong-scaling run, no exchange
 """
@@ -91,7 +92,63 @@ def config5(args):
             return 1e3 * float(np.median(ts))
 
         t_jac, t_res = timed(False), timed(True)
+        rank_rows = []
+        if args.world > 1:
+            # the same mesh on args.world ranks (general partition, cracks_amd/partition.py): every rank's share is
+            # timed on this GPU, one after the other, without the ghost import
+            from cracks_amd import partition as P
+
+            gflags = node_flags_from_dof_flags(lay, cu.flag, ch.flag)
+            fields_g = np.stack([sol[0::3], sol[1::3], sol[2::3], old[2::3], oldold[2::3]], axis=1)  # one-block layout
+            t0 = time.perf_counter()
+            lps = P.partition_general(mesh, args.world)
+            t_part = time.perf_counter() - t0
+            for r, lp in enumerate(lps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                a = Assembler(lp.mesh, blocked=False, n_owned_nodes=lp.n_owned)
+                a.allocate_matrix()
+                a.set_params(prm)
+                a.set_constraints(gflags[lp.global_ids])
+                torch.cuda.synchronize()
+                t_rctx = time.perf_counter() - t0
+                gd = (lp.global_ids[:lp.n_owned, None] * 3 + np.arange(3)[None, :]).ravel()  # one-block layout
+                a.set_vectors(sol[gd], old[gd], oldold[gd])
+                # ghost values: what the import would deliver (packed per peer, field-major), through the HIP unpack
+                a.ctx.state_set_device(a.solution.data_ptr(), a.old_solution.data_ptr(), a.old_old_solution.data_ptr())
+                a.ctx.halo_register(lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes)
+                loc = fields_g[lp.global_ids]
+                msgs = [loc[lp.recv_nodes[lp.recv_ptr[k]:lp.recv_ptr[k + 1]]].T.ravel() for k in range(len(lp.peers))]
+                if msgs:
+                    recv_all = torch.from_numpy(np.concatenate(msgs)).cuda()
+                    a.ctx.halo_unpack_all(recv_all.data_ptr())
+                ts = {}
+                for ro in (False, True):
+                    for _ in range(3):
+                        a.ctx.assemble_device(ro, [m.data_ptr() for m in a.system_pde_matrix] if not ro else [],
+                                              a.system_pde_residual.data_ptr(), a.system_total_residual.data_ptr())
+                    a.synchronize()
+                    tt = []
+                    for _ in range(20):
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        a.ctx.assemble_device(ro, [m.data_ptr() for m in a.system_pde_matrix] if not ro else [],
+                                              a.system_pde_residual.data_ptr(), a.system_total_residual.data_ptr())
+                        torch.cuda.synchronize()
+                        tt.append(time.perf_counter() - t)
+                    ts[ro] = 1e3 * float(np.median(tt))
+                rank_rows.append({"rank": r, "local_cells": int(lp.mesh.n_cells), "owned_cells": int(lp.cell_owned.sum()),
+                                  "owned_nodes": int(lp.n_owned), "ghost_nodes": int(lp.mesh.n_nodes - lp.n_owned),
+                                  "peers": lp.peers, "halo_bytes_sent": int(lp.send_ptr[-1]) * 5 * 8,
+                                  "context_rebuild_s": round(t_rctx, 4), "assemble_jacobian_ms": round(ts[False], 4),
+                                  "assemble_residual_ms": round(ts[True], 4)})
+                print(rank_rows[-1], flush=True)
+                del a
+            rank_rows = {"world": args.world, "partition_host_s": round(t_part, 3), "ranks": rank_rows,
+                         "max_assemble_jacobian_ms": max(x["assemble_jacobian_ms"] for x in rank_rows),
+                         "max_context_rebuild_s": max(x["context_rebuild_s"] for x in rank_rows)}
         rows.append({"mesh": step, "cells": int(mesh.n_cells), "nodes": int(mesh.n_nodes), "dofs": int(lay.n_dofs),
+                     **({"multi_rank": rank_rows} if rank_rows else {}),
                      "hanging_nodes": int(mesh.hn_nodes.size), "refine_host_s": round(t_refine, 3),
                      "context_rebuild_s": round(t_ctx, 4), "set_params_constraints_s": round(t_con, 4),
                      "assemble_jacobian_ms": round(t_jac, 4), "assemble_residual_ms": round(t_res, 4),
@@ -102,6 +159,103 @@ def config5(args):
                      "stress split active, single MI355X" % n, "rows": rows}
     if args.out:
         json.dump(out, open(os.path.join(ROOT, args.out), "w"), indent=1)
+
+
+def config5_dist(args):
+    """BASELINE config 'Miehe shear with predictor-corrector AMR, 4 x MI355X': the config5 mesh sequence on
+    WORLD_SIZE ranks (python -m torch.distributed.run --nproc-per-node 4 tools/bench_extra.py config5 --dist).
+    Per mesh: general partition (cracks_amd/partition.py), context rebuild, then timed reassemblies INCLUDING the
+    ghost import over RCCL; times are the max over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    from cracks_amd import mesh as M
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler, node_flags_from_dof_flags
+    from cracks_amd.capi import PfmParams
+    from cracks_amd.halo import HaloExchange
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rows = []
+    base = M.slit_mesh(args.levels)
+    n = 2 ** (args.levels + 1)
+    h = 1.0 / n
+    for step in range(args.meshes):
+        tip = 0.5 - 0.08 * step
+        cc = base.coords[base.cells].mean(axis=1)
+        mesh = M.refine_cells(base, (np.abs(cc[:, 1] - 0.5) < 6 * h) & (cc[:, 0] > tip - 4 * h))
+        lay = M.DofLayout(mesh.n_nodes, 2, blocked=False)
+        hfine, dt = 0.5 * h, 1.0e-4
+        prm = PfmParams(lambda_=121.15e3, mu=80.77e3, G_c=2.7, alpha_eps=2.0 * hfine * np.sqrt(2.0),
+                        constant_k=1.0e-10 * hfine, pressure=0.0, alpha_biot=0.0, gamma_penal=0.0, timestep=dt,
+                        time=5 * dt, old_timestep=dt, old_old_timestep=dt, decompose_stress_rhs=1.0,
+                        decompose_stress_matrix=1.0, timestep_number=5, outer_solver=0, use_old_timestep_pf=0,
+                        reserved=0)
+        ch = M.hanging_constraints(mesh, lay)
+        cu = M.update_constraints(mesh, lay, M.miehe_shear_dirichlet_dofs(mesh, lay))
+        rng = np.random.default_rng(1234 + step)
+        x, y = mesh.coords[:, 0], mesh.coords[:, 1]
+        u = np.stack([-5 * dt * y + 1e-6 * rng.standard_normal(x.size), 1e-6 * rng.standard_normal(x.size)], axis=1)
+        phi = np.clip(1.0 - np.exp(-np.abs(y - 0.5) / (4 * hfine)) * (x > tip), 0.0, 1.0)
+        sol = ch.distribute(lay.pack(u, phi))
+        old = ch.distribute(lay.pack(0.9 * u, np.clip(phi + 0.01 * rng.random(x.size), 0, 1)))
+        oldold = ch.distribute(lay.pack(0.8 * u, np.clip(phi + 0.02 * rng.random(x.size), 0, 1)))
+        gflags = node_flags_from_dof_flags(lay, cu.flag, ch.flag)
+
+        t0 = time.perf_counter()
+        lp = P.partition_general(mesh, world)[rank]
+        t_part = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        halo = HaloExchange(2, lp.peers, lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes, dev) if world > 1 else None
+        asm = Assembler(lp.mesh, blocked=False, device=local_rank, n_owned_nodes=lp.n_owned, halo=halo)
+        asm.allocate_matrix()
+        asm.set_params(prm)
+        asm.set_constraints(gflags[lp.global_ids])
+        torch.cuda.synchronize(dev)
+        t_ctx = time.perf_counter() - t0
+        gd = (lp.global_ids[:lp.n_owned, None] * 3 + np.arange(3)[None, :]).ravel()
+        asm.set_vectors(sol[gd], old[gd], oldold[gd])
+
+        def fence():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        out = {}
+        for ro in (False, True):
+            for _ in range(3):
+                asm.assemble_system(ro)
+            asm.synchronize()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                asm.assemble_system(ro)
+            fence()
+            out[ro] = (time.perf_counter() - t0) / args.steps
+        asm.synchronize()
+        tt = torch.tensor([out[False], out[True], t_ctx, t_part], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            rows.append({"mesh": step, "cells": int(mesh.n_cells), "dofs": int(lay.n_dofs), "hanging_nodes": int(mesh.hn_nodes.size),
+                         "n_gpus": world, "reassemble_jacobian_ms": 1e3 * float(tt[0]), "reassemble_residual_ms": 1e3 * float(tt[1]),
+                         "context_rebuild_s": float(tt[2]), "partition_host_s": float(tt[3]),
+                         "dofs_per_s_jacobian": lay.n_dofs / float(tt[0])})
+            print(json.dumps(rows[-1]), flush=True)
+        del asm
+    if rank == 0 and args.out:
+        json.dump({"config": "Miehe-shear-like AMR sequence on %d GPU(s), ghost import over RCCL included" % world, "rows": rows},
+                  open(os.path.join(ROOT, args.out), "w"), indent=1)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def pcie(args):
@@ -186,5 +340,10 @@ if __name__ == "__main__":
     ap.add_argument("--meshes", type=int, default=5)
     ap.add_argument("--n", type=int, default=216)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--dist", action="store_true", help="config5: one process per GPU under torch.distributed.run")
+    ap.add_argument("--steps", type=int, default=20)
     a = ap.parse_args()
-    {"config5": config5, "pcie": pcie, "rank": rank_share}[a.what](a)
+    if a.what == "config5" and (a.dist or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        config5_dist(a)
+    else:
+        {"config5": config5, "pcie": pcie, "rank": rank_share}[a.what](a)
