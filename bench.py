@@ -157,11 +157,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dim", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="cells per direction (default 216 in 3-D, 1000 in 2-D)")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=0,
+                    help="cells per direction (default 216 in 3-D, 1000 in 2-D); --cells under torch.distributed.run, whose parser trips over --n")
     ap.add_argument("--residual-only", action="store_true")
     ap.add_argument("--path", choices=["auto", "general", "cart", "overlay"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare a small instance with the oracle first")
+    ap.add_argument("--checksum", action="store_true",
+                    help="add partition-independent sums of the assembled values (outside the timed region): the "
+                         "N-rank run must reproduce the 1-rank numbers up to round-off")
     args = ap.parse_args()
 
     import torch
@@ -177,11 +181,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # PFM_BENCH_SMOKE_GLOO=1: all ranks on cuda:0, ghost import staged through the host over gloo -- exercises the
+    # multi-process flow on a single-GPU box; never a measurement
+    smoke_gloo = os.environ.get("PFM_BENCH_SMOKE_GLOO") == "1"
+    if smoke_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if smoke_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     dim = args.dim
     n = args.n or (216 if dim == 3 else 1000)
@@ -237,10 +249,23 @@ def main():
     k_ms, k_n = asm.ctx.kernel_time_ms()
     asm.ctx.timing_enable(False)
 
-    tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, k_ms = float(tt[0]), float(tt[1])
+    checksum = None
+    if args.checksum:
+        # sums over the owned rows: every global row is owned by exactly one rank
+        parts = [asm.system_pde_residual.sum(), asm.system_pde_residual.abs().sum()]
+        if residual_only:
+            parts += [asm.system_total_residual.sum(), asm.system_total_residual.abs().sum()]
+        else:
+            for m in asm.system_pde_matrix:
+                parts += [m.sum(), m.abs().sum()]
+        cs = torch.stack(parts).to("cpu" if smoke_gloo else dev)
+        if world > 1:
+            dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        checksum = [float(x) for x in cs.cpu()]
     n_nodes_global = int(np.prod([k + 1 for k in ncell]))
     n_cells_global = int(np.prod(ncell))
     n_dofs = n_nodes_global * (dim + 1)
@@ -261,7 +286,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (uniform hex mesh on [-10,10]^d, interpolated Sneddon crack + seeded perturbation)",
+            "data": "synthetic (uniform hex mesh on [-10,10]^d, interpolated Sneddon crack + seeded perturbation)" +
+                    (" -- SMOKE RUN: all ranks on one GPU, gloo, not a measurement" if smoke_gloo else ""),
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
                                    f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (%d nnz/row-node-comp)' % (4 * 3 ** dim)}",
                        "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
@@ -277,6 +303,8 @@ def main():
                          "kernel_ms": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
         }
+        if checksum is not None:
+            out["checksum"] = checksum
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, residual_only)
         print(json.dumps(out), flush=True)

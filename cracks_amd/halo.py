@@ -40,6 +40,9 @@ class HaloExchange:
         self.send_bufs = [self.send_all[int(so[k]):int(so[k + 1])] for k in range(len(self.peers))]
         self.recv_bufs = [self.recv_all[int(ro[k]):int(ro[k + 1])] for k in range(len(self.peers))]
         self._registered = None
+        # gloo moves host memory only: device buffers are staged through the host (smoke tests of the multi-process
+        # flow on a box without one GPU per rank; the product path is backend "nccl" = RCCL, device to device)
+        self._stage_host = self.send_all.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     @property
     def bytes_per_exchange(self) -> int:
@@ -51,6 +54,19 @@ class HaloExchange:
 
     def _post(self):
         dist = self.dist
+        if self._stage_host:
+            send_h, recv_h = self.send_all.cpu(), self.torch.empty(self.recv_all.shape, dtype=self.torch.float64)
+            so = (self.send_ptr - self.send_ptr[0]) * self.rec
+            ro = (self.recv_ptr - self.recv_ptr[0]) * self.rec
+            ops = [dist.P2POp(dist.irecv, recv_h[int(ro[k]):int(ro[k + 1])], peer, group=self.group)
+                   for k, peer in enumerate(self.peers) if ro[k + 1] > ro[k]]
+            ops += [dist.P2POp(dist.isend, send_h[int(so[k]):int(so[k + 1])], peer, group=self.group)
+                    for k, peer in enumerate(self.peers) if so[k + 1] > so[k]]
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            self.recv_all.copy_(recv_h)
+            return
         ops = []
         for k, peer in enumerate(self.peers):
             if self.recv_bufs[k].numel():

@@ -232,3 +232,34 @@ def test_general_partition_owned_rows_match_single_rank(kind, world):
                 assert set(got) == set(want)
                 scale = max(1.0, max(abs(x) for x in want.values()))
                 assert max(abs(got[k] - want[k]) for k in want) < 1e-12 * scale
+
+
+@pytest.mark.parametrize("world,cells,extra", [(2, 40, []), (8, 36, []), (4, 300, ["--dim", "2", "--residual-only"])])
+def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with all
+    ranks on this GPU and the ghost import over gloo (PFM_BENCH_SMOKE_GLOO=1): partition-independent sums of every
+    matrix block and residual must agree with the single-process run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--cells", str(cells), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--checksum"] + extra
+    env = dict(os.environ, PFM_BENCH_SMOKE_GLOO="1")
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+
+    one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
+    port = 29600 + world
+    many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world)] + common)
+    assert many["n_gpus"] == world and one["n_gpus"] == 1
+    a, b = np.array(one["checksum"]), np.array(many["checksum"])
+    assert a.shape == b.shape and np.abs(a).max() > 0
+    scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)  # each pair is (sum, sum of absolute values)
+    assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
