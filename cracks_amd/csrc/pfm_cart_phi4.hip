@@ -75,21 +75,27 @@ namespace pfm
                    : "v"(byte_off), "s"(base), "s"(l)
                    : "memory");
     }
-    __device__ __forceinline__ void dy_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double nz0,
-                                                double nz1, double ihy, double (&Dy)[2])
+    // the 8 vertex values of one nodal field of a cell, index = x + 2 y + 4 z: read from the nodal ring ONCE per
+    // cell and role (the compiler cannot keep LDS values across the LDS-side adds of the pushes by itself)
+    __device__ __forceinline__ void load_cell_field(const double *__restrict__ lo, const double *__restrict__ hi, double (&a)[8])
     {
-      Dy[0] = (nz0 * (lo[PH] - lo[0]) + nz1 * (hi[PH] - hi[0])) * ihy;
-      Dy[1] = (nz0 * (lo[PH + 1] - lo[1]) + nz1 * (hi[PH + 1] - hi[1])) * ihy;
+      a[0] = lo[0], a[1] = lo[1], a[2] = lo[PH], a[3] = lo[PH + 1];
+      a[4] = hi[0], a[5] = hi[1], a[6] = hi[PH], a[7] = hi[PH + 1];
+    }
+    __device__ __forceinline__ void dy_of_field(const double (&a)[8], double nz0, double nz1, double ihy, double (&Dy)[2])
+    {
+      Dy[0] = (nz0 * (a[2] - a[0]) + nz1 * (a[6] - a[4])) * ihy;
+      Dy[1] = (nz0 * (a[3] - a[1]) + nz1 * (a[7] - a[5])) * ihy;
     }
 
     // values of one nodal field at the (qy,qz) line of a cell: L = value at x-vertex 0/1, Dy/Dz = d/dy, d/dz there
     template <bool DY, bool DZ>
-    __device__ __forceinline__ void line_of_field(const double *__restrict__ lo, const double *__restrict__ hi, double ny0,
+    __device__ __forceinline__ void line_of_field(const double (&a)[8], double ny0,
                                                   double ny1, double nz0, double nz1, double ihy, double ihz, double (&L)[2],
                                                   double (&Dy)[2], double (&Dz)[2])
     {
-      const double a00 = lo[0], a10 = lo[1], a01 = lo[PH], a11 = lo[PH + 1];
-      const double b00 = hi[0], b10 = hi[1], b01 = hi[PH], b11 = hi[PH + 1];
+      const double a00 = a[0], a10 = a[1], a01 = a[2], a11 = a[3];
+      const double b00 = a[4], b10 = a[5], b01 = a[6], b11 = a[7];
       const double l0 = ny0 * a00 + ny1 * a01, l1 = ny0 * a10 + ny1 * a11;
       const double h0 = ny0 * b00 + ny1 * b01, h1 = ny0 * b10 + ny1 * b11;
       L[0] = nz0 * l0 + nz1 * h0;
@@ -121,6 +127,10 @@ namespace pfm
                                             bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
     {
       const double c_muh = S.c_muh, c_la = S.c_la, cdiag = S.cdiag;
+      double V[4][8]; // u_x u_y u_z phi at the cell's vertices
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        load_cell_field(Ulo + f * NPH, Uhi + f * NPH, V[f]);
 #pragma unroll 1
       for (int qz = 0; qz < 3; ++qz)
         {
@@ -138,7 +148,7 @@ namespace pfm
               static_for<3>([&](auto F) __attribute__((always_inline)) {
                 constexpr int f = decltype(F)::value;
                 if constexpr ((f == D) || (D == 1) || (f == 1))
-                  dy_of_field(Ulo + f * NPH, Uhi + f * NPH, nz0, nz1, S.ih[1], Dy[f]);
+                  dy_of_field(V[f], nz0, nz1, S.ih[1], Dy[f]);
               });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
@@ -150,14 +160,12 @@ namespace pfm
                     constexpr int f = decltype(F)::value;
                     constexpr bool need_dz = (f == D) || (D == 2) || (f == 2);
                     double dummy_dy[2];
-                    line_of_field<false, need_dz>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f],
-                                                  dummy_dy, Dz[f]);
+                    line_of_field<false, need_dz>(V[f], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], dummy_dy, Dz[f]);
                     __builtin_amdgcn_sched_barrier(0);
                   });
                   {
                     double dummy[2];
-                    line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
-                                                dummy);
+                    line_of_field<false, false>(V[3], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy, dummy);
                   }
                   double Dx[3];
 #pragma unroll
@@ -264,6 +272,10 @@ namespace pfm
 #pragma unroll
       for (int m = 0; m < 27; ++m)
         M[m] = 0.0;
+      double V[4][8]; // u_x u_y u_z phi at the cell's vertices
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        load_cell_field(Ulo + f * NPH, Uhi + f * NPH, V[f]);
 #pragma unroll 1
       for (int qz = 0; qz < 3; ++qz)
         {
@@ -277,7 +289,7 @@ namespace pfm
               double Dy[3][2]; // d/dy depends on the z-level only
               static_for<3>([&](auto F) __attribute__((always_inline)) {
                 constexpr int f = decltype(F)::value;
-                dy_of_field(Ulo + f * NPH, Uhi + f * NPH, nz0, nz1, S.ih[1], Dy[f]);
+                dy_of_field(V[f], nz0, nz1, S.ih[1], Dy[f]);
               });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
@@ -287,16 +299,17 @@ namespace pfm
                   double L[5][2], Dz[3][2], dummy[2];
                   static_for<3>([&](auto F) __attribute__((always_inline)) {
                     constexpr int f = decltype(F)::value;
-                    line_of_field<false, true>(Ulo + f * NPH, Uhi + f * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], dummy,
-                                               Dz[f]);
+                    line_of_field<false, true>(V[f], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], dummy, Dz[f]);
                     __builtin_amdgcn_sched_barrier(0);
                   });
-                  line_of_field<false, false>(Ulo + 3 * NPH, Uhi + 3 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy,
-                                              dummy);
+                  line_of_field<false, false>(V[3], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy, dummy);
                   L[4][0] = L[4][1] = 0.0;
                   if (use_pen) // phi_old enters only through the penalisation term (gamma != 0: monolithic runs)
-                    line_of_field<false, false>(Ulo + 4 * NPH, Uhi + 4 * NPH, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4],
-                                                dummy, dummy);
+                    {
+                      double Vo[8];
+                      load_cell_field(Ulo + 4 * NPH, Uhi + 4 * NPH, Vo);
+                      line_of_field<false, false>(Vo, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy, dummy);
+                    }
                   double Dx[3];
 #pragma unroll
                   for (int f = 0; f < 3; ++f)
