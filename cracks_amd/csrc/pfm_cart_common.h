@@ -87,6 +87,7 @@ namespace pfm
     {
       double lam, mu, kappa, eps, Gc, p, aB1, gamma_fac, tfac;
       double ih[3], vol;
+      double hz;       // h_z (the phase-field rows interpolate along z first)
       double cA[3][3]; // cA[c][k] = (k == c ? lam + 2 mu : mu) / h_k^2
       double cT[3];    // 1 / (h_lo h_hi) for the pairs (0,1), (0,2), (1,2)
       int monolithic, use_old;
@@ -175,6 +176,8 @@ namespace pfm
           diam2 += cv.h[d] * cv.h[d];
           s.ih[d] = 1.0 / cv.h[d];
           s.vol *= cv.h[d];
+          if (d == 2)
+            s.hz = cv.h[d];
         }
       s.gamma_fac = gamma / prm.timestep * 1.0 / diam2;
       s.tfac = (prm.time - (prm.time - prm.old_timestep - prm.old_old_timestep)) /

@@ -75,9 +75,44 @@ namespace pfm
                    : "v"(byte_off), "s"(base), "s"(l)
                    : "memory");
     }
-    // the 8 vertex values of one nodal field of a cell, index = x + 2 y + 4 z: read from the nodal ring ONCE per
-    // cell and role (the compiler cannot keep LDS values across the LDS-side adds of the pushes by itself)
-    __device__ __forceinline__ void load_cell_field(const double *__restrict__ lo, const double *__restrict__ hi, double (&a)[8])
+    // The 8 vertex values of one nodal field of a cell are read from the nodal ring ONCE per cell and role (the
+    // compiler cannot keep LDS values across the LDS-side adds of the pushes by itself), as the 4 values of the lower
+    // z-face a[0..3] (index x + 2 y) and the z-derivative (upper - lower) / h_z at the same 4 positions a[4..7].
+    // The trilinear interpolation then runs along z first: per z-level 4 FMAs, per (qy,qz) line 4 + 4 operations.
+    __device__ __forceinline__ void load_cell_field(const double *__restrict__ lo, const double *__restrict__ hi, double ihz,
+                                                    double (&a)[8])
+    {
+      a[0] = lo[0], a[1] = lo[1], a[2] = lo[PH], a[3] = lo[PH + 1];
+      a[4] = (hi[0] - a[0]) * ihz, a[5] = (hi[1] - a[1]) * ihz, a[6] = (hi[PH] - a[2]) * ihz, a[7] = (hi[PH + 1] - a[3]) * ihz;
+    }
+    // field at the 4 (x,y) vertices of z-level qz: zq = n_1(q_z) h_z
+    __device__ __forceinline__ void zlevel_of_field(const double (&a)[8], double zq, double (&Z)[4])
+    {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        Z[i] = fma(zq, a[4 + i], a[i]);
+    }
+    __device__ __forceinline__ void dy_of_level(const double (&Z)[4], double ihy, double (&Dy)[2])
+    {
+      Dy[0] = (Z[2] - Z[0]) * ihy;
+      Dy[1] = (Z[3] - Z[1]) * ihy;
+    }
+    // values of one nodal field at the (qy,qz) line of a cell: L = value at x-vertex 0/1, Dz = d/dz there
+    template <bool DZ>
+    __device__ __forceinline__ void line_of_level(const double (&Z)[4], const double (&a)[8], double ny0, double ny1, double (&L)[2],
+                                                  double (&Dz)[2])
+    {
+      L[0] = ny0 * Z[0] + ny1 * Z[2];
+      L[1] = ny0 * Z[1] + ny1 * Z[3];
+      if constexpr (DZ)
+        {
+          Dz[0] = ny0 * a[4] + ny1 * a[6];
+          Dz[1] = ny0 * a[5] + ny1 * a[7];
+        }
+    }
+
+    // ---- helpers of the (phi,phi) role: the 8 raw vertex values, index x + 2 y + 4 z
+    __device__ __forceinline__ void load_cell_field_raw(const double *__restrict__ lo, const double *__restrict__ hi, double (&a)[8])
     {
       a[0] = lo[0], a[1] = lo[1], a[2] = lo[PH], a[3] = lo[PH + 1];
       a[4] = hi[0], a[5] = hi[1], a[6] = hi[PH], a[7] = hi[PH + 1];
@@ -88,7 +123,7 @@ namespace pfm
       Dy[1] = (nz0 * (a[3] - a[1]) + nz1 * (a[7] - a[5])) * ihy;
     }
 
-    // values of one nodal field at the (qy,qz) line of a cell: L = value at x-vertex 0/1, Dy/Dz = d/dy, d/dz there
+    // (phi,phi) role: raw vertex values, y-z interpolation per line (fewer live registers next to the 27 moments)
     template <bool DY, bool DZ>
     __device__ __forceinline__ void line_of_field(const double (&a)[8], double ny0,
                                                   double ny1, double nz0, double nz1, double ihy, double ihz, double (&L)[2],
@@ -130,7 +165,7 @@ namespace pfm
       double V[4][8]; // u_x u_y u_z phi at the cell's vertices
 #pragma unroll
       for (int f = 0; f < 4; ++f)
-        load_cell_field(Ulo + f * NPH, Uhi + f * NPH, V[f]);
+        load_cell_field(Ulo + f * NPH, Uhi + f * NPH, S.ih[2], V[f]);
 #pragma unroll 1
       for (int qz = 0; qz < 3; ++qz)
         {
@@ -144,11 +179,13 @@ namespace pfm
           const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
           if (cell_ok)
             {
-              double Dy[3][2]; // d/dy depends on the z-level only
-              static_for<3>([&](auto F) __attribute__((always_inline)) {
+              double Z[4][4], Dy[3][2]; // z-level values; d/dy depends on the z-level only
+              const double zq = nz1 * S.hz;
+              static_for<4>([&](auto F) __attribute__((always_inline)) {
                 constexpr int f = decltype(F)::value;
-                if constexpr ((f == D) || (D == 1) || (f == 1))
-                  dy_of_field(V[f], nz0, nz1, S.ih[1], Dy[f]);
+                zlevel_of_field(V[f], zq, Z[f]);
+                if constexpr (f < 3 && ((f == D) || (D == 1) || (f == 1)))
+                  dy_of_level(Z[f], S.ih[1], Dy[f]);
               });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
@@ -159,13 +196,11 @@ namespace pfm
                   static_for<3>([&](auto F) __attribute__((always_inline)) {
                     constexpr int f = decltype(F)::value;
                     constexpr bool need_dz = (f == D) || (D == 2) || (f == 2);
-                    double dummy_dy[2];
-                    line_of_field<false, need_dz>(V[f], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[f], dummy_dy, Dz[f]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    line_of_level<need_dz>(Z[f], V[f], ny0, ny1, L[f], Dz[f]);
                   });
                   {
                     double dummy[2];
-                    line_of_field<false, false>(V[3], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy, dummy);
+                    line_of_level<false>(Z[3], V[3], ny0, ny1, L[3], dummy);
                   }
                   double Dx[3];
 #pragma unroll
@@ -275,7 +310,7 @@ namespace pfm
       double V[4][8]; // u_x u_y u_z phi at the cell's vertices
 #pragma unroll
       for (int f = 0; f < 4; ++f)
-        load_cell_field(Ulo + f * NPH, Uhi + f * NPH, V[f]);
+        load_cell_field_raw(Ulo + f * NPH, Uhi + f * NPH, V[f]);
 #pragma unroll 1
       for (int qz = 0; qz < 3; ++qz)
         {
@@ -307,7 +342,7 @@ namespace pfm
                   if (use_pen) // phi_old enters only through the penalisation term (gamma != 0: monolithic runs)
                     {
                       double Vo[8];
-                      load_cell_field(Ulo + 4 * NPH, Uhi + 4 * NPH, Vo);
+                      load_cell_field_raw(Ulo + 4 * NPH, Uhi + 4 * NPH, Vo);
                       line_of_field<false, false>(Vo, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy, dummy);
                     }
                   double Dx[3];
