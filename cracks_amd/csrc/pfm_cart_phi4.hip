@@ -179,13 +179,16 @@ namespace pfm
           const double nz0 = c_g1.n[0][qz], nz1 = c_g1.n[1][qz];
           if (cell_ok)
             {
-              double Z[4][4], Dy[3][2]; // z-level values; d/dy depends on the z-level only
+              double Z[4][4], Dy[3][2], dDy[3]; // z-level values; d/dy depends on the z-level only
               const double zq = nz1 * S.hz;
               static_for<4>([&](auto F) __attribute__((always_inline)) {
                 constexpr int f = decltype(F)::value;
                 zlevel_of_field(V[f], zq, Z[f]);
                 if constexpr (f < 3 && ((f == D) || (D == 1) || (f == 1)))
-                  dy_of_level(Z[f], S.ih[1], Dy[f]);
+                  {
+                    dy_of_level(Z[f], S.ih[1], Dy[f]);
+                    dDy[f] = Dy[f][1] - Dy[f][0];
+                  }
               });
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
@@ -206,12 +209,18 @@ namespace pfm
 #pragma unroll
                   for (int f = 0; f < 3; ++f)
                     Dx[f] = (L[f][1] - L[f][0]) * S.ih[0];
+                  // along x everything is linear: value(q_x) = v0 + n_1(q_x) (v1 - v0), one FMA per q-point
+                  const double dpf = L[3][1] - L[3][0];
+                  double dDz[3];
+#pragma unroll
+                  for (int f = 0; f < 3; ++f)
+                    dDz[f] = Dz[f][1] - Dz[f][0]; // unused components are dropped by the compiler
                   double Xx[2] = {0.0, 0.0}, Xy[3] = {0.0, 0.0, 0.0}, Xz[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                   for (int qx = 0; qx < 3; ++qx)
                     {
                       const double nx0 = c_g1.n[0][qx], nx1 = c_g1.n[1][qx];
-                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
+                      double pf = fma(nx1, dpf, L[3][0]);
                       if (S.monolithic)
                         pf = fmax(0.0, pf); // cracks.cc:2251-2256
                       const double wp = (wyz * c_g1.w[qx]) * pf;
@@ -221,9 +230,9 @@ namespace pfm
                         if constexpr (k == 0)
                           return Dx[c];
                         else if constexpr (k == 1)
-                          return nx0 * Dy[c][0] + nx1 * Dy[c][1];
+                          return fma(nx1, dDy[c], Dy[c][0]);
                         else
-                          return nx0 * Dz[c][0] + nx1 * Dz[c][1];
+                          return fma(nx1, dDz[c], Dz[c][0]);
                       };
                       using I0 = std::integral_constant<int, 0>;
                       using I1 = std::integral_constant<int, 1>;
