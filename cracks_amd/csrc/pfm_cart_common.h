@@ -90,6 +90,7 @@ namespace pfm
       double hz;       // h_z (the phase-field rows interpolate along z first)
       double cA[3][3]; // cA[c][k] = (k == c ? lam + 2 mu : mu) / h_k^2
       double cT[3];    // 1 / (h_lo h_hi) for the pairs (0,1), (0,2), (1,2)
+      double cTl[3], cTm[3]; // cT * lambda, cT * mu: one FMA per table entry in the (u,u) node phase
       int monolithic, use_old;
       // uniform constants of the phase-field rows, precomputed on the host so that they arrive in scalar registers
       double c_muh, c_la, cdiag;       // 2(1-kappa) mu, 2(1-kappa) lambda, -2(alpha_B-1) p
@@ -188,6 +189,11 @@ namespace pfm
       s.cT[0] = s.ih[0] * s.ih[1];
       s.cT[1] = s.ih[0] * s.ih[2];
       s.cT[2] = s.ih[1] * s.ih[2];
+      for (int q = 0; q < 3; ++q)
+        {
+          s.cTl[q] = s.cT[q] * prm.lambda;
+          s.cTm[q] = s.cT[q] * prm.mu;
+        }
       s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
       s.use_old = prm.use_old_timestep_pf;
       s.c_muh = 2.0 * (1.0 - s.kappa) * s.mu;

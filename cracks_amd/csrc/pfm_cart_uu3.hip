@@ -39,21 +39,22 @@ namespace pfm
     __host__ __device__ constexpr int idxT3(int p, int al, int be, int g) { return 27 + p * 12 + al * 6 + be * 3 + g; }
     __host__ __device__ constexpr int sg3(int bit) { return bit ? 1 : -1; }
 
+    // r += contribution of one cell to entry (row comp C, col comp D) of vertex pair (a, b): every table entry enters
+    // through ONE FMA with a host-precombined constant (sign folded in at compile time)
     template <int C, int D, int AX, int AY, int AZ, int BX, int BY, int BZ>
-    __device__ __forceinline__ double kuu3(const double *__restrict__ lds, const MatScal &S)
+    __device__ __forceinline__ void kuu3(const double *__restrict__ lds, const MatScal &S, double &r)
     {
       constexpr int a[3] = {AX, AY, AZ}, b[3] = {BX, BY, BZ};
       constexpr int g[3] = {AX + BX, AY + BY, AZ + BZ};
       if constexpr (C == D)
         {
-          double r = 0.0;
 #pragma unroll
           for (int k = 0; k < 3; ++k)
             {
               const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-              r += (double)(sg3(a[k]) * sg3(b[k])) * S.cA[C][k] * lds[idxA3(k, g[i], g[j]) * CS3];
+              const double v = lds[idxA3(k, g[i], g[j]) * CS3];
+              r = fma((sg3(a[k]) * sg3(b[k]) > 0) ? S.cA[C][k] : -S.cA[C][k], v, r);
             }
-          return r;
         }
       else
         {
@@ -62,7 +63,8 @@ namespace pfm
           constexpr int al2 = (C < D) ? a[lo] : b[lo], be2 = (C < D) ? b[hi] : a[hi]; // G^{DC}
           const double t1 = lds[idxT3(p, al1, be1, g[e]) * CS3];
           const double t2 = lds[idxT3(p, al2, be2, g[e]) * CS3];
-          return S.cT[p] * (S.lam * (double)(sg3(a[C]) * sg3(b[D])) * t1 + S.mu * (double)(sg3(a[D]) * sg3(b[C])) * t2);
+          r = fma((sg3(a[C]) * sg3(b[D]) > 0) ? S.cTl[p] : -S.cTl[p], t1, r);
+          r = fma((sg3(a[D]) * sg3(b[C]) > 0) ? S.cTm[p] : -S.cTm[p], t2, r);
         }
     }
 
@@ -76,7 +78,7 @@ namespace pfm
         constexpr int ex = decltype(EX)::value, ey = decltype(EY)::value;
         constexpr int ax = -ex, ay = -ey, bx = ax + OX, by = ay + OY;
         if constexpr (bx >= 0 && bx <= 1 && by >= 0 && by <= 1)
-          r += kuu3<C, D, ax, ay, 1, bx, by, 1 + OZ>(lane_base + (ey * C3X + ex), S);
+          kuu3<C, D, ax, ay, 1, bx, by, 1 + OZ>(lane_base + (ey * C3X + ex), S, r);
       };
       using M1 = std::integral_constant<int, -1>;
       using Z0 = std::integral_constant<int, 0>;
