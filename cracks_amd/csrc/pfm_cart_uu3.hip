@@ -219,8 +219,7 @@ namespace pfm
       __shared__ int s_node[NH3];
       __shared__ unsigned char s_flag[NH3];
       __shared__ long long s_rowbase[NN3];
-      __shared__ int s_deg[NN3];
-      __shared__ unsigned char s_inv[NN3 * 27];
+      __shared__ unsigned s_mask[NN3]; // neighbour mask of the row (bit o: lattice offset o exists)
       __shared__ int s_info[2];
       static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
 
@@ -264,22 +263,16 @@ namespace pfm
           const int nl = t - 256, li = nl % T3X, lj = nl / T3X;
           const int gi = i0 + li, gj = j0 + lj;
           long long base = -1;
-          int deg = 0;
-          bool regular = false;
+          unsigned mask = 0u;
           if (gi <= cv.o1[0] && gj <= cv.o1[1])
             {
               const int r = cart_local_id(cv, gi, gj, k);
-              const long long off = v.nadj_ptr[r];
-              deg = (int)(v.nadj_ptr[r + 1] - off);
-              base = (long long)NCOL * NCOL * off;
-              regular = cv.row_regular[r] != 0;
-              // slot maps are only read by the copy-out of irregular tiles; a regular row's map is the identity
-              for (int s = 0; s < 27; ++s)
-                s_inv[nl * 27 + s] = regular ? (unsigned char)s : cv.inv27[(long long)r * 27 + s];
+              base = (long long)NCOL * NCOL * v.nadj_ptr[r];
+              mask = cv.nbr_mask[r];
             }
           s_rowbase[nl] = base;
-          s_deg[nl] = deg;
-          if (!regular)
+          s_mask[nl] = mask;
+          if (mask != 0x7ffffffu) // fewer than 27 neighbours, or not an owned node of this tile
             atomicAdd(&s_info[1], 1);
         }
       __syncthreads();
@@ -456,18 +449,20 @@ namespace pfm
             }
           else
             {
+              // rows at the faces of the box / partial tiles: thread <-> (row, lattice offset o, column component);
+              // rows are in lattice order, so the CSR slot of offset o is its rank among the offsets that exist
               constexpr int rowlen = 27 * NCOL;
               for (int f = t; f < NN3 * rowlen; f += NT3)
                 {
                   const int nl = f / rowlen, e = f - nl * rowlen;
-                  const int s = e / NCOL, d = e - s * NCOL;
+                  const int o = e / NCOL, d = e - o * NCOL;
                   const long long base = s_rowbase[nl];
-                  const int deg = s_deg[nl];
-                  if (base < 0 || s >= deg)
+                  const unsigned mask = s_mask[nl];
+                  if (base < 0 || !((mask >> o) & 1u))
                     continue;
-                  const int o = s_inv[nl * 27 + s];
+                  const int sl = __popc(mask & ((1u << o) - 1u)), deg = __popc(mask);
                   const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
-                  vals[base + (long long)c * NCOL * deg + s * NCOL + d] = val;
+                  vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
                 }
             }
           lds_barrier();

@@ -202,15 +202,10 @@ namespace
         if (found != (int)(re - rb))
           return false;
       }
-    std::vector<uint8_t> regular((size_t)NO, 0);
     std::vector<uint32_t> nbr_mask((size_t)NO, 0); // bit o: the neighbour at lattice offset o exists in the row
     for (int32_t n = 0; n < NO; ++n)
       {
         const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
-        bool reg = deg == no;
-        for (int o = 0; reg && o < no; ++o)
-          reg = inv[(size_t)n * no + o] == (uint8_t)o;
-        regular[n] = reg ? 1 : 0;
         for (int sl = 0; sl < deg; ++sl)
           {
             // rows are in lattice order (pfm_ctx_create): slot sl = rank of its offset among the existing ones
@@ -230,8 +225,6 @@ namespace
         cv.h[d] = h[d];
       }
     cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
-    cv.inv27 = dev_upload(c, inv.data(), inv.size());
-    cv.row_regular = dev_upload(c, regular.data(), regular.size());
     cv.nbr_mask = dev_upload(c, nbr_mask.data(), nbr_mask.size());
     cv.owned_lex = 1;
     {

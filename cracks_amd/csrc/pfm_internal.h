@@ -41,8 +41,6 @@ namespace pfm
     int o0[3], o1[3];
     double h[3];
     const int32_t *local_of_box; // [NX*NY*NZ] lattice index -> local node id
-    const uint8_t *inv27;        // [n_owned][3^dim] CSR neighbour slot -> lattice offset index, 0xff = none
-    const uint8_t *row_regular;  // [n_owned] 1: the row has all 3^dim neighbours and slot s is lattice offset s
     const uint32_t *nbr_mask;    // [n_owned] bit o: lattice offset o exists in the row; rows are in lattice order, so
                                  // the CSR slot of offset o is popcount(mask & ((1 << o) - 1))
     int owned_lex;               // 1: owned node (i,j,k) has local id (i-o0x) + OWX*((j-o0y) + OWY*(k-o0z))
