@@ -220,7 +220,7 @@ namespace pfm
       __shared__ unsigned char s_flag[NH3];
       __shared__ long long s_rowbase[NN3];
       __shared__ unsigned s_mask[NN3]; // neighbour mask of the row (bit o: lattice offset o exists)
-      __shared__ int s_info[2];
+      __shared__ int s_any[4]; // waves 0..2: some node of the halo carries a displacement flag; [3]: some row is not full
       static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
 
       const int t = threadIdx.x;
@@ -232,10 +232,7 @@ namespace pfm
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
 
-      // ---- phase 0: nodal halo + CSR row info
-      if (t < 2)
-        s_info[t] = 0;
-      __syncthreads();
+      // ---- phase 0: nodal halo + CSR row info (flags of the tile are collected per wave: no atomics, no init barrier)
       stamp(0);
       if (t < NH3)
         {
@@ -255,8 +252,9 @@ namespace pfm
           s_po[t] = a;
           s_poo[t] = b;
           s_flag[t] = f;
-          if (f & 7u)
-            atomicOr(&s_info[0], 1);
+          const unsigned long long any = __ballot((f & 7u) != 0);
+          if ((t & 63) == 0)
+            s_any[t >> 6] = any != 0; // waves 0..2
         }
       else if (t >= 256 && t < 256 + NN3)
         {
@@ -272,8 +270,9 @@ namespace pfm
             }
           s_rowbase[nl] = base;
           s_mask[nl] = mask;
-          if (mask != 0x7ffffffu) // fewer than 27 neighbours, or not an owned node of this tile
-            atomicAdd(&s_info[1], 1);
+          const unsigned long long irr = __ballot(mask != 0x7ffffffu); // fewer than 27 neighbours, or not an owned node
+          if (nl == 0)
+            s_any[3] = irr != 0;
         }
       __syncthreads();
       stamp(0);
@@ -408,8 +407,8 @@ namespace pfm
       const int ti = nl_lane % T3X, tj = nl_lane / T3X;
       const int hc = (ti + 1) + H3X * ((tj + 1) + H3Y * 1);
       const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
-      const bool masked = s_info[0] != 0;
-      const bool regular_tile = (NCOL == 3) && s_info[1] == 0;
+      const bool masked = (s_any[0] | s_any[1] | s_any[2]) != 0;
+      const bool regular_tile = (NCOL == 3) && s_any[3] == 0;
       const unsigned row_flag = s_flag[hc];
       // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
       const double *lane_base = s_tab + (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1);
