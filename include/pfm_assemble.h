@@ -159,8 +159,9 @@ int pfm_assemble(pfm_ctx *ctx, const double *sol, const double *old, const doubl
                  double *residual_total);
 
 /* -- measurement ---------------------------------------------------------------------- */
-/* When enabled, every pfm_assemble_device() brackets its dominant kernel (the cell / row
- * kernel, not the memsets or the state scatter) with HIP events on the context's stream;
+/* When enabled, every pfm_assemble_device() brackets its kernel group (output zeroing where
+ * the kernel family needs it, residual and Jacobian kernels; not the state scatter, which is
+ * pfm_state_set_device) with HIP events on the context's stream;
  * pfm_kernel_time_ms() synchronises, returns the mean duration of the launches recorded
  * since the last call and resets the record. */
 int pfm_timing_enable(pfm_ctx *ctx, int on);
