@@ -948,10 +948,7 @@ namespace pfm
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    int rc = upload_mat_scal(p, cv, d_scal, s); // one upload serves both Jacobian kernels
-    if (rc)
-      return rc;
-    rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal);
+    int rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal);
     if (rc)
       return rc;
     return launch_cart_phi4(v, cv, p, d_values, s, d_scal);

@@ -511,7 +511,6 @@ namespace pfm
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)
   {
-    const int rc = upload_mat_scal(p, cv, d_scal, s);
-    return rc ? rc : launch_cart_uu3(v, cv, p, vals_uu, s, d_scal);
+    return launch_cart_uu3(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

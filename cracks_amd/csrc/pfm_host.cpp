@@ -534,6 +534,7 @@ extern "C"
                   "stress split is 2-D only in the reference (cracks.cc:1685-1690)");
     c->prm = *p;
     c->have_params = true;
+    c->scal_dirty = true; // the per-launch scalar tables of the cartesian Jacobian kernels follow the parameters
     return PFM_OK;
   }
 
@@ -802,6 +803,16 @@ extern "C"
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
+    if (cart && !residual_only && c->scal_dirty)
+      {
+        // off the hot path: once per pfm_set_params, complete before any kernel of any stream may read it
+        int rcs = upload_mat_scal(c->prm, c->cv, c->d_scal, c->stream);
+        if (rcs == PFM_OK && hipStreamSynchronize(c->stream) != hipSuccess)
+          rcs = PFM_ERR_HIP;
+        if (rcs)
+          return fail(c, rcs, "scalar tables");
+        c->scal_dirty = false;
+      }
     int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal)
                   : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
     if (fork)
@@ -811,6 +822,11 @@ extern "C"
           e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
         if (e != hipSuccess)
           return hipfail(c, e, "join");
+      }
+    if (rc == PFM_OK && overlay_uu && c->scal_dirty)
+      {
+        rc = upload_mat_scal(c->prm, c->cv, c->d_scal, c->stream);
+        c->scal_dirty = rc != PFM_OK;
       }
     if (rc == PFM_OK && overlay_uu)
       rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream, c->d_scal);

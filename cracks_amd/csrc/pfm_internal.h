@@ -78,7 +78,8 @@ namespace pfm
   // 8-rank sub-box) put every boundary tile on the same two XCDs (+30 % kernel time).
   constexpr unsigned xcd_grid(unsigned n_tiles) { return ((n_tiles + 7u) / 8u) * 8u; }
   constexpr size_t PFM_SCAL_BYTES = 4096;
-  // the Jacobian launchers expect the MatScal of this assembly at d_scal (upload_mat_scal, stream ordered)
+  // the Jacobian launchers expect the MatScal of the current parameters at d_scal (uploaded by pfm_assemble_device
+  // after every pfm_set_params, pfm_ctx::scal_dirty)
   int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s);
   int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
                        const void *d_scal);
@@ -119,6 +120,7 @@ struct pfm_ctx
   long long *d_send_ptr = nullptr, *d_recv_ptr = nullptr;
   int64_t n_send_all = 0, n_recv_all = 0;
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
+  bool scal_dirty = true; // d_scal does not hold the tables of the current parameters yet
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;
   double *d_partial = nullptr;
