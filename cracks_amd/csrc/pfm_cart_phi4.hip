@@ -58,7 +58,6 @@ namespace pfm
       double ex[2][NPN][2];  // per node: placeholder sum, (u,u) placeholder patch
     };
 
-    __host__ __device__ constexpr int idxC4(int al, int gi, int gj) { return al * 9 + gi * 3 + gj; }
 
     // d/dy of one nodal field at x-vertex 0/1: depends on the z-level only, evaluated once per qz
     // global -> LDS without staging registers: LDS address = (wave-uniform) lds + lane * size.  Written as asm so that

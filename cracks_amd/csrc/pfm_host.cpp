@@ -443,13 +443,18 @@ extern "C"
         v.phi = dev_alloc<double>(c, (size_t)N);
         v.phi_old = dev_alloc<double>(c, (size_t)N);
         v.phi_oldold = dev_alloc<double>(c, (size_t)N);
+        auto zero = [](void *q, size_t bytes) {
+          const hipError_t e = hipMemset(q, 0, bytes);
+          if (e != hipSuccess)
+            throw HipFail{e, "hipMemset"};
+        };
         for (int d = 0; d < dim; ++d)
-          hipMemset(v.u[d], 0, sizeof(double) * (size_t)N);
-        hipMemset(v.phi, 0, sizeof(double) * (size_t)N);
-        hipMemset(v.phi_old, 0, sizeof(double) * (size_t)N);
-        hipMemset(v.phi_oldold, 0, sizeof(double) * (size_t)N);
+          zero(v.u[d], sizeof(double) * (size_t)N);
+        zero(v.phi, sizeof(double) * (size_t)N);
+        zero(v.phi_old, sizeof(double) * (size_t)N);
+        zero(v.phi_oldold, sizeof(double) * (size_t)N);
         v.status = dev_alloc<int>(c, 1);
-        hipMemset(v.status, 0, sizeof(int));
+        zero(v.status, sizeof(int));
       }
     catch (const HipFail &f)
       {
@@ -476,40 +481,40 @@ extern "C"
   {
     if (!c)
       return PFM_OK;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(c->device); // a failure surfaces in the next call on the stream
+    (void)hipDeviceSynchronize(); // nothing of this context may still be running when its buffers go
     for (void *p : c->allocs)
-      hipFree(p);
+      (void)hipFree(p);
     for (auto &p : c->peers)
       {
         if (p.d_send)
-          hipFree(p.d_send);
+          (void)hipFree(p.d_send);
         if (p.d_recv)
-          hipFree(p.d_recv);
+          (void)hipFree(p.d_recv);
       }
     for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr})
       if (q)
-        hipFree(q);
+        (void)hipFree(q);
     if (c->side_stream)
       {
-        hipStreamDestroy(c->side_stream);
-        hipEventDestroy(c->ev_fork);
-        hipEventDestroy(c->ev_join);
+        (void)hipStreamDestroy(c->side_stream);
+        (void)hipEventDestroy(c->ev_fork);
+        (void)hipEventDestroy(c->ev_join);
       }
     for (auto &ev : c->ev_pool)
       {
-        hipEventDestroy(ev.first);
-        hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
       }
     for (double *p : c->d_stage_vec)
       if (p)
-        hipFree(p);
+        (void)hipFree(p);
     for (double *p : c->d_stage_res)
       if (p)
-        hipFree(p);
+        (void)hipFree(p);
     for (double *p : c->d_stage_val)
       if (p)
-        hipFree(p);
+        (void)hipFree(p);
     delete c;
     return PFM_OK;
   }
@@ -542,7 +547,7 @@ extern "C"
   {
     if (!c || !node_flags)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     hipError_t e = hipMemcpyAsync(const_cast<uint8_t *>(c->v.node_flags), node_flags,
                                   (size_t)c->v.n_nodes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess)
@@ -599,7 +604,7 @@ extern "C"
   {
     if (!c || !sol || !old || !oldold)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     const double *src[3] = {sol, old, oldold};
     const double *d[3] = {sol, old, oldold};
     if (!on_device)
@@ -637,13 +642,13 @@ extern "C"
   {
     if (!c || n_peers < 0 || (n_peers > 0 && (!send_ptr || !recv_ptr)))
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     for (auto &p : c->peers)
       {
         if (p.d_send)
-          hipFree(p.d_send);
+          (void)hipFree(p.d_send);
         if (p.d_recv)
-          hipFree(p.d_recv);
+          (void)hipFree(p.d_recv);
       }
     c->peers.assign((size_t)n_peers, HaloPeer{});
     for (int k = 0; k < n_peers; ++k)
@@ -670,7 +675,7 @@ extern "C"
     // concatenated lists for the one-launch pack / unpack
     for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr})
       if (q)
-        hipFree(q);
+        (void)hipFree(q);
     c->d_send_all = c->d_recv_all = nullptr;
     c->d_send_ptr = c->d_recv_ptr = nullptr;
     c->n_send_all = n_peers ? send_ptr[n_peers] - send_ptr[0] : 0;
@@ -708,7 +713,7 @@ extern "C"
   {
     if (!c || (!d_buf_all && c->n_send_all))
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     return launch_halo_all(c->v, c->d_send_all, c->d_send_ptr, (int)c->peers.size(), c->n_send_all, d_buf_all, 0, c->stream);
   }
 
@@ -716,7 +721,7 @@ extern "C"
   {
     if (!c || (!d_buf_all && c->n_recv_all))
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     return launch_halo_all(c->v, c->d_recv_all, c->d_recv_ptr, (int)c->peers.size(), c->n_recv_all,
                            const_cast<double *>(d_buf_all), 1, c->stream);
   }
@@ -725,7 +730,7 @@ extern "C"
   {
     if (!c || peer < 0 || peer >= (int)c->peers.size() || !d_buf)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     return launch_halo_pack(c->v, c->peers[peer].d_send, c->peers[peer].n_send, d_buf, c->stream);
   }
 
@@ -733,7 +738,7 @@ extern "C"
   {
     if (!c || peer < 0 || peer >= (int)c->peers.size() || !d_buf)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     return launch_halo_unpack(c->v, c->peers[peer].d_recv, c->peers[peer].n_recv, d_buf, c->stream);
   }
 
@@ -744,7 +749,7 @@ extern "C"
       return PFM_ERR_BAD_ARG;
     if (!c->have_params)
       return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     hipError_t e = hipSuccess;
     const bool split = (c->prm.decompose_stress_matrix > 0 || c->prm.decompose_stress_rhs > 0) &&
                        c->prm.timestep_number > 0;
@@ -763,7 +768,7 @@ extern "C"
         ev0 = c->ev_pool[c->ev_used].first;
         ev1 = c->ev_pool[c->ev_used].second;
         ++c->ev_used;
-        hipEventRecord(ev0, c->stream);
+        (void)hipEventRecord(ev0, c->stream);
       }
     // Optional (PFM_SIDE_STREAM=1): residual kernel on a side stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
     // the kernels do not share CUs usefully; off by default.
@@ -831,7 +836,7 @@ extern "C"
     if (rc == PFM_OK && overlay_uu)
       rc = launch_cart_uu_only(c->v, c->cv, c->prm, d_values[0], c->stream, c->d_scal);
     if (ev1)
-      hipEventRecord(ev1, c->stream);
+      (void)hipEventRecord(ev1, c->stream);
     if (rc)
       return fail(c, rc, "assemble launch failed");
     return PFM_OK;
@@ -841,7 +846,7 @@ extern "C"
   {
     if (!c)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     int st = 0;
     hipError_t e = hipMemcpyAsync(&st, c->v.status, sizeof(int), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess)
@@ -850,7 +855,7 @@ extern "C"
       return hipfail(c, e, "sync_status");
     if (st != 0)
       {
-        hipMemsetAsync(c->v.status, 0, sizeof(int), c->stream);
+        (void)hipMemsetAsync(c->v.status, 0, sizeof(int), c->stream);
         return fail(c, st, st == PFM_ERR_NOT_ORTHOGONAL
                              ? "eigenvectors not orthogonal (cracks.cc:1732-1736)"
                              : "device-side error");
@@ -916,7 +921,7 @@ extern "C"
   {
     if (!c || !mean_ms)
       return PFM_ERR_BAD_ARG;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess)
       return hipfail(c, e, "kernel_time sync");
