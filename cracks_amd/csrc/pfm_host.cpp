@@ -602,7 +602,11 @@ extern "C"
   int pfm_state_set(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
                     int on_device)
   {
-    if (!c || !sol || !old || !oldold)
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    if (c->n_owned_dofs() == 0)
+      return PFM_OK; // a rank that owns nothing: its node state comes from the ghost import alone
+    if (!sol || !old || !oldold)
       return PFM_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
     const double *src[3] = {sol, old, oldold};
@@ -745,7 +749,9 @@ extern "C"
   int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values,
                           double *d_res_pde, double *d_res_tot)
   {
-    if (!c || !d_res_pde || (residual_only && !d_res_tot) || (!residual_only && !d_values))
+    // a rank may own nothing (empty partition piece): null buffers are fine where there is nothing to write
+    const bool no_rows = c && c->n_owned_dofs() == 0;
+    if (!c || (!d_res_pde && !no_rows) || (residual_only && !d_res_tot && !no_rows) || (!residual_only && !d_values))
       return PFM_ERR_BAD_ARG;
     if (!c->have_params)
       return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
@@ -799,7 +805,7 @@ extern "C"
     if (e == hipSuccess && !residual_only)
       for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
         {
-          if (!d_values[b])
+          if (!d_values[b] && c->block_nnz(b) > 0)
             return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
           // the row-owner kernels write every value once, the structurally zero (u,phi) block
           // of the blocked layout included (k_cart_phi4)

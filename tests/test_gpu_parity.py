@@ -179,3 +179,35 @@ def test_device_resident_assembler_matches_host_entry():
     r, _, _ = _oracle(c, True)
     assert linf_scaled(asm.system_total_residual.cpu().numpy(), r.residual_total) < TOL
     assert torch.isfinite(asm.system_pde_residual).all()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_rank_without_cells_or_owned_rows(dim):
+    """Empty inputs as a partition can produce them: a rank whose local mesh has nodes but no cells (all values and
+    residuals zero), and a rank that owns no node at all (nothing to write, every call still succeeds)."""
+    from cracks_amd.assembler import Assembler
+    import torch
+
+    g = M.box_mesh(dim, (3,) * dim)
+    empty = M.Mesh(dim=dim, coords=g.coords.copy(), cells=np.zeros((0, 1 << dim), np.int32), boundary_nodes={})
+    a = Assembler(empty, blocked=True)
+    a.set_params(cases.kat_sneddon_3d(4).params if dim == 3 else cases.kat_sneddon_2d().params)
+    a.set_constraints(np.zeros(empty.n_nodes, np.uint8))
+    n = empty.n_nodes * (dim + 1)
+    a.set_vectors(np.linspace(0, 1, n), np.zeros(n), np.zeros(n))
+    a.system_pde_residual.fill_(float("nan"))
+    for ro in (False, True):
+        a.assemble_system(ro)
+        a.synchronize()
+        assert float(a.system_pde_residual.abs().max()) == 0.0
+    assert all(m.numel() == 0 or float(m.abs().max()) == 0.0 for m in a.system_pde_matrix)
+
+    b = Assembler(g, blocked=True, n_owned_nodes=0)
+    b.set_params(cases.kat_sneddon_3d(4).params if dim == 3 else cases.kat_sneddon_2d().params)
+    b.set_constraints(np.zeros(g.n_nodes, np.uint8))
+    assert b.solution.numel() == 0
+    for ro in (False, True):
+        b.assemble_system(ro)
+        b.synchronize()
+    assert all(m.numel() == 0 for m in b.system_pde_matrix)
+    torch.cuda.synchronize()
