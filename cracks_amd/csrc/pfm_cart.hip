@@ -647,7 +647,8 @@ namespace pfm
       {
         const int ntx = (int)((OWX + RNX - 1) / RNX), nty = (int)((OWY + RNY - 1) / RNY);
         // chunks of z-planes: fill the dispatch rounds of the chip (2 workgroups per CU) at few redundant layers
-        const int zc = choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
+        static const int zc_force = getenv("PFM_RES_ZC") ? atoi(getenv("PFM_RES_ZC")) : 0; // tuning only
+        const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
         const int nch = (int)((OWZ + zc - 1) / zc);
         hipLaunchKernelGGL(k_cart_residual3, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
                            res_tot, residual_only, zc);

@@ -901,7 +901,8 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
     // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
-    const int zc = choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
+    static const int zc_force = getenv("PFM_PHI_ZC") ? atoi(getenv("PFM_PHI_ZC")) : 0; // tuning only
+    const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
     const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
     if (v.layout == PFM_LAYOUT_INTERLEAVED)
