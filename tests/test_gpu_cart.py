@@ -224,3 +224,20 @@ def test_cart_overwrites_every_output(blocked):
         assert torch.equal(a, b)
     if blocked:
         assert float(outs[0][1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+def test_cart_matches_general_family_on_a_medium_box(blocked):
+    """Two independent implementations (row-owner kernels vs cell-owner kernels with atomics) on a box with many
+    tiles, partial tiles on both high faces and several z-chunks: 40 x 33 x 70 cells, every value of every block."""
+    c = box_case(3, (40, 33, 70), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0), blocked, seed=5, monolithic=True)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    v1, r1, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    _, rp1, rt1 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    ctx.force_path(0)
+    v0, r0, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    _, rp0, rt0 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    for a, b in zip(v1, v0):
+        assert linf_scaled(a, b) < TOL
+    assert linf_scaled(r1, r0) < TOL and linf_scaled(rp1, rp0) < TOL and linf_scaled(rt1, rt0) < TOL
