@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""One-off robustness run on the GPU box: (1) 200 Jacobian assemblies of the 3-D Sneddon 216^3 bench problem must
+leave bit-identical outputs and a stable amount of free device memory; (2) 60 context create/destroy cycles on a
+40^3 box must give the memory back."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    import bench
+    from cracks_amd import mesh as M
+    from cracks_amd.assembler import Assembler
+
+    def problem(n):
+        g = M.box_mesh(3, (n,) * 3)
+        h = (20.0 / n) * np.sqrt(3.0)
+        u, phi, po, poo, flags = bench.synthetic_state(g, np.arange(g.n_nodes), h, 3)
+        a = Assembler(g, blocked=True)
+        a.set_params(bench.sneddon_params(h, 3))
+        a.set_constraints(flags)
+        N = g.n_nodes
+        pack = lambda uu, pp: np.concatenate([uu.reshape(-1), pp])
+        a.set_vectors(pack(u, phi), pack(0 * u, po), pack(0 * u, poo))
+        return a
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 216
+    a = problem(n)
+    a.assemble_system(False)
+    a.synchronize()
+    ref = [m.clone() for m in a.system_pde_matrix] + [a.system_pde_residual.clone()]
+    free0 = torch.cuda.mem_get_info()[0]
+    for it in range(200):
+        for m in a.system_pde_matrix:
+            m.fill_(float(it))  # whatever was there must be overwritten
+        a.assemble_system(False)
+        if it % 50 == 49:
+            a.synchronize()
+            print(f"  after {it + 1}: free {torch.cuda.mem_get_info()[0] / 2**30:.3f} GiB", flush=True)
+    a.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]  # before the comparison below, whose temporaries torch keeps cached
+    assert abs(free0 - free1) < (64 << 20), "device memory grew during the assemblies"
+    now = list(a.system_pde_matrix) + [a.system_pde_residual]
+    assert all(torch.equal(x, y) for x, y in zip(ref, now)), "outputs changed between assemblies"
+    print(f"200 assemblies at {n}^3: bit-identical; free memory {free0 / 2**30:.2f} -> {free1 / 2**30:.2f} GiB")
+    del a, ref, now
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for it in range(60):
+        b = problem(40)
+        b.assemble_system(False)
+        b.synchronize()
+        del b
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    print(f"60 context create/destroy cycles: free memory {free0 / 2**30:.2f} -> {free1 / 2**30:.2f} GiB")
+    assert abs(free0 - free1) < (64 << 20)
+
+
+if __name__ == "__main__":
+    main()
