@@ -347,6 +347,10 @@ namespace pfm
     constexpr int RHX = RTX + 1, RHY = RTY + 1; // nodal halo per plane
     constexpr int RPL = RHX * RHY + 3;          // padded plane stride (292)
 
+    // LIN: pf_extra is a linear function of the two old phase fields up to its final clamp (no per-q-point clamping of
+    // the old fields: not monolithic; no penalisation term that needs phi_old alone): the combination is formed once
+    // per node when a plane is loaded and interpolated as ONE field (cracks.cc:2262-2277 are linear until the clamp).
+    template <bool LIN>
     __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3(DevView v, CartView cv, Scal S,
                                                                  double *__restrict__ res_pde,
                                                                  double *__restrict__ res_tot, int write_total,
@@ -387,9 +391,11 @@ namespace pfm
                 val[3] = v.phi[n];
                 val[4] = v.phi_old[n];
                 val[5] = v.phi_oldold[n];
+                if constexpr (LIN)
+                  val[4] = S.use_old ? val[4] : val[5] + S.tfac * (val[4] - val[5]);
               }
 #pragma unroll
-            for (int f = 0; f < 6; ++f)
+            for (int f = 0; f < (LIN ? 5 : 6); ++f)
               s_U[buf][f][idx] = val[f];
           }
       };
@@ -430,8 +436,9 @@ namespace pfm
                         }
                     }
                   double L[6][2], Dz[4][2], Dx[4];
+                  L[5][0] = L[5][1] = 0.0;
 #pragma unroll
-                  for (int f = 0; f < 6; ++f)
+                  for (int f = 0; f < (LIN ? 5 : 6); ++f)
                     {
                       const double a00 = Ulo[f * RPL], a10 = Ulo[f * RPL + 1], a01 = Ulo[f * RPL + RHX],
                                    a11 = Ulo[f * RPL + RHX + 1];
@@ -473,22 +480,32 @@ namespace pfm
                       gpf[1] = nx0 * Dy[3][0] + nx1 * Dy[3][1];
                       gpf[2] = nx0 * Dz[3][0] + nx1 * Dz[3][1];
                       double pf = nx0 * L[3][0] + nx1 * L[3][1];
-                      double pfo = nx0 * L[4][0] + nx1 * L[4][1];
-                      double pfoo = nx0 * L[5][0] + nx1 * L[5][1];
-                      if (S.monolithic)
+                      double pfo = nx0 * L[4][0] + nx1 * L[4][1]; // LIN: the combined field
+                      double pen = 0.0, pfx;
+                      if constexpr (LIN)
                         {
-                          pf = fmax(0.0, pf);
-                          pfo = fmax(0.0, pfo);
-                          pfoo = fmax(0.0, pfoo);
+                          pfx = pfo;
+                          if (!S.use_old)
+                            pfx = fmin(fmax(pfx, 0.0), 1.0);
                         }
-                      const double pen = fmax(0.0, pf - pfo);
-                      double pfx = pfoo + S.tfac * (pfo - pfoo);
-                      if (pfx <= 0.0)
-                        pfx = 0.0;
-                      if (pfx >= 1.0)
-                        pfx = 1.0;
-                      if (S.use_old)
-                        pfx = pfo;
+                      else
+                        {
+                          double pfoo = nx0 * L[5][0] + nx1 * L[5][1];
+                          if (S.monolithic)
+                            {
+                              pf = fmax(0.0, pf);
+                              pfo = fmax(0.0, pfo);
+                              pfoo = fmax(0.0, pfoo);
+                            }
+                          pen = fmax(0.0, pf - pfo);
+                          pfx = pfoo + S.tfac * (pfo - pfoo);
+                          if (pfx <= 0.0)
+                            pfx = 0.0;
+                          if (pfx >= 1.0)
+                            pfx = 1.0;
+                          if (S.use_old)
+                            pfx = pfo;
+                        }
                       const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
                       const double e01 = 0.5 * (gu[0][1] + gu[1][0]), e02 = 0.5 * (gu[0][2] + gu[2][0]),
                                    e12 = 0.5 * (gu[1][2] + gu[2][1]);
@@ -650,8 +667,12 @@ namespace pfm
         static const int zc_force = getenv("PFM_RES_ZC") ? atoi(getenv("PFM_RES_ZC")) : 0; // tuning only
         const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
         const int nch = (int)((OWZ + zc - 1) / zc);
-        hipLaunchKernelGGL(k_cart_residual3, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S, res_pde,
-                           res_tot, residual_only, zc);
+        if (!S.monolithic && S.gamma_fac == 0.0)
+          hipLaunchKernelGGL(k_cart_residual3<true>, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S,
+                             res_pde, res_tot, residual_only, zc);
+        else
+          hipLaunchKernelGGL(k_cart_residual3<false>, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S,
+                             res_pde, res_tot, residual_only, zc);
       }
     if (hipGetLastError() != hipSuccess)
       return PFM_ERR_HIP;

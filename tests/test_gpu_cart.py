@@ -241,3 +241,22 @@ def test_cart_matches_general_family_on_a_medium_box(blocked):
     for a, b in zip(v1, v0):
         assert linf_scaled(a, b) < TOL
     assert linf_scaled(r1, r0) < TOL and linf_scaled(rp1, rp0) < TOL and linf_scaled(rt1, rt0) < TOL
+
+
+@pytest.mark.parametrize("dim,n", [(3, (9, 5, 11)), (2, (12, 7))])
+def test_cart_residual_with_old_timestep_phase_field(dim, n):
+    """use_old_timestep_pf (cracks.cc:2273-2276: pf_extra = phi_old, unclamped) on the staggered (non-monolithic) path,
+    where the 3-D residual kernel interpolates one combined old field instead of two."""
+    c = box_case(dim, n, -1.0, 2.0, True, seed=9)
+    c.params.use_old_timestep_pf = 1
+    c.params.time, c.params.timestep, c.params.old_timestep, c.params.old_old_timestep = 2.3, 0.5, 0.7, 0.4
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(res_pde, r.residual_pde) < TOL and linf_scaled(res_tot, r.residual_total) < TOL
+    c.params.use_old_timestep_pf = 0  # extrapolated pf_extra with unequal time steps (tfac != 1), clamped to [0, 1]
+    ctx = make_context(c)
+    _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(res_pde, r.residual_pde) < TOL and linf_scaled(res_tot, r.residual_total) < TOL
