@@ -100,6 +100,32 @@ namespace pfm
       double lapM[27];                 // G_c eps sum_q w grad N_a . grad N_b by moment index g_x + 3 g_y + 9 g_z
     };
 
+    // the same from ONE nodal field: staggered scheme (no clamping of the old fields at the q-points), where pf_extra is
+    // linear in (phi_old, phi_oldold) up to its final clamp -- pw = phi_old if use_old_timestep_pf, else
+    // phi_oldold + tfac (phi_old - phi_oldold), formed per node by the caller
+    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9])
+    {
+      double a[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        a[v] = c_g1.n[0][qz] * pw[v] + c_g1.n[1][qz] * pw[v + 4];
+#pragma unroll
+      for (int qy = 0; qy < 3; ++qy)
+        {
+          const double a0 = c_g1.n[0][qy] * a[0] + c_g1.n[1][qy] * a[2];
+          const double a1 = c_g1.n[0][qy] * a[1] + c_g1.n[1][qy] * a[3];
+#pragma unroll
+          for (int qx = 0; qx < 3; ++qx)
+            {
+              double pfx = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
+              if (!S.use_old)
+                pfx = fmin(fmax(pfx, 0.0), 1.0);
+              const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz]) * g;
+            }
+        }
+    }
+
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
     __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScal &S, int qz,
                                                   double wg[9])

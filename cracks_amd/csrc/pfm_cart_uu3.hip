@@ -247,6 +247,8 @@ namespace pfm
               a = v.phi_old[n];
               b = v.phi_oldold[n];
               f = v.node_flags[n];
+              if (!S.monolithic) // one combined field is interpolated in the cell phase (cell_wg_plane_lin)
+                a = S.use_old ? a : b + S.tfac * (a - b);
             }
           s_node[t] = n;
           s_po[t] = a;
@@ -288,14 +290,24 @@ namespace pfm
           if (valid)
             {
               double po[8], poo[8];
-#pragma unroll
-              for (int b = 0; b < 8; ++b)
+              if (!S.monolithic)
                 {
-                  const int hb = h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1);
-                  po[b] = s_po[hb];
-                  poo[b] = s_poo[hb];
+#pragma unroll
+                  for (int b = 0; b < 8; ++b)
+                    po[b] = s_po[h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1)];
+                  cell_wg_plane_lin(po, S, qz, wg);
                 }
-              cell_wg_plane(po, poo, S, qz, wg);
+              else
+                {
+#pragma unroll
+                  for (int b = 0; b < 8; ++b)
+                    {
+                      const int hb = h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1);
+                      po[b] = s_po[hb];
+                      poo[b] = s_poo[hb];
+                    }
+                  cell_wg_plane(po, poo, S, qz, wg);
+                }
             }
           else
             {
