@@ -255,7 +255,11 @@ def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra
         return json.loads(line)
 
     one = run([sys.executable, "bench.py", "--gpus", "1"] + common)
-    port = 29600 + world
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))  # a free port for the rendezvous
+    port = sock.getsockname()[1]
+    sock.close()
     many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                 "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world)] + common)
     assert many["n_gpus"] == world and one["n_gpus"] == 1
