@@ -125,6 +125,26 @@ class Context:
                                              capi.np_ptr(colind, np.int32)), "pfm_pattern_get")
         return rowptr, colind
 
+    def pattern_bind(self, block: int, rowptr: np.ndarray, colind: np.ndarray):
+        """``pfm_pattern_bind``: adopt the host's CSR arrays of one block (int64 or int32 row pointers)."""
+        ci = np.ascontiguousarray(colind, np.int32)
+        if np.asarray(rowptr).dtype == np.int32:
+            rp = np.ascontiguousarray(rowptr, np.int32)
+            rc = self.lib.pfm_pattern_bind_i32(self._h, block, capi.np_ptr(rp, np.int32), capi.np_ptr(ci, np.int32))
+        else:
+            rp = np.ascontiguousarray(rowptr, np.int64)
+            rc = self.lib.pfm_pattern_bind(self._h, block, capi.np_ptr(rp, np.int64), capi.np_ptr(ci, np.int32))
+        self._check(rc, "pfm_pattern_bind")
+
+    def halo_exchange(self, comm_handle: int, peer_ranks):
+        """``pfm_halo_exchange``: pack -> RCCL send/recv -> unpack inside the library (context's stream)."""
+        pr = np.ascontiguousarray(peer_ranks, np.int32)
+        self._check(self.lib.pfm_halo_exchange(self._h, C.c_void_p(comm_handle),
+                                               capi.np_ptr(pr, np.int32) if pr.size else None), "pfm_halo_exchange")
+
+    def check_finite(self, data_ptr: int, n: int):
+        self._check(self.lib.pfm_check_finite(self._h, C.c_void_p(data_ptr), C.c_int64(n)), "pfm_check_finite")
+
     def state_set_device(self, sol_ptr: int, old_ptr: int, oldold_ptr: int):
         self._check(self.lib.pfm_state_set(self._h, C.c_void_p(sol_ptr), C.c_void_p(old_ptr),
                                            C.c_void_p(oldold_ptr), 1), "pfm_state_set")
@@ -223,11 +243,19 @@ class Context:
         self._check(self.lib.pfm_get_constraints(self._h, capi.np_ptr(flags, np.uint8)), "pfm_get_constraints")
         return flags
 
-    def functionals(self, cell_owned: Optional[np.ndarray] = None):
-        """(bulk energy, crack energy, TCV) of the node state in the context (cracks.cc:3553-3701)."""
+    def functionals(self, cell_owned: Optional[np.ndarray] = None, cell_lambda=None, cell_mu=None):
+        """(bulk energy, crack energy, TCV) of the node state in the context (cracks.cc:3553-3701); optional per-cell
+        Lame coefficients for the energy (the reference's heterogeneous case uses other ones than the assembly)."""
         out = (C.c_double * 3)()
         mask = None if cell_owned is None else np.ascontiguousarray(cell_owned, np.uint8)
-        self._check(self.lib.pfm_functionals(self._h, None if mask is None else capi.np_ptr(mask, np.uint8), out), "pfm_functionals")
+        mp = None if mask is None else capi.np_ptr(mask, np.uint8)
+        if cell_lambda is None:
+            self._check(self.lib.pfm_functionals(self._h, mp, out), "pfm_functionals")
+        else:
+            la = np.ascontiguousarray(cell_lambda, np.float64)
+            mu = np.ascontiguousarray(cell_mu, np.float64)
+            self._check(self.lib.pfm_functionals_material(self._h, mp, capi.np_ptr(la, np.float64),
+                                                          capi.np_ptr(mu, np.float64), out), "pfm_functionals_material")
         return float(out[0]), float(out[1]), float(out[2])
 
 

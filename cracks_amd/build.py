@@ -37,7 +37,12 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     SOURCES = srcs
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in srcs] + ["-o", LIB]
+    # RCCL (the in-library ghost exchange, pfm_halo_exchange): the ROCm copy; in a process that has imported torch the
+    # loader resolves the same SONAME (librccl.so.1) to torch's bundled build
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    link = ["-L" + os.path.join(rocm, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(rocm, "include"), "-x", "hip"] + \
+          [os.path.join(CSRC, s) for s in srcs] + ["-o", LIB] + link
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -15,19 +15,23 @@ LIB_PATH = os.path.join(HERE, "csrc", "libpfm_hip.so")
 
 PFM_OK = 0
 STATUS_NAMES = {0: "PFM_OK", 1: "PFM_ERR_BAD_ARG", 2: "PFM_ERR_HIP", 3: "PFM_ERR_NOT_ORTHOGONAL",
-                4: "PFM_ERR_NONFINITE", 5: "PFM_ERR_UNSUPPORTED", 6: "PFM_ERR_NOMEM"}
+                4: "PFM_ERR_NONFINITE", 5: "PFM_ERR_UNSUPPORTED", 6: "PFM_ERR_NOMEM", 7: "PFM_ERR_COMM"}
+COMM_ID_BYTES = 128
 LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 
 # every symbol include/pfm_assemble.h declares
 EXPORTS = [
     "pfm_ctx_create", "pfm_ctx_destroy", "pfm_last_error", "pfm_ctx_set_stream", "pfm_set_params",
-    "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_state_set",
+    "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_pattern_bind", "pfm_pattern_bind_i32",
+    "pfm_state_set", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_destroy", "pfm_halo_exchange",
+    "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
     "pfm_assemble_device",
     "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms",
     # include/pfm_newton.h
     "pfm_diag_mass_device", "pfm_active_set_device", "pfm_get_constraints", "pfm_functionals",
+    "pfm_functionals_material",
 ]
 
 
@@ -94,6 +98,14 @@ def load():
     lib.pfm_set_constraints.argtypes = [vp, vp]
     lib.pfm_pattern_size.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.pfm_pattern_get.argtypes = [vp, i32, vp, vp]
+    lib.pfm_pattern_bind.argtypes = [vp, i32, vp, vp]
+    lib.pfm_pattern_bind_i32.argtypes = [vp, i32, vp, vp]
+    lib.pfm_comm_unique_id.argtypes = [vp]
+    lib.pfm_comm_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
+    lib.pfm_comm_destroy.argtypes = [vp]
+    lib.pfm_halo_exchange.argtypes = [vp, vp, vp]
+    lib.pfm_check_finite.argtypes = [vp, vp, i64]
+    lib.pfm_functionals_material.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
     lib.pfm_state_set.argtypes = [vp, vp, vp, vp, i32]
     lib.pfm_halo_register.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pfm_halo_pack.argtypes = [vp, i32, vp]

@@ -651,7 +651,7 @@ namespace pfm
     int rc = ensure_tab();
     if (rc)
       return rc;
-    if ((p.decompose_stress_matrix > 0 || p.decompose_stress_rhs > 0) && p.timestep_number > 0)
+    if (p.decompose_stress_matrix > 0 && p.timestep_number > 0)
       return PFM_ERR_UNSUPPORTED; // the host routes split runs to the general path
     const Scal S = make_scal(p, cv, v.dim);
     const int bs = 256;

@@ -694,9 +694,11 @@ namespace pfm
               double *pu_m1 = s.pu[cp], *pu_z0 = s.pu[2 + cp], *pu_p1 = s.pu[4];
               double *pp_m1 = s.pp[cp], *pp_z0 = s.pp[2 + cp], *pp_p1 = s.pp[4];
               const bool tile_full = (i0 + PN - 1) <= cv.o1[0] && (j0 + PN - 1) <= cv.o1[1];
-              const bool fast = regular && !masked && tile_full; // all rows full, owned and free of constraint flags
-              // Rows are in lattice order: the CSR slot of lattice offset o is its rank among the offsets that exist
-              // (popcount of the row's neighbour mask below bit o); interior rows have all 27.
+              // all rows full, in lattice order, owned and free of constraint flags; the blocked copy-out below writes the
+              // 7 rows of a y-line as ONE run, i.e. it also needs x-consecutive owned nodes to have consecutive local ids
+              const bool fast = regular && !masked && tile_full && (NCOL != 3 || cv.owned_lex);
+              // Rows in lattice order (bit 31 of the mask clear): the CSR slot of lattice offset o is its rank among the
+              // offsets that exist (popcount of the row's neighbour mask below bit o); interior rows have all 27.
               if (NCOL == 3 && fast)
                 {
                   // Blocked layout, interior plane without constraint flags (the common case): the 7 rows of a
@@ -834,7 +836,9 @@ namespace pfm
                             }
                           if (off >= 0 && ((nmask >> fe_o) & 1u)) // owned node, neighbour inside the mesh
                             {
-                              const int sl = __popc(nmask & below);
+                              int sl = __popc(nmask & below);
+                              if (nmask >> 31) // row not in lattice order: permutation of the ranks
+                                sl = cv.row_perm[off + sl];
                               if constexpr (NCOL == 3)
                                 {
                                   if (fe_pp)
@@ -846,7 +850,7 @@ namespace pfm
                                     }
                                 }
                               else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
-                                vals_uu[16 * off + (long long)3 * 4 * __popc(nmask) + sl * 4 + fe_d] = val;
+                                vals_uu[16 * off + (long long)3 * 4 * __popc(nmask & 0x7ffffffu) + sl * 4 + fe_d] = val;
                             }
                         }
                     }
@@ -866,7 +870,10 @@ namespace pfm
                       // constrained displacement rows whose element diagonal vanished in some cell
                       const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
                       const unsigned nmask = (unsigned)s.deg[cp][nl];
-                      const int deg = __popc(nmask), sself = __popc(nmask & ((1u << 13) - 1u));
+                      const int deg = __popc(nmask & 0x7ffffffu);
+                      int sself = __popc(nmask & ((1u << 13) - 1u));
+                      if (nmask >> 31)
+                        sself = cv.row_perm[off + sself];
                       for (int c = 0; c < 3; ++c)
                         if ((row_flag >> c) & 1u)
                           vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += patch;

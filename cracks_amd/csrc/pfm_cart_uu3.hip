@@ -460,8 +460,9 @@ namespace pfm
             }
           else
             {
-              // rows at the faces of the box / partial tiles: thread <-> (row, lattice offset o, column component);
-              // rows are in lattice order, so the CSR slot of offset o is its rank among the offsets that exist
+              // rows at the faces of the box / partial tiles / next to ghost columns: thread <-> (row, lattice offset o,
+              // column component); the CSR slot of offset o is its rank among the offsets that exist, or the row's
+              // permutation of that rank
               constexpr int rowlen = 27 * NCOL;
               for (int f = t; f < NN3 * rowlen; f += NT3)
                 {
@@ -471,7 +472,10 @@ namespace pfm
                   const unsigned mask = s_mask[nl];
                   if (base < 0 || !((mask >> o) & 1u))
                     continue;
-                  const int sl = __popc(mask & ((1u << o) - 1u)), deg = __popc(mask);
+                  int sl = __popc(mask & ((1u << o) - 1u));
+                  const int deg = __popc(mask & 0x7ffffffu);
+                  if (mask >> 31) // the row is not in lattice order (ghost columns behind the owned ones, bound pattern)
+                    sl = cv.row_perm[base / (NCOL * NCOL) + sl];
                   const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
                   vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
                 }

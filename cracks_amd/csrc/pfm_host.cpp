@@ -14,11 +14,15 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <new>
+#include <thread>
 
 using namespace pfm;
 
@@ -67,19 +71,52 @@ namespace
   {
     return fail(c, PFM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
   }
+
+  // Host threads for the O(n_nodes) / O(n_cells) loops of the context build (setup_system of the reference runs them
+  // after every refine_mesh, cracks.cc:4148): the cores this process may use (affinity mask, cgroup quota), at most 32.
+  int host_threads()
+  {
+    static int n = 0;
+    if (n)
+      return n;
+    unsigned hc = std::thread::hardware_concurrency();
+    int t = hc ? (int)hc : 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string q;
+    double per = 0;
+    if (f >> q >> per && q != "max" && per > 0)
+      t = std::min(t, std::max(1, (int)(std::stod(q) / per)));
+    if (const char *e = getenv("PFM_HOST_THREADS"))
+      t = std::max(1, atoi(e));
+    n = std::max(1, std::min(t, 32));
+    return n;
+  }
+
+  // fn(begin, end) over [0, n) in contiguous chunks, one per thread
+  template <class F>
+  void parallel_for(int64_t n, F &&fn)
+  {
+    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / 65536));
+    if (nt <= 1)
+      {
+        fn((int64_t)0, n);
+        return;
+      }
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&fn, n, nt, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th)
+      x.join();
+  }
   // Lattice of a uniform Cartesian box: node n <-> lattice index box_of_local[n] (x fastest), cells in deal.II
   // vertex order, every lattice cell present exactly once.  false whenever any check fails.
-  struct Lattice
-  {
-    int NX = 0, NY = 0, NZ = 0, nc[3] = {0, 0, 0};
-    double h[3] = {1, 1, 1};
-    std::vector<int32_t> local_of_box, box_of_local;
-  };
+  using Lattice = pfm::LatticeHost;
 
   bool detect_lattice(const pfm_mesh_desc *m, Lattice &L)
   {
     const int dim = m->dim, nv = 1 << dim;
-    if (m->n_hanging > 0 || m->cell_lambda || m->cell_mu)
+    if (m->n_hanging > 0)
       return false;
     int nc[3] = {m->box_cells[0], m->box_cells[1], dim == 3 ? m->box_cells[2] : 1};
     if (nc[0] <= 0 || nc[1] <= 0 || nc[2] <= 0)
@@ -104,41 +141,62 @@ namespace
       }
     std::vector<int32_t> local_of_box((size_t)nn, -1);
     std::vector<int32_t> box_of_local((size_t)N);
+    std::atomic<bool> ok{true};
+    parallel_for(N, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        {
+          int64_t idx[3] = {0, 0, 0};
+          for (int d = 0; d < dim; ++d)
+            {
+              const double t = (m->coords[(size_t)n * dim + d] - x0[d]) / h[d];
+              idx[d] = llround(t);
+              if (std::abs(t - (double)idx[d]) > 1e-9 || idx[d] < 0 || idx[d] > nc[d])
+                {
+                  ok = false;
+                  return;
+                }
+            }
+          box_of_local[n] = (int32_t)(idx[0] + (int64_t)NX * (idx[1] + (int64_t)NY * idx[2]));
+        }
+    });
+    if (!ok)
+      return false;
     for (int32_t n = 0; n < N; ++n)
       {
-        int64_t idx[3] = {0, 0, 0};
-        for (int d = 0; d < dim; ++d)
-          {
-            const double t = (m->coords[(size_t)n * dim + d] - x0[d]) / h[d];
-            idx[d] = llround(t);
-            if (std::abs(t - (double)idx[d]) > 1e-9 || idx[d] < 0 || idx[d] > nc[d])
-              return false;
-          }
-        const int64_t b = idx[0] + (int64_t)NX * (idx[1] + (int64_t)NY * idx[2]);
+        const int32_t b = box_of_local[n];
         if (local_of_box[b] != -1)
           return false; // duplicated coordinates (e.g. a slit): not a lattice
         local_of_box[b] = n;
-        box_of_local[n] = (int32_t)b;
       }
     // every lattice cell must be present exactly once, vertices in deal.II order
     std::vector<uint8_t> seen((size_t)m->n_cells, 0);
+    parallel_for(m->n_cells, [&](int64_t cb, int64_t ce) {
+      for (int64_t cell = cb; cell < ce; ++cell)
+        {
+          const int64_t b0 = box_of_local[m->cell_nodes[cell * nv]];
+          const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / ((int64_t)NX * NY);
+          if (i >= nc[0] || j >= nc[1] || (dim == 3 && k >= nc[2]))
+            {
+              ok = false;
+              return;
+            }
+          for (int a = 0; a < nv; ++a)
+            {
+              const int64_t b = (i + (a & 1)) + (int64_t)NX * ((j + ((a >> 1) & 1)) + (int64_t)NY * (k + ((a >> 2) & 1)));
+              if (local_of_box[b] != m->cell_nodes[cell * nv + a])
+                {
+                  ok = false;
+                  return;
+                }
+            }
+          seen[i + (int64_t)nc[0] * (j + (int64_t)nc[1] * k)] = 1; // distinct cells write distinct bytes unless duplicated
+        }
+    });
+    if (!ok)
+      return false;
     for (int64_t cell = 0; cell < m->n_cells; ++cell)
-      {
-        const int64_t b0 = box_of_local[m->cell_nodes[cell * nv]];
-        const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / ((int64_t)NX * NY);
-        if (i >= nc[0] || j >= nc[1] || (dim == 3 && k >= nc[2]))
-          return false;
-        for (int a = 0; a < nv; ++a)
-          {
-            const int64_t b = (i + (a & 1)) + (int64_t)NX * ((j + ((a >> 1) & 1)) + (int64_t)NY * (k + ((a >> 2) & 1)));
-            if (local_of_box[b] != m->cell_nodes[cell * nv + a])
-              return false;
-          }
-        const int64_t cid = i + (int64_t)nc[0] * (j + (int64_t)nc[1] * k);
-        if (seen[cid])
-          return false;
-        seen[cid] = 1;
-      }
+      if (!seen[cell])
+        return false; // n_cells matches the box, so a missing cell means another one is present twice
     L.NX = NX;
     L.NY = NY;
     L.NZ = NZ;
@@ -152,15 +210,145 @@ namespace
     return true;
   }
 
+  // Node graph of a lattice mesh, rows = owned nodes, columns ascending by local node id (the canonical order of the
+  // ABI, what a host CSR sorted by local column id has).  Arithmetic instead of the generic cell-incidence build: the
+  // neighbours of lattice node (i,j,k) are the lattice offsets that stay inside the local box (every cell of the box
+  // is local, detect_lattice).  Also fills the host copies of the cartesian row tables (row_order_tables).
+  void lattice_graph(pfm_ctx *c, int dim, int32_t NO, const Lattice &L)
+  {
+    const int NX = L.NX, NY = L.NY, NZ = L.NZ, no = dim == 3 ? 27 : 9;
+    std::vector<long long> &ptr = c->h_nadj_ptr;
+    ptr.assign((size_t)NO + 1, 0);
+    parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        {
+          const int64_t b = L.box_of_local[n];
+          const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+          const int cx = 1 + (i > 0) + (i < NX - 1), cy = 1 + (j > 0) + (j < NY - 1), cz = 1 + (k > 0) + (k < NZ - 1);
+          ptr[n + 1] = cx * cy * cz;
+        }
+    });
+    for (int32_t n = 0; n < NO; ++n)
+      ptr[n + 1] += ptr[n];
+    c->h_nadj.resize((size_t)ptr[NO]);
+    parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        {
+          const int64_t b = L.box_of_local[n];
+          const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+          int32_t *row = c->h_nadj.data() + ptr[n];
+          int deg = 0;
+          for (int o = 0; o < no; ++o)
+            {
+              const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+              if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+                continue;
+              row[deg++] = L.local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
+            }
+          std::sort(row, row + deg);
+        }
+    });
+  }
+
+  // Cartesian row tables from the CURRENT order of the node-graph rows (pfm_ctx_create: ascending local id;
+  // pfm_pattern_bind: the caller's order): nbr_mask[n] bit o = lattice offset o exists; the CSR slot of offset o is its
+  // rank among the existing offsets when the row is in lattice order, else row_perm[nadj_ptr[n] + rank] (bit 31 of the
+  // mask set).  Returns false when a row is not a lattice row (cannot happen for meshes detect_lattice accepts).
+  bool row_order_tables(const pfm_ctx *c, int dim, int32_t NO, const Lattice &L, std::vector<uint32_t> &mask,
+                        std::vector<uint8_t> &perm, bool &any_perm)
+  {
+    const int NX = L.NX, NY = L.NY, NZ = L.NZ, no = dim == 3 ? 27 : 9;
+    mask.assign((size_t)NO, 0u);
+    perm.clear();
+    std::vector<uint8_t> flagged((size_t)NO, 0);
+    std::atomic<bool> ok{true};
+    parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        {
+          const int64_t b = L.box_of_local[n];
+          const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+          const int32_t *row = c->h_nadj.data() + c->h_nadj_ptr[n];
+          const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
+          uint32_t mk = 0;
+          int rank = 0;
+          bool lattice_order = true;
+          for (int o = 0; o < no; ++o)
+            {
+              const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+              if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+                continue;
+              const int32_t q = L.local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
+              mk |= 1u << o;
+              if (rank >= deg || row[rank] != q)
+                lattice_order = false;
+              ++rank;
+            }
+          if (rank != deg)
+            ok = false;
+          mask[n] = mk | (lattice_order ? 0u : 0x80000000u);
+          flagged[n] = !lattice_order;
+        }
+    });
+    if (!ok)
+      return false;
+    any_perm = false;
+    for (int32_t n = 0; n < NO && !any_perm; ++n)
+      any_perm = flagged[n] != 0;
+    if (!any_perm)
+      return true;
+    perm.assign((size_t)c->h_nadj_ptr[NO], 0);
+    parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        {
+          if (!flagged[n])
+            continue;
+          const int64_t b = L.box_of_local[n];
+          const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+          const int32_t *row = c->h_nadj.data() + c->h_nadj_ptr[n];
+          const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
+          int rank = 0;
+          for (int o = 0; o < no; ++o)
+            {
+              const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+              if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+                continue;
+              const int32_t q = L.local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
+              const int32_t *p = std::find(row, row + deg, q);
+              if (p == row + deg)
+                ok = false;
+              perm[(size_t)c->h_nadj_ptr[n] + rank] = (uint8_t)(p - row);
+              ++rank;
+            }
+        }
+    });
+    return ok;
+  }
+
+  // upload (or replace) the device copies of the cartesian row tables
+  void upload_row_tables(pfm_ctx *c, const std::vector<uint32_t> &mask, const std::vector<uint8_t> &perm, bool any_perm)
+  {
+    CartView &cv = c->cv;
+    if (!cv.nbr_mask)
+      cv.nbr_mask = dev_alloc<uint32_t>(c, mask.size());
+    if (!mask.empty() && hipMemcpy(const_cast<uint32_t *>(cv.nbr_mask), mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+      throw HipFail{hipGetLastError(), "hipMemcpy nbr_mask"};
+    if (any_perm)
+      {
+        if (!c->d_row_perm)
+          c->d_row_perm = dev_alloc<uint8_t>(c, perm.size());
+        if (hipMemcpy(c->d_row_perm, perm.data(), perm.size(), hipMemcpyHostToDevice) != hipSuccess)
+          throw HipFail{hipGetLastError(), "hipMemcpy row_perm"};
+      }
+    cv.row_perm = any_perm ? c->d_row_perm : nullptr;
+  }
+
   // Build the fast-path tables of a lattice mesh.  Returns false (general path) whenever a
   // check fails; never an error.
   bool build_cart(pfm_ctx *c, const pfm_mesh_desc *m, const Lattice &L)
   {
-    const int dim = m->dim;
-    const int NX = L.NX, NY = L.NY, NZ = L.NZ;
+    const int NX = L.NX, NY = L.NY;
     const int32_t NO = m->n_owned_nodes;
-    const double *h = L.h;
-    const std::vector<int32_t> &local_of_box = L.local_of_box, &box_of_local = L.box_of_local;
+    const std::vector<int32_t> &box_of_local = L.box_of_local;
     // owned nodes must form a sub-box
     int o0[3] = {1 << 30, 1 << 30, 1 << 30}, o1[3] = {-1, -1, -1};
     for (int32_t n = 0; n < NO; ++n)
@@ -177,55 +365,23 @@ namespace
       return false;
     if ((int64_t)(o1[0] - o0[0] + 1) * (o1[1] - o0[1] + 1) * (o1[2] - o0[2] + 1) != NO)
       return false;
-    // CSR neighbour slot -> lattice offset index (dx+1) + 3*(dy+1) + 9*(dz+1)
-    const int no = dim == 3 ? 27 : 9;
-    std::vector<uint8_t> inv((size_t)NO * no, 0xff);
-    for (int32_t n = 0; n < NO; ++n)
-      {
-        const int64_t b = box_of_local[n];
-        const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
-        const int32_t *rb = c->h_nadj.data() + c->h_nadj_ptr[n];
-        const int32_t *re = c->h_nadj.data() + c->h_nadj_ptr[n + 1];
-        int found = 0;
-        for (int o = 0; o < no; ++o)
-          {
-            const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
-            if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
-              continue;
-            const int32_t q = local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
-            const int32_t *p = std::find(rb, re, q);
-            if (p == re)
-              continue; // neighbour not coupled through a local cell (cannot happen for owned rows)
-            inv[(size_t)n * no + (p - rb)] = (uint8_t)o;
-            ++found;
-          }
-        if (found != (int)(re - rb))
-          return false;
-      }
-    std::vector<uint32_t> nbr_mask((size_t)NO, 0); // bit o: the neighbour at lattice offset o exists in the row
-    for (int32_t n = 0; n < NO; ++n)
-      {
-        const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
-        for (int sl = 0; sl < deg; ++sl)
-          {
-            // rows are in lattice order (pfm_ctx_create): slot sl = rank of its offset among the existing ones
-            if (sl > 0 && inv[(size_t)n * no + sl] <= inv[(size_t)n * no + sl - 1])
-              return false;
-            nbr_mask[n] |= 1u << inv[(size_t)n * no + sl];
-          }
-      }
+    std::vector<uint32_t> mask;
+    std::vector<uint8_t> perm;
+    bool any_perm = false;
+    if (!row_order_tables(c, m->dim, NO, L, mask, perm, any_perm))
+      return false;
     CartView &cv = c->cv;
     cv.NX = NX;
     cv.NY = NY;
-    cv.NZ = NZ;
+    cv.NZ = L.NZ;
     for (int d = 0; d < 3; ++d)
       {
         cv.o0[d] = o0[d];
         cv.o1[d] = o1[d];
-        cv.h[d] = h[d];
+        cv.h[d] = L.h[d];
       }
-    cv.local_of_box = dev_upload(c, local_of_box.data(), local_of_box.size());
-    cv.nbr_mask = dev_upload(c, nbr_mask.data(), nbr_mask.size());
+    cv.local_of_box = dev_upload(c, L.local_of_box.data(), L.local_of_box.size());
+    upload_row_tables(c, mask, perm, any_perm);
     cv.owned_lex = 1;
     {
       const int64_t OWX = o1[0] - o0[0] + 1, OWY = o1[1] - o0[1] + 1;
@@ -300,7 +456,7 @@ extern "C"
       if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
         return fail(c, PFM_ERR_BAD_ARG, "cell_nodes out of range");
 
-    Lattice lattice;
+    Lattice &lattice = c->lat;
     bool lattice_ok = false;
     try
       {
@@ -320,89 +476,71 @@ extern "C"
                 return fail(c, PFM_ERR_BAD_ARG, "hanging table must be closed (parents unconstrained)");
           }
 
-        // ---- node graph over the constraint-resolved cells, rows = owned nodes
-        // pass 1: count cells incident to each owned node (through its own vertices and
-        // through hanging vertices it is a parent of)
-        auto for_each_resolved = [&](int64_t cell, auto &&fn) {
-          for (int a = 0; a < nv; ++a)
-            {
-              const int32_t n = m->cell_nodes[cell * nv + a];
-              const int32_t k = hn_index.empty() ? -1 : hn_index[n];
-              fn(n);
-              if (k >= 0)
-                for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
-                  fn(m->hn_parents[j]);
-            }
-        };
-        std::vector<int64_t> inc_ptr((size_t)NO + 1, 0);
-        for (int64_t cell = 0; cell < NC; ++cell)
-          for_each_resolved(cell, [&](int32_t n) {
-            if (n < NO)
-              ++inc_ptr[n + 1];
-          });
-        for (int32_t n = 0; n < NO; ++n)
-          inc_ptr[n + 1] += inc_ptr[n];
-        std::vector<int64_t> inc((size_t)inc_ptr[NO]);
-        {
-          std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
-          for (int64_t cell = 0; cell < NC; ++cell)
-            for_each_resolved(cell, [&](int32_t n) {
-              if (n < NO)
-                inc[fill[n]++] = cell;
-            });
-        }
-        // On a lattice the neighbours of a row are ordered by lattice offset (x fastest), not by local node id: a full
-        // row then has its 3^dim slots in the order the row-owner kernels produce them on EVERY rank (ghost nodes,
-        // which are numbered after the owned ones, would otherwise break the order next to partition faces).
+        // ---- node graph over the constraint-resolved cells, rows = owned nodes, columns ascending by local node id
+        // (ghost nodes, numbered after the owned ones, come last: the order of a host CSR sorted by local column id).
         lattice_ok = detect_lattice(m, lattice);
-        c->h_nadj_ptr.assign((size_t)NO + 1, 0);
-        std::vector<int32_t> &nadj = c->h_nadj;
-        nadj.clear();
-        nadj.reserve((size_t)NO * (dim == 2 ? 9 : 27));
-        std::vector<int32_t> tmp;
-        for (int32_t n = 0; n < NO; ++n)
+        if (lattice_ok)
+          lattice_graph(c, dim, NO, lattice);
+        else
           {
-            tmp.clear();
-            for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; ++k)
-              for_each_resolved(inc[k], [&](int32_t q) { tmp.push_back(q); });
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            if (lattice_ok)
-              {
-                const std::vector<int32_t> &bol = lattice.box_of_local;
-                std::sort(tmp.begin(), tmp.end(), [&](int32_t p, int32_t q) { return bol[p] < bol[q]; });
-              }
-            if (tmp.size() > 254)
-              return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
-            nadj.insert(nadj.end(), tmp.begin(), tmp.end());
-            c->h_nadj_ptr[n + 1] = (long long)nadj.size();
-          }
-        std::vector<int64_t>().swap(inc);
-
-        // ---- slot table: position of vertex b's node in the row of vertex a's node
-        std::vector<uint8_t> cslot((size_t)NC * nv * nv, 0xff);
-        for (int64_t cell = 0; cell < NC; ++cell)
-          for (int a = 0; a < nv; ++a)
-            {
-              const int32_t A = m->cell_nodes[cell * nv + a];
-              if (A >= NO)
-                continue;
-              const int32_t *rb = nadj.data() + c->h_nadj_ptr[A];
-              const int32_t *re = nadj.data() + c->h_nadj_ptr[A + 1];
-              for (int b = 0; b < nv; ++b)
+            // pass 1: count cells incident to each owned node (through its own vertices and through hanging
+            // vertices it is a parent of)
+            auto for_each_resolved = [&](int64_t cell, auto &&fn) {
+              for (int a = 0; a < nv; ++a)
                 {
-                  const int32_t B = m->cell_nodes[cell * nv + b];
-                  const int32_t *p = std::find(rb, re, B);
-                  cslot[(cell * nv + a) * nv + b] = (uint8_t)(p - rb);
+                  const int32_t n = m->cell_nodes[cell * nv + a];
+                  const int32_t k = hn_index.empty() ? -1 : hn_index[n];
+                  fn(n);
+                  if (k >= 0)
+                    for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
+                      fn(m->hn_parents[j]);
                 }
+            };
+            std::vector<int64_t> inc_ptr((size_t)NO + 1, 0);
+            for (int64_t cell = 0; cell < NC; ++cell)
+              for_each_resolved(cell, [&](int32_t n) {
+                if (n < NO)
+                  ++inc_ptr[n + 1];
+              });
+            for (int32_t n = 0; n < NO; ++n)
+              inc_ptr[n + 1] += inc_ptr[n];
+            std::vector<int64_t> inc((size_t)inc_ptr[NO]);
+            {
+              std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
+              for (int64_t cell = 0; cell < NC; ++cell)
+                for_each_resolved(cell, [&](int32_t n) {
+                  if (n < NO)
+                    inc[fill[n]++] = cell;
+                });
             }
+            c->h_nadj_ptr.assign((size_t)NO + 1, 0);
+            std::vector<int32_t> &nadj = c->h_nadj;
+            nadj.clear();
+            nadj.reserve((size_t)NO * (dim == 2 ? 9 : 27));
+            std::vector<int32_t> tmp;
+            for (int32_t n = 0; n < NO; ++n)
+              {
+                tmp.clear();
+                for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; ++k)
+                  for_each_resolved(inc[k], [&](int32_t q) { tmp.push_back(q); });
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                if (tmp.size() > 254)
+                  return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
+                nadj.insert(nadj.end(), tmp.begin(), tmp.end());
+                c->h_nadj_ptr[n + 1] = (long long)nadj.size();
+              }
+          }
+        std::vector<int32_t> &nadj = c->h_nadj;
 
         // ---- device mirrors (SoA)
         {
           std::vector<int32_t> conn((size_t)NC * nv);
-          for (int64_t cell = 0; cell < NC; ++cell)
-            for (int a = 0; a < nv; ++a)
-              conn[(size_t)a * NC + cell] = m->cell_nodes[cell * nv + a];
+          parallel_for(NC, [&](int64_t cb, int64_t ce) {
+            for (int64_t cell = cb; cell < ce; ++cell)
+              for (int a = 0; a < nv; ++a)
+                conn[(size_t)a * NC + cell] = m->cell_nodes[cell * nv + a];
+          });
           v.conn = dev_upload(c, conn.data(), conn.size());
         }
         {
@@ -420,7 +558,11 @@ extern "C"
           }
         v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
         v.nadj = dev_upload(c, nadj.data(), nadj.size());
-        v.cslot = dev_upload(c, cslot.data(), cslot.size());
+        // slot table of the general kernel family: position of vertex b's node in the row of vertex a's node,
+        // searched on the device (64 row searches per hex: 8 s on one host core at 1e7 cells)
+        v.cslot = dev_alloc<uint8_t>(c, (size_t)NC * nv * nv);
+        if (launch_build_cslot(v, nullptr) != PFM_OK)
+          throw HipFail{hipGetLastError(), "cslot kernel"};
         v.hn_index = nullptr;
         v.hn_ptr = nullptr;
         v.hn_parents = nullptr;
@@ -466,7 +608,11 @@ extern "C"
       }
     try
       {
-        c->cart_ok = lattice_ok && build_cart(c, m, lattice);
+        c->cart_ok = lattice_ok && !m->cell_lambda && !m->cell_mu && build_cart(c, m, lattice);
+        if (!c->cart_ok)
+          c->lat = Lattice{}; // the host lattice tables are only kept for pfm_pattern_bind on the cartesian path
+        if (hipDeviceSynchronize() != hipSuccess)
+          throw HipFail{hipGetLastError(), "context build"};
         c->d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
       }
     catch (const HipFail &f)
@@ -492,7 +638,8 @@ extern "C"
         if (p.d_recv)
           (void)hipFree(p.d_recv);
       }
-    for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr})
+    for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr,
+                    (void *)c->d_halo_send, (void *)c->d_halo_recv})
       if (q)
         (void)hipFree(q);
     if (c->side_stream)
@@ -533,8 +680,9 @@ extern "C"
   {
     if (!c || !p)
       return PFM_ERR_BAD_ARG;
-    if (c->v.dim == 3 && (p->decompose_stress_matrix > 0 || p->decompose_stress_rhs > 0) &&
-        p->timestep_number > 0)
+    // the reference gates the split on decompose_stress_matrix alone (cracks.cc:2294): decompose_stress_rhs > 0
+    // without it multiplies a zero stress_term_minus, i.e. is a plain assembly and valid in 3-D
+    if (c->v.dim == 3 && p->decompose_stress_matrix > 0 && p->timestep_number > 0)
       return fail(c, PFM_ERR_UNSUPPORTED,
                   "stress split is 2-D only in the reference (cracks.cc:1685-1690)");
     c->prm = *p;
@@ -597,6 +745,125 @@ extern "C"
           }
       }
     return PFM_OK;
+  }
+
+  // Adopt the caller's CSR pattern of one block.  The pattern must be the canonical one up to the order of the
+  // entries within a row, and that order must keep the structure (node, component): the ncc column components of a
+  // neighbour node adjacent and ascending -- what any CSR sorted by local column id has.  The node order of the rows
+  // becomes the order of the context's node graph: every kernel family addresses values through it.
+  static int pattern_bind_impl(pfm_ctx *c, int block, const int64_t *rp64, const int32_t *rp32, const int32_t *colind)
+  {
+    if (!c || block < 0 || block >= c->n_blocks || (!rp64 && !rp32) || !colind)
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    const int dim = c->v.dim;
+    int ncr, ncc;
+    if (c->v.layout == PFM_LAYOUT_INTERLEAVED)
+      ncr = ncc = dim + 1;
+    else
+      {
+        ncr = (block == 0 || block == 1) ? dim : 1;
+        ncc = (block == 0 || block == 2) ? dim : 1;
+      }
+    const int32_t NO = c->v.n_owned;
+    auto rp = [&](int64_t r) -> int64_t { return rp64 ? rp64[r] : (int64_t)rp32[r]; };
+    if (rp(0) != 0 || rp(c->block_rows(block)) != c->block_nnz(block))
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_pattern_bind: row pointers do not describe this block (size mismatch)");
+    std::vector<int32_t> order(c->h_nadj.size());
+    std::atomic<int> bad{0}; // 1: structure, 2: column set
+    std::atomic<bool> changed{false};
+    parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      std::vector<int32_t> a, b;
+      for (int64_t n = nb; n < ne && !bad; ++n)
+        {
+          const long long off = c->h_nadj_ptr[n];
+          const int deg = (int)(c->h_nadj_ptr[n + 1] - off);
+          for (int ci = 0; ci < ncr; ++ci)
+            {
+              const int64_t r = n * ncr + ci, b0 = rp(r);
+              if (rp(r + 1) - b0 != (int64_t)deg * ncc)
+                {
+                  bad = 1;
+                  return;
+                }
+              for (int sl = 0; sl < deg; ++sl)
+                {
+                  const int32_t col0 = colind[b0 + (int64_t)sl * ncc];
+                  const int32_t q = col0 / ncc;
+                  for (int d = 0; d < ncc; ++d)
+                    if (colind[b0 + (int64_t)sl * ncc + d] != q * ncc + d)
+                      {
+                        bad = 1;
+                        return;
+                      }
+                  if (ci == 0)
+                    order[off + sl] = q;
+                  else if (order[off + sl] != q)
+                    {
+                      bad = 1;
+                      return;
+                    }
+                }
+            }
+          a.assign(order.begin() + off, order.begin() + off + deg);
+          b.assign(c->h_nadj.begin() + off, c->h_nadj.begin() + off + deg);
+          if (a != b)
+            {
+              changed = true;
+              std::sort(a.begin(), a.end());
+              std::sort(b.begin(), b.end());
+              if (a != b)
+                {
+                  bad = 2;
+                  return;
+                }
+            }
+        }
+    });
+    if (bad == 1)
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_pattern_bind: rows must keep the (node, component) structure of the canonical pattern");
+    if (bad == 2)
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_pattern_bind: a row couples other nodes than the mesh does (see pfm_pattern_get)");
+    if (changed)
+      {
+        for (int b = 0; b < c->n_blocks; ++b)
+          if (b != block && c->pattern_bound[b])
+            return fail(c, PFM_ERR_UNSUPPORTED, "pfm_pattern_bind: all blocks must order the neighbour nodes of a row alike");
+        try
+          {
+            c->h_nadj.swap(order);
+            if (!c->h_nadj.empty() &&
+                hipMemcpy(const_cast<int32_t *>(c->v.nadj), c->h_nadj.data(), c->h_nadj.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+              throw HipFail{hipGetLastError(), "hipMemcpy nadj"};
+            if (launch_build_cslot(c->v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
+              throw HipFail{hipGetLastError(), "cslot kernel"};
+            if (c->cart_ok)
+              {
+                std::vector<uint32_t> mask;
+                std::vector<uint8_t> perm;
+                bool any_perm = false;
+                if (!row_order_tables(c, dim, NO, c->lat, mask, perm, any_perm))
+                  return fail(c, PFM_ERR_BAD_ARG, "pfm_pattern_bind: lattice rows inconsistent");
+                upload_row_tables(c, mask, perm, any_perm);
+              }
+          }
+        catch (const HipFail &f)
+          {
+            return hipfail(c, f.e, f.what);
+          }
+      }
+    c->pattern_bound[block] = true;
+    return PFM_OK;
+  }
+
+  int pfm_pattern_bind(pfm_ctx *c, int block, const int64_t *rowptr, const int32_t *colind)
+  {
+    return pattern_bind_impl(c, block, rowptr, nullptr, colind);
+  }
+
+  int pfm_pattern_bind_i32(pfm_ctx *c, int block, const int32_t *rowptr, const int32_t *colind)
+  {
+    return pattern_bind_impl(c, block, nullptr, rowptr, colind);
   }
 
   int pfm_state_set(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
@@ -682,6 +949,12 @@ extern "C"
         (void)hipFree(q);
     c->d_send_all = c->d_recv_all = nullptr;
     c->d_send_ptr = c->d_recv_ptr = nullptr;
+    for (double **q : {&c->d_halo_send, &c->d_halo_recv})
+      if (*q)
+        {
+          (void)hipFree(*q);
+          *q = nullptr;
+        }
     c->n_send_all = n_peers ? send_ptr[n_peers] - send_ptr[0] : 0;
     c->n_recv_all = n_peers ? recv_ptr[n_peers] - recv_ptr[0] : 0;
     if (n_peers > 0)
@@ -746,6 +1019,86 @@ extern "C"
     return launch_halo_unpack(c->v, c->peers[peer].d_recv, c->peers[peer].n_recv, d_buf, c->stream);
   }
 
+  // ---- ghost import over RCCL inside the library (include/pfm_assemble.h)
+  static_assert(sizeof(ncclUniqueId) == PFM_COMM_ID_BYTES, "PFM_COMM_ID_BYTES must match ncclUniqueId");
+
+  int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES])
+  {
+    if (!id)
+      return PFM_ERR_BAD_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess)
+      return PFM_ERR_COMM;
+    memcpy(id, &u, sizeof(u));
+    return PFM_OK;
+  }
+
+  int pfm_comm_create(void **comm, const uint8_t id[PFM_COMM_ID_BYTES], int n_ranks, int rank, int device)
+  {
+    if (!comm || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+      return PFM_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess)
+      return PFM_ERR_HIP;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t cm = nullptr;
+    if (ncclCommInitRank(&cm, n_ranks, u, rank) != ncclSuccess)
+      return PFM_ERR_COMM;
+    *comm = cm;
+    return PFM_OK;
+  }
+
+  int pfm_comm_destroy(void *comm)
+  {
+    if (!comm)
+      return PFM_OK;
+    return ncclCommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? PFM_OK : PFM_ERR_COMM;
+  }
+
+  int pfm_halo_exchange(pfm_ctx *c, void *comm, const int *peer_ranks)
+  {
+    if (!c || (!c->peers.empty() && (!comm || !peer_ranks)))
+      return PFM_ERR_BAD_ARG;
+    if (c->peers.empty())
+      return PFM_OK;
+    (void)hipSetDevice(c->device);
+    const int rec = PFM_HALO_DOUBLES_PER_NODE(c->v.dim);
+    if (!c->d_halo_send)
+      {
+        hipError_t e = hipMalloc((void **)&c->d_halo_send, std::max<size_t>(8, sizeof(double) * rec * c->n_send_all));
+        if (e == hipSuccess)
+          e = hipMalloc((void **)&c->d_halo_recv, std::max<size_t>(8, sizeof(double) * rec * c->n_recv_all));
+        if (e != hipSuccess)
+          return hipfail(c, e, "hipMalloc halo buffers");
+        c->device_bytes += (int64_t)sizeof(double) * rec * (c->n_send_all + c->n_recv_all);
+      }
+    int rc = pfm_halo_pack_all(c, c->d_halo_send);
+    if (rc)
+      return fail(c, rc, "halo pack launch failed");
+    ncclComm_t cm = static_cast<ncclComm_t>(comm);
+    ncclResult_t r = ncclGroupStart();
+    int64_t so = 0, ro = 0;
+    for (size_t k = 0; k < c->peers.size() && r == ncclSuccess; ++k)
+      {
+        const HaloPeer &p = c->peers[k];
+        if (p.n_recv)
+          r = ncclRecv(c->d_halo_recv + rec * ro, (size_t)(rec * p.n_recv), ncclDouble, peer_ranks[k], cm, c->stream);
+        if (p.n_send && r == ncclSuccess)
+          r = ncclSend(c->d_halo_send + rec * so, (size_t)(rec * p.n_send), ncclDouble, peer_ranks[k], cm, c->stream);
+        so += p.n_send;
+        ro += p.n_recv;
+      }
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r == ncclSuccess)
+      r = r2;
+    if (r != ncclSuccess)
+      return fail(c, PFM_ERR_COMM, std::string("RCCL: ") + ncclGetErrorString(r));
+    rc = pfm_halo_unpack_all(c, c->d_halo_recv);
+    if (rc)
+      return fail(c, rc, "halo unpack launch failed");
+    return PFM_OK;
+  }
+
   int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values,
                           double *d_res_pde, double *d_res_tot)
   {
@@ -757,8 +1110,7 @@ extern "C"
       return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
     (void)hipSetDevice(c->device);
     hipError_t e = hipSuccess;
-    const bool split = (c->prm.decompose_stress_matrix > 0 || c->prm.decompose_stress_rhs > 0) &&
-                       c->prm.timestep_number > 0;
+    const bool split = c->prm.decompose_stress_matrix > 0 && c->prm.timestep_number > 0; // cracks.cc:2294
     const bool cart = c->kernel_path == 1 && !split && (residual_only || cart_matrix_supported(c->v.dim));
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -862,11 +1214,22 @@ extern "C"
     if (st != 0)
       {
         (void)hipMemsetAsync(c->v.status, 0, sizeof(int), c->stream);
-        return fail(c, st, st == PFM_ERR_NOT_ORTHOGONAL
-                             ? "eigenvectors not orthogonal (cracks.cc:1732-1736)"
-                             : "device-side error");
+        return fail(c, st, st == PFM_ERR_NOT_ORTHOGONAL ? "eigenvectors not orthogonal (cracks.cc:1732-1736)"
+                           : st == PFM_ERR_NONFINITE    ? "non-finite value (pfm_check_finite)"
+                                                        : "device-side error");
       }
     return PFM_OK;
+  }
+
+  int pfm_check_finite(pfm_ctx *c, const double *d_data, int64_t n)
+  {
+    if (!c || n < 0 || (n > 0 && !d_data))
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    const int rc = launch_check_finite(c->v, d_data, n, c->stream);
+    if (rc)
+      return fail(c, rc, "check_finite launch failed");
+    return pfm_sync_status(c);
   }
 
   int pfm_assemble(pfm_ctx *c, const double *sol, const double *old, const double *oldold,

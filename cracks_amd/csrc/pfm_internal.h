@@ -41,9 +41,20 @@ namespace pfm
     int o0[3], o1[3];
     double h[3];
     const int32_t *local_of_box; // [NX*NY*NZ] lattice index -> local node id
-    const uint32_t *nbr_mask;    // [n_owned] bit o: lattice offset o exists in the row; rows are in lattice order, so
-                                 // the CSR slot of offset o is popcount(mask & ((1 << o) - 1))
+    const uint32_t *nbr_mask;    // [n_owned] bit o (o < 27): lattice offset o exists in the row.  Bit 31 clear: the row
+                                 // is in lattice order, the CSR slot of offset o is popcount(mask & ((1 << o) - 1))
     int owned_lex;               // 1: owned node (i,j,k) has local id (i-o0x) + OWX*((j-o0y) + OWY*(k-o0z))
+    const uint8_t *row_perm;     // rows whose order is not the lattice order (bit 31 of nbr_mask: e.g. ghost columns
+                                 // sorted behind the owned ones): CSR slot of the r-th existing offset =
+                                 // row_perm[nadj_ptr[row] + r]; nullptr when no row needs it
+  };
+
+  // host copy of the lattice tables of a uniform box (kept for pfm_pattern_bind)
+  struct LatticeHost
+  {
+    int NX = 0, NY = 0, NZ = 0, nc[3] = {0, 0, 0};
+    double h[3] = {1, 1, 1};
+    std::vector<int32_t> local_of_box, box_of_local;
   };
 
   struct HaloPeer
@@ -55,6 +66,9 @@ namespace pfm
   // launchers implemented in pfm_kernels.hip
   int launch_state_set(const DevView &v, const double *d_sol, const double *d_old,
                        const double *d_oldold, hipStream_t s);
+  // fills v.cslot from the current order of the node-graph rows (context creation, pfm_pattern_bind)
+  int launch_build_cslot(const DevView &v, hipStream_t s);
+  int launch_check_finite(const DevView &v, const double *d, int64_t n, hipStream_t s);
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
   // all peers at once: d_nodes = concatenated lists, d_ptr[n_peers + 1] = their offsets (device)
   int launch_halo_all(const DevView &v, const int32_t *d_nodes, const long long *d_ptr, int n_peers, int64_t n_total,
@@ -119,13 +133,18 @@ struct pfm_ctx
   int32_t *d_send_all = nullptr, *d_recv_all = nullptr; // concatenated halo lists and their per-peer offsets
   long long *d_send_ptr = nullptr, *d_recv_ptr = nullptr;
   int64_t n_send_all = 0, n_recv_all = 0;
+  double *d_halo_send = nullptr, *d_halo_recv = nullptr; // message buffers of pfm_halo_exchange
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
+  uint8_t *d_row_perm = nullptr; // CartView::row_perm storage (in allocs)
+  pfm::LatticeHost lat;          // host lattice tables (cartesian path only)
+  bool pattern_bound[4] = {false, false, false, false};
   bool scal_dirty = true; // d_scal does not hold the tables of the current parameters yet
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;
   double *d_partial = nullptr;
   int64_t n_partial = 0;
   uint8_t *d_cell_owned = nullptr;
+  double *d_func_mat = nullptr; // per-cell Lame override of pfm_functionals_material
   // measurement (pfm_timing_enable)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

@@ -16,6 +16,7 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 namespace pfm
 {
@@ -138,19 +139,15 @@ namespace pfm
       return c < dim ? (long long)P * dim + c : (long long)v.n_owned * dim + P;
     }
 
+    // position of node Q in the row of node P; the rows carry the order of the bound pattern (ascending local id
+    // unless pfm_pattern_bind gave another one), so the search is linear (used for hanging-node parents only)
     __device__ __forceinline__ int find_slot(const DevView &v, int P, int Q)
     {
-      long long lo = v.nadj_ptr[P], hi = v.nadj_ptr[P + 1];
-      const long long base = lo;
-      while (lo < hi)
-        {
-          const long long mid = (lo + hi) >> 1;
-          if (v.nadj[mid] < Q)
-            lo = mid + 1;
-          else
-            hi = mid;
-        }
-      return (int)(lo - base);
+      const long long lo = v.nadj_ptr[P], hi = v.nadj_ptr[P + 1];
+      long long k = lo;
+      while (k < hi && v.nadj[k] != Q)
+        ++k;
+      return (int)(k - lo);
     }
 
     __device__ __forceinline__ void atomic_add(double *p, double x)
@@ -800,6 +797,48 @@ namespace pfm
         }
     }
 
+    // slot table of the general family: cslot[cell][a][b] = position of vertex b's node in the row of vertex a's node
+    // (0xff: a is not an owned node, or b is not in the row).  thread <-> (cell, a)
+    template <int dim>
+    __global__ void k_build_cslot(DevView v, uint8_t *__restrict__ cslot)
+    {
+      constexpr int nv = 1 << dim;
+      const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (idx >= v.n_cells * nv)
+        return;
+      const long long cell = idx / nv;
+      const int a = (int)(idx % nv);
+      const int A = v.conn[(long long)a * v.n_cells + cell];
+      uint8_t *out = cslot + idx * nv;
+      if (A >= v.n_owned)
+        {
+#pragma unroll
+          for (int b = 0; b < nv; ++b)
+            out[b] = 0xff;
+          return;
+        }
+      const long long lo = v.nadj_ptr[A], hi = v.nadj_ptr[A + 1];
+#pragma unroll
+      for (int b = 0; b < nv; ++b)
+        {
+          const int B = v.conn[(long long)b * v.n_cells + cell];
+          long long k = lo;
+          while (k < hi && v.nadj[k] != B)
+            ++k;
+          out[b] = k < hi ? (uint8_t)(k - lo) : (uint8_t)0xff;
+        }
+    }
+
+    // raises PFM_ERR_NONFINITE in the context's status word if any of the n values is NaN or +-Inf
+    __global__ void k_check_finite(const double *__restrict__ x, long long n, int *__restrict__ status)
+    {
+      bool bad = false;
+      for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        bad = bad || !isfinite(x[i]);
+      if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0)
+        atomicMax(status, (int)PFM_ERR_NONFINITE);
+    }
+
     bool g_tables_ready[16] = {};
 
     int ensure_tables()
@@ -830,6 +869,30 @@ namespace pfm
       hipLaunchKernelGGL(k_state_set<2>, dim3(nb), dim3(bs), 0, s, v, sol, old, oldold);
     else
       hipLaunchKernelGGL(k_state_set<3>, dim3(nb), dim3(bs), 0, s, v, sol, old, oldold);
+    return check_launch();
+  }
+
+  int launch_check_finite(const DevView &v, const double *d, int64_t n, hipStream_t s)
+  {
+    if (n <= 0)
+      return PFM_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_check_finite, dim3(nb), dim3(256), 0, s, d, (long long)n, v.status);
+    return check_launch();
+  }
+
+  int launch_build_cslot(const DevView &v, hipStream_t s)
+  {
+    const int nv = 1 << v.dim;
+    const long long n = v.n_cells * nv;
+    if (n == 0)
+      return PFM_OK;
+    const int bs = 256;
+    const unsigned nb = (unsigned)((n + bs - 1) / bs);
+    if (v.dim == 2)
+      hipLaunchKernelGGL(k_build_cslot<2>, dim3(nb), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot));
+    else
+      hipLaunchKernelGGL(k_build_cslot<3>, dim3(nb), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot));
     return check_launch();
   }
 

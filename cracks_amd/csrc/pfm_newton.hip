@@ -159,6 +159,7 @@ namespace pfm
     // ---- energies and total crack volume: thread <-> cell, QGauss(3)^dim, MappingQ1; fixed-order reduction
     template <int dim>
     __global__ __launch_bounds__(256) void k_functionals(DevView v, pfm_params prm, const uint8_t *__restrict__ cell_owned,
+                                                         const double *__restrict__ lam_over, const double *__restrict__ mu_over,
                                                          double *__restrict__ partial /* [gridDim.x][3] */)
     {
       constexpr int nv = 1 << dim, nq = dim == 2 ? 9 : 27;
@@ -181,8 +182,8 @@ namespace pfm
                 }
               PH[b] = v.phi[n];
             }
-          const double lam = v.cell_lambda ? v.cell_lambda[cell] : prm.lambda;
-          const double mu = v.cell_mu ? v.cell_mu[cell] : prm.mu;
+          const double lam = lam_over ? lam_over[cell] : (v.cell_lambda ? v.cell_lambda[cell] : prm.lambda);
+          const double mu = mu_over ? mu_over[cell] : (v.cell_mu ? v.cell_mu[cell] : prm.mu);
 #pragma unroll 1
           for (int q = 0; q < nq; ++q)
             {
@@ -389,15 +390,17 @@ extern "C"
       }
     if (hipMemsetAsync(c->d_counts, 0, 3 * sizeof(unsigned long long), c->stream) != hipSuccess)
       return fail(c, PFM_ERR_HIP, "counts memset");
-    const unsigned nb = (unsigned)((c->v.n_owned + 255) / 256);
+    const unsigned nb = (unsigned)((c->v.n_owned + 255) / 256); // 0 on a rank that owns no node: nothing to launch
     uint8_t *flags = const_cast<uint8_t *>(c->v.node_flags);
-    if (c->v.dim == 2)
+    if (nb == 0)
+      ;
+    else if (c->v.dim == 2)
       hipLaunchKernelGGL(k_active_set<2>, dim3(nb), dim3(256), 0, c->stream, c->v, flags, d_residual_total, d_mass, c_const,
                          d_solution, d_old_solution, d_cycle_counter, c->d_counts);
     else
       hipLaunchKernelGGL(k_active_set<3>, dim3(nb), dim3(256), 0, c->stream, c->v, flags, d_residual_total, d_mass, c_const,
                          d_solution, d_old_solution, d_cycle_counter, c->d_counts);
-    if (c->v.hn_index)
+    if (c->v.hn_index && nb)
       {
         // we might have changed values of the solution, so fix the hanging nodes (cracks.cc:2888-2890)
         const long long n = (long long)c->v.n_owned * (c->v.dim + 1);
@@ -432,7 +435,13 @@ extern "C"
 
   int pfm_functionals(pfm_ctx *c, const uint8_t *cell_owned, double *out)
   {
-    if (!c || !out)
+    return pfm_functionals_material(c, cell_owned, nullptr, nullptr, out);
+  }
+
+  int pfm_functionals_material(pfm_ctx *c, const uint8_t *cell_owned, const double *cell_lambda, const double *cell_mu,
+                               double *out)
+  {
+    if (!c || !out || ((cell_lambda == nullptr) != (cell_mu == nullptr)))
       return PFM_ERR_BAD_ARG;
     if (!c->have_params)
       return fail(c, PFM_ERR_BAD_ARG, "pfm_set_params has not been called");
@@ -460,13 +469,28 @@ extern "C"
           return fail(c, PFM_ERR_HIP, "cell mask upload");
         d_owned = c->d_cell_owned;
       }
+    double *d_lam = nullptr, *d_mu = nullptr;
+    if (cell_lambda && c->v.n_cells > 0)
+      {
+        if (!c->d_func_mat)
+          {
+            if (hipMalloc((void **)&c->d_func_mat, 2 * sizeof(double) * (size_t)c->v.n_cells) != hipSuccess)
+              return fail(c, PFM_ERR_NOMEM, "hipMalloc material override");
+            c->allocs.push_back(c->d_func_mat);
+          }
+        d_lam = c->d_func_mat;
+        d_mu = c->d_func_mat + c->v.n_cells;
+        if (hipMemcpyAsync(d_lam, cell_lambda, sizeof(double) * (size_t)c->v.n_cells, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(d_mu, cell_mu, sizeof(double) * (size_t)c->v.n_cells, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+          return fail(c, PFM_ERR_HIP, "material override upload");
+      }
     double *d_out = c->d_partial + 3 * (size_t)nb;
     if (nb)
       {
         if (c->v.dim == 2)
-          hipLaunchKernelGGL(k_functionals<2>, dim3(nb), dim3(256), 0, c->stream, c->v, c->prm, d_owned, c->d_partial);
+          hipLaunchKernelGGL(k_functionals<2>, dim3(nb), dim3(256), 0, c->stream, c->v, c->prm, d_owned, d_lam, d_mu, c->d_partial);
         else
-          hipLaunchKernelGGL(k_functionals<3>, dim3(nb), dim3(256), 0, c->stream, c->v, c->prm, d_owned, c->d_partial);
+          hipLaunchKernelGGL(k_functionals<3>, dim3(nb), dim3(256), 0, c->stream, c->v, c->prm, d_owned, d_lam, d_mu, c->d_partial);
       }
     hipLaunchKernelGGL(k_reduce3, dim3(1), dim3(256), 0, c->stream, c->d_partial, (long long)nb, d_out);
     if (hipGetLastError() != hipSuccess)

@@ -5,11 +5,19 @@ Import => MPI point-to-point).  Pattern = neighbour halo exchange, not a reducti
 peer one packed message of ``(dim+3)`` doubles per interface node (u, phi, phi_old,
 phi_oldold), all peers posted together with ``batch_isend_irecv`` so that every xGMI link
 of the GPU carries its own pair concurrently.  Packing/unpacking are HIP kernels behind
-the C ABI (``pfm_halo_pack_all`` / ``pfm_halo_unpack_all``: one launch each for all peers); ``torch.distributed`` (backend
-``nccl`` = RCCL on ROCm, ``gloo`` in the CPU tests) only moves the buffers.
+the C ABI (``pfm_halo_pack_all`` / ``pfm_halo_unpack_all``: one launch each for all peers).
+
+Transport.  With one GPU per rank (``torch.distributed`` backend ``nccl``) the whole exchange is ONE library call,
+``pfm_halo_exchange``: pack -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd -> unpack on the context's stream,
+on a communicator the library creates (``pfm_comm_create``; torch.distributed only broadcasts the 128-byte unique id).
+That is the code path a C++ host (the deal.II application, no torch) uses.  ``PFM_HALO_TORCH=1`` moves the buffers with
+``torch.distributed.batch_isend_irecv`` instead; ``gloo`` (CPU tests, single-GPU smoke runs) always does, staging
+device buffers through the host.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Callable, List, Sequence
 
 import numpy as np
@@ -43,6 +51,11 @@ class HaloExchange:
         # gloo moves host memory only: device buffers are staged through the host (smoke tests of the multi-process
         # flow on a box without one GPU per rank; the product path is backend "nccl" = RCCL, device to device)
         self._stage_host = self.send_all.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        # in-library RCCL transport (pfm_halo_exchange) whenever every rank has its own GPU
+        self._use_lib = (self.send_all.is_cuda and dist.is_initialized() and dist.get_backend(group) == "nccl"
+                         and os.environ.get("PFM_HALO_TORCH") != "1")
+        self._comm = None
+        self._comm_lib = None
 
     @property
     def bytes_per_exchange(self) -> int:
@@ -78,10 +91,41 @@ class HaloExchange:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
+    def _ensure_comm(self, ctx):
+        """ncclCommInitRank through the C ABI; torch.distributed only carries the unique id to the other ranks."""
+        if self._comm is not None:
+            return
+        torch, dist = self.torch, self.dist
+        from . import capi
+
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        uid = np.zeros(capi.COMM_ID_BYTES, np.uint8)
+        if rank == 0:
+            rc = ctx.lib.pfm_comm_unique_id(capi.np_ptr(uid, np.uint8))
+            if rc != capi.PFM_OK:
+                raise capi.PfmError(rc, "pfm_comm_unique_id")
+        t = torch.from_numpy(uid).to(self.send_all.device)
+        dist.broadcast(t, 0, group=self.group)
+        uid = np.ascontiguousarray(t.cpu().numpy())
+        h = C.c_void_p()
+        rc = ctx.lib.pfm_comm_create(C.byref(h), capi.np_ptr(uid, np.uint8), world, rank, self.send_all.device.index)
+        if rc != capi.PFM_OK:
+            raise capi.PfmError(rc, "pfm_comm_create")
+        self._comm, self._comm_lib = h, ctx.lib
+
+    def close(self):
+        if self._comm is not None:
+            self._comm_lib.pfm_comm_destroy(self._comm)
+            self._comm = None
+
     def exchange(self, ctx):
         """pack (HIP) -> RCCL send/recv -> unpack (HIP), all on torch's current stream."""
         if self._registered is not ctx:
             self.register(ctx)
+        if self._use_lib:
+            self._ensure_comm(ctx)
+            ctx.halo_exchange(self._comm.value, self.peers)
+            return
         if self.send_all.numel():
             ctx.halo_pack_all(self.send_all.data_ptr())  # one launch for all peers
         self._post()

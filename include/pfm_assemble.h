@@ -23,12 +23,12 @@
  * numberings (cracks.cc:1587-1590):
  *   PFM_LAYOUT_INTERLEAVED  one block,  dof = node*(dim+1)+comp      (direct solver)
  *   PFM_LAYOUT_BLOCKED      [u | phi],  u dof = node*dim+comp, phi dof = n_owned*dim+node
- * Matrix values are CSR, rows = owned dofs, sorted columns in the rank-local numbering
- * (ghost columns included), full component coupling (cracks.cc:1644-1654):
+ * Matrix values are CSR, rows = owned dofs, columns in the rank-local numbering (ghost columns
+ * included), ascending within a row unless pfm_pattern_bind() adopted another order from the host;
+ * full component coupling (cracks.cc:1644-1654):
  *   INTERLEAVED: block 0 only;   BLOCKED: 0 = (u,u), 1 = (u,phi), 2 = (phi,u), 3 = (phi,phi)
  * The pattern is the node graph of the constraint-resolved mesh tensor the component
- * coupling; pfm_pattern_get() returns it so the caller can check it against (or build)
- * its Trilinos pattern.
+ * coupling; pfm_pattern_get() returns it, pfm_pattern_bind() adopts the host's own arrays.
  */
 #ifndef PFM_ASSEMBLE_H
 #define PFM_ASSEMBLE_H
@@ -46,9 +46,10 @@ typedef enum pfm_status
   PFM_ERR_BAD_ARG = 1,
   PFM_ERR_HIP = 2,            /* a HIP runtime call failed; pfm_last_error() has the text */
   PFM_ERR_NOT_ORTHOGONAL = 3, /* eigenvector sanity check failed (reference abort(), cracks.cc:1732-1736) */
-  PFM_ERR_NONFINITE = 4,      /* non-finite value in an output (only checked on request) */
+  PFM_ERR_NONFINITE = 4,      /* non-finite value in an output (checked by pfm_check_finite only) */
   PFM_ERR_UNSUPPORTED = 5,    /* e.g. stress split in 3-D (reference is 2-D only, cracks.cc:1685-1690) */
-  PFM_ERR_NOMEM = 6
+  PFM_ERR_NOMEM = 6,
+  PFM_ERR_COMM = 7            /* an RCCL call failed; pfm_last_error() has the text */
 } pfm_status;
 
 enum
@@ -109,8 +110,20 @@ int pfm_set_constraints(pfm_ctx *ctx, const uint8_t *node_flags /* host, [n_node
 
 /* -- matrix pattern ------------------------------------------------------------------- */
 int pfm_pattern_size(const pfm_ctx *ctx, int block, int64_t *n_rows, int64_t *nnz);
-/* host outputs: rowptr[n_rows+1], colind[nnz] */
+/* host outputs: rowptr[n_rows+1], colind[nnz]: the pattern the value arrays of pfm_assemble_device follow.  After
+ * pfm_ctx_create the columns of every row ascend by local id (owned columns first, ghost columns last): the layout of
+ * a host CSR sorted by local column index, e.g. an Epetra_CrsMatrix after FillComplete with optimised storage. */
 int pfm_pattern_get(const pfm_ctx *ctx, int block, int64_t *rowptr, int32_t *colind);
+/* Bind the HOST's pattern of `block` (make_sparsity_pattern + reinit, cracks.cc:1644-1654; the arrays
+ * Epetra_CrsMatrix::ExtractCrsDataPointers returns): from now on the value arrays handed to the assembly are laid
+ * out exactly like the host's values[] -- the library borrows the host's CSR, it does not dictate one.  The arrays are
+ * read during the call only.  Requirements (checked, PFM_ERR_BAD_ARG otherwise): same rows and the same set of
+ * columns per row as pfm_pattern_get (the node graph of the constraint-resolved mesh, full component coupling); within a
+ * row the entries of one neighbour node adjacent with ascending component.  Any order of the neighbour nodes is
+ * accepted, but all blocks must use the same one (PFM_ERR_UNSUPPORTED).  Binding a pattern that already has the
+ * library's order is a pure check.  _i32: 32-bit row pointers (Epetra's int offsets). */
+int pfm_pattern_bind(pfm_ctx *ctx, int block, const int64_t *rowptr, const int32_t *colind);
+int pfm_pattern_bind_i32(pfm_ctx *ctx, int block, const int32_t *rowptr, const int32_t *colind);
 
 /* -- state: the three vectors read at cracks.cc:2147-2154 ----------------------------- */
 /* Scatter the OWNED dofs of solution / old_solution / old_old_solution (dof vectors in the
@@ -134,6 +147,21 @@ int pfm_halo_unpack(pfm_ctx *ctx, int peer, const double *d_buf); /* device buff
 int pfm_halo_pack_all(pfm_ctx *ctx, double *d_buf_all);
 int pfm_halo_unpack_all(pfm_ctx *ctx, const double *d_buf_all);
 
+/* The whole ghost import inside the library, for hosts without torch (the deal.II application): RCCL point-to-point
+ * over xGMI in place of the Trilinos/MPI import of cracks.cc:2147-2154.
+ *   pfm_comm_unique_id   ncclGetUniqueId on one rank; the host broadcasts the bytes (MPI_Bcast in the reference's world)
+ *   pfm_comm_create      ncclCommInitRank: collective over the n_ranks processes, one GPU each
+ *   pfm_halo_exchange    pack (one launch) -> ncclGroupStart, ncclSend/ncclRecv per peer, ncclGroupEnd -> unpack (one
+ *                        launch), all asynchronous on the context's stream, into buffers the context owns;
+ *                        peer_ranks[k] = communicator rank of peer k of pfm_halo_register.  `comm` is an ncclComm_t:
+ *                        one made by pfm_comm_create or the host's own.  Collective: every rank of the communicator
+ *                        that is somebody's peer must call it. */
+#define PFM_COMM_ID_BYTES 128
+int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES]);
+int pfm_comm_create(void **comm, const uint8_t id[PFM_COMM_ID_BYTES], int n_ranks, int rank, int device);
+int pfm_comm_destroy(void *comm);
+int pfm_halo_exchange(pfm_ctx *ctx, void *comm, const int *peer_ranks /* host, [n_peers] */);
+
 /* -- the hot path --------------------------------------------------------------------- */
 /* assemble_system(residual_only) on the current state.  Output pointers are DEVICE
  * pointers; the call is asynchronous on the context's stream.
@@ -150,6 +178,12 @@ int pfm_assemble_device(pfm_ctx *ctx, int residual_only, double *const *d_values
 /* Blocks until the stream is idle and returns the deferred status of the launches since
  * the last call (PFM_ERR_NOT_ORTHOGONAL, PFM_ERR_HIP, ...). */
 int pfm_sync_status(pfm_ctx *ctx);
+
+/* On request: scan n doubles of a device array (an assembled residual or value block) for NaN / Inf.  Returns
+ * PFM_ERR_NONFINITE if there is one, else whatever pfm_sync_status() would return.  The assembly itself never checks:
+ * like the reference it lets IEEE specials propagate (e.g. the stress split at diagonal or zero strain,
+ * cracks.cc:1982-2006). */
+int pfm_check_finite(pfm_ctx *ctx, const double *d_data, int64_t n);
 
 /* Synchronous host-pointer convenience = pfm_state_set + pfm_assemble_device + copies back
  * + pfm_sync_status: the exact call shape of the reference (outputs complete in host memory

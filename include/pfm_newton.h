@@ -52,6 +52,13 @@ int pfm_get_constraints(pfm_ctx *ctx, uint8_t *node_flags);
  * part of the sums (the caller adds the ranks, Utilities::MPI::sum, cracks.cc:3590, 3685-3686).
  * Deterministic two-stage reduction; synchronous, out is a host pointer. */
 int pfm_functionals(pfm_ctx *ctx, const uint8_t *cell_owned, double out[3]);
+/* The same with the Lame coefficients of the energy given per cell (host arrays [n_cells]; both NULL = the context's,
+ * i.e. pfm_functionals).  Needed for the reference's heterogeneous test case: assemble_system adds 1.0 to the
+ * Young's modulus read from the bitmap (cracks.cc:2209-2210) but compute_energy does not (cracks.cc:3649-3657), so
+ * the energy is NOT evaluated with the coefficients the assembly uses; a caller that wants the reference's
+ * statistics passes the un-shifted ones here. */
+int pfm_functionals_material(pfm_ctx *ctx, const uint8_t *cell_owned, const double *cell_lambda, const double *cell_mu,
+                             double out[3]);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def _declared_symbols():
     for header in ("pfm_assemble.h", "pfm_newton.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names |= set(re.findall(r"\b(pfm_[a-z_]+)\s*\(", text))
+        names |= set(re.findall(r"\b(pfm_[a-z0-9_]+)\s*\(", text))
     return sorted(names)
 
 

@@ -1,0 +1,286 @@
+"""The boundary binds to the HOST's CSR storage (SURVEY.md §8(b) "Host owns CSR arrays", cracks.cc:1644-1654):
+
+* after pfm_ctx_create the columns of every row ascend by local id (ghost columns last), so the value arrays land in
+  an Epetra-ordered values[] as they are -- checked on 2- and 8-rank sub-boxes against the oracle WITHOUT any
+  re-sorting of the library's output;
+* pfm_pattern_bind adopts an arbitrary node order of the host's rows (cartesian and general kernel family, both
+  layouts, hanging nodes), rejects patterns of another mesh and blocks that disagree with each other;
+* a lattice whose nodes are not numbered lexicographically still assembles correctly (blocked fast copy-out).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cases
+import oracle_api as O
+from cracks_amd import capi
+from cracks_amd import mesh as M
+from cracks_amd import partition as P
+from cracks_amd.assembler import Context, node_flags_from_dof_flags
+from gpu_util import make_context
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _oracle_matrix(mesh, lay, prm, sol, old, oo, cu, ch):
+    rp, ci = M.dof_sparsity(mesh, lay)
+    r = O.assemble(mesh, lay, prm, sol, old, oo, cu, ch, False, rp, ci)
+    assert r.err == 0
+    return sp.csr_matrix((r.values, ci, rp), shape=(lay.n_dofs,) * 2), r.residual_pde
+
+
+def _block_dims(dim, blocked, b):
+    if not blocked:
+        return dim + 1, dim + 1
+    return (dim if b in (0, 1) else 1), (dim if b in (0, 2) else 1)
+
+
+def _fill_ghosts(ctx, lp, dim, u, phi, po, poo):
+    """Ghost import without a transport: the message every peer would send, written on the host in the packed layout
+    of pfm_halo_pack_all (per peer: field-major u[dim], phi, phi_old, phi_oldold) and unpacked by the HIP kernel."""
+    import torch
+
+    ctx.halo_register(lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes)
+    rec = dim + 3
+    buf = np.zeros(int(lp.recv_ptr[-1]) * rec)
+    for k in range(len(lp.peers)):
+        a, b = int(lp.recv_ptr[k]), int(lp.recv_ptr[k + 1])
+        g = lp.global_ids[lp.recv_nodes[a:b]]
+        n = b - a
+        msg = np.concatenate([u[g, d] for d in range(dim)] + [phi[g], po[g], poo[g]])
+        buf[rec * a:rec * a + rec * n] = msg
+    t = torch.from_numpy(buf).cuda()
+    if t.numel():
+        ctx.halo_unpack_all(t.data_ptr())
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("path", [1, 0])
+def test_partitioned_rows_land_in_a_column_sorted_host_csr(world, path):
+    """Every rank of a sub-box partition: columns ascending (owned first, ghosts last) in every row of every block, and
+    the value arrays -- taken exactly as the library wrote them, no sort_indices() -- equal the oracle's entries."""
+    import torch
+
+    dim, n = 3, (12, 11, 10)
+    g = M.box_mesh(dim, n)
+    h = g.min_cell_diameter()
+    lay = M.DofLayout(g.n_nodes, dim, blocked=True)
+    base = cases.perturbed(cases.kat_sneddon_3d(4))
+    prm = O.PfmParams.from_buffer_copy(bytes(base.params))
+    prm.alpha_eps, prm.constant_k = 2.0 * h, 1e-8 * h
+    rng = np.random.default_rng(5)
+    u = rng.uniform(-1e-3, 1e-3, (g.n_nodes, dim))
+    phi, po, poo = (rng.uniform(0.05, 0.95, g.n_nodes) for _ in range(3))
+    cu = M.update_constraints(g, lay, M.sneddon_dirichlet_dofs(g, lay))
+    ch = M.hanging_constraints(g, lay)
+    node, comp = lay.node_comp_of_dof()
+    u[cu.flag.astype(bool)[lay.dof(np.arange(g.n_nodes), 0)]] = 0.0
+    sol, old, oo = lay.pack(u, phi), lay.pack(0 * u, po), lay.pack(0 * u, poo)
+    A_ref, res_ref = _oracle_matrix(g, lay, prm, sol, old, oo, cu, ch)
+    flags = node_flags_from_dof_flags(lay, cu.flag, ch.flag)
+    N = g.n_nodes
+    p = P.factor_ranks(world, dim)
+    n_perm_rows = 0
+    for rank in range(world):
+        lp = P.build_local_problem(dim, n, p, rank)
+        no, gi = lp.n_owned, lp.global_ids
+        ctx = Context(lp.mesh, True, n_owned_nodes=no)
+        assert ctx.kernel_path == 1
+        if path == 0:
+            ctx.force_path(0)
+        ctx.set_params(prm)
+        ctx.set_constraints(flags[gi])
+        loc = lambda uu, pp: np.concatenate([uu[gi[:no]].reshape(-1), pp[gi[:no]]])
+        ctx.state_set_host(loc(u, phi), loc(0 * u, po), loc(0 * u, poo))
+        _fill_ghosts(ctx, lp, dim, u, phi, po, poo)
+        vals = [torch.empty(ctx.pattern_size(b)[1], dtype=torch.float64, device="cuda") for b in range(4)]
+        res = torch.empty(no * (dim + 1), dtype=torch.float64, device="cuda")
+        ctx.assemble_device(False, [v.data_ptr() for v in vals], res.data_ptr(), 0)
+        ctx.sync_status()
+        for b in range(4):
+            ncr, ncc = _block_dims(dim, True, b)
+            rp, ci = ctx.pattern(b)
+            # ascending columns in every row: a host CSR sorted by local column id has exactly this layout
+            inner = np.ones(ci.size, bool)
+            inner[rp[1:-1][rp[1:-1] < ci.size]] = False
+            assert (np.diff(ci)[inner[1:]] > 0).all()
+            ctx.pattern_bind(b, rp, ci)  # what the glue does with Epetra's arrays: a pure check here
+            rows = np.repeat(np.arange(no * ncr), np.diff(rp))
+            rnode, rc = rows // ncr, rows % ncr
+            cnode, cc = ci // ncc, ci % ncc
+            n_perm_rows += int((cnode >= no).any())
+            grow = (gi[rnode] * dim + rc) if b in (0, 1) else (N * dim + gi[rnode])
+            gcol = (gi[cnode] * dim + cc) if b in (0, 2) else (N * dim + gi[cnode])
+            want = np.asarray(A_ref[grow, gcol]).ravel()
+            got = vals[b].cpu().numpy()
+            assert np.abs(got - want).max() < TOL * max(1.0, np.abs(want).max()), (rank, b)
+        r = res.cpu().numpy()
+        assert np.abs(r[:no * dim] - res_ref[(gi[:no, None] * dim + np.arange(dim)).ravel()]).max() < TOL
+        assert np.abs(r[no * dim:] - res_ref[N * dim + gi[:no]]).max() < TOL
+        ctx.close()
+    assert n_perm_rows > 0  # ghost columns were present
+
+
+def _permuted_patterns(ctx, dim, blocked, seed):
+    """The canonical pattern of every block with the neighbour nodes of each row shuffled (same shuffle in every block
+    and row component, as any host ordering by column id would be).  Returns per block (rowptr, colind, src) with
+    values_in_new_order = values_in_canonical_order[src]."""
+    rng = np.random.default_rng(seed)
+    nblocks = 4 if blocked else 1
+    out = []
+    node_perm = None
+    for b in range(nblocks):
+        ncr, ncc = _block_dims(dim, blocked, b)
+        rp, ci = ctx.pattern(b)
+        n_owned = (rp.size - 1) // ncr
+        deg = np.diff(rp)[::ncr] // ncc
+        if node_perm is None:
+            node_perm = [rng.permutation(d) for d in deg]
+        new_ci = np.empty_like(ci)
+        src = np.empty(ci.size, np.int64)
+        for nd in range(n_owned):
+            pm = node_perm[nd]
+            for c in range(ncr):
+                r0 = rp[nd * ncr + c]
+                idx = (pm[:, None] * ncc + np.arange(ncc)[None, :]).ravel()
+                new_ci[r0:r0 + idx.size] = ci[r0 + idx]
+                src[r0:r0 + idx.size] = r0 + idx
+        out.append((rp, new_ci, src))
+    return out
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("kind", ["box_cart", "box_general", "hanging2d", "slit2d", "subbox"])
+def test_bind_an_arbitrarily_ordered_host_pattern(kind, blocked):
+    import torch
+
+    if kind in ("hanging2d", "slit2d"):
+        # general family with hanging-node rows (blocked layout) / the slit mesh in the direct-solver layout
+        c = cases.perturbed(cases.kat_sneddon_2d() if kind == "hanging2d" else cases.kat_miehe_shear_1())
+        if c.layout.blocked != blocked:
+            pytest.skip("case defined in the other layout")
+        mesh, dim, n_owned = c.mesh, 2, None
+        ctx = make_context(c)
+        sol, old, oo = c.sol, c.old, c.oldold
+        lp = None
+    else:
+        dim = 3
+        if kind == "subbox":
+            lp = P.build_local_problem(dim, (9, 8, 7), P.factor_ranks(8, dim), 3)
+            mesh, n_owned = lp.mesh, lp.n_owned
+        else:
+            lp = None
+            mesh, n_owned = M.box_mesh(dim, (9, 6, 5)), None
+        base = cases.perturbed(cases.kat_sneddon_3d(4))
+        ctx = Context(mesh, blocked, n_owned_nodes=n_owned)
+        ctx.set_params(base.params)
+        rng = np.random.default_rng(2)
+        fl = (rng.uniform(size=mesh.n_nodes) < 0.1).astype(np.uint8) * rng.integers(1, 16, mesh.n_nodes).astype(np.uint8)
+        ctx.set_constraints(fl)
+        no = mesh.n_nodes if n_owned is None else n_owned
+        sol, old, oo = (rng.uniform(0.1, 0.9, no * 4) for _ in range(3))
+        if kind == "box_general":
+            ctx.force_path(0)
+    nb = 4 if blocked else 1
+
+    def run():
+        ctx.state_set_host(sol, old, oo)
+        if lp is not None:
+            g = np.random.default_rng(9)
+            N = int(lp.global_ids.max()) + 1
+            _fill_ghosts(ctx, lp, dim, g.uniform(-1e-3, 1e-3, (N, dim)), g.uniform(0.1, 0.9, N), g.uniform(0.1, 0.9, N),
+                         g.uniform(0.1, 0.9, N))
+        vals = [torch.full((ctx.pattern_size(b)[1],), np.nan, dtype=torch.float64, device="cuda") for b in range(nb)]
+        res = torch.empty(ctx.n_owned_dofs, dtype=torch.float64, device="cuda")
+        ctx.assemble_device(False, [v.data_ptr() for v in vals], res.data_ptr(), 0)
+        ctx.sync_status()
+        return [v.cpu().numpy() for v in vals], res.cpu().numpy()
+
+    v0, r0 = run()
+    pats = _permuted_patterns(ctx, dim, blocked, seed=11)
+    for b, (rp, ci, _) in enumerate(pats):
+        ctx.pattern_bind(b, rp.astype(np.int32) if b % 2 else rp, ci)
+    for b, (rp, ci, _) in enumerate(pats):  # the library now reports the host's pattern
+        rp2, ci2 = ctx.pattern(b)
+        assert (rp2 == rp).all() and (ci2 == ci).all()
+    v1, r1 = run()
+    # the row-owner kernels are bitwise reproducible; the general family sums with hardware atomics (order varies)
+    same = np.array_equal if (ctx.kernel_path == 1 and dim == 3) else (lambda a, b: np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max()))
+    assert same(r0, r1)
+    for b, (_, _, src) in enumerate(pats):
+        assert not np.isnan(v1[b]).any()
+        assert same(v1[b], v0[b][src]), f"block {b}"
+    ctx.close()
+
+
+def test_bind_rejects_foreign_and_inconsistent_patterns():
+    mesh = M.box_mesh(3, (4, 3, 3))
+    ctx = Context(mesh, True)
+    other = Context(M.box_mesh(3, (3, 4, 3)), True)  # same sizes, other coupling
+    rp, ci = other.pattern(0)
+    rp0, ci0 = ctx.pattern(0)
+    assert rp.size == rp0.size and ci.size == ci0.size
+    with pytest.raises(capi.PfmError) as e:
+        ctx.pattern_bind(0, rp, ci)
+    assert e.value.status == 1  # PFM_ERR_BAD_ARG
+    with pytest.raises(capi.PfmError):
+        ctx.pattern_bind(0, rp0[:-1], ci0)  # wrong size (row pointers end too early)
+    # two blocks with different node orders
+    pats_a = _permuted_patterns(ctx, 3, True, seed=1)
+    pats_b = _permuted_patterns(ctx, 3, True, seed=2)
+    ctx.pattern_bind(0, pats_a[0][0], pats_a[0][1])
+    with pytest.raises(capi.PfmError) as e:
+        ctx.pattern_bind(3, pats_b[3][0], pats_b[3][1])
+    assert e.value.status == 5  # PFM_ERR_UNSUPPORTED
+    ctx.pattern_bind(3, pats_a[3][0], pats_a[3][1])
+    # broken (node, component) structure: components of one neighbour not adjacent
+    rp2, ci2 = ctx.pattern(2)
+    bad = ci2.copy()
+    bad[[0, 3]] = bad[[3, 0]]
+    with pytest.raises(capi.PfmError):
+        ctx.pattern_bind(2, rp2, bad)
+    ctx.close()
+    other.close()
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+def test_lattice_with_permuted_node_numbering(blocked):
+    """box_cells set, coordinates on a lattice, but the node ids are a random permutation: the library must verify
+    the claim it relies on (x-consecutive ids in the blocked fast copy-out) and still match the oracle."""
+    dim, n = 3, (15, 9, 8)
+    g = M.box_mesh(dim, n)
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(g.n_nodes)  # new id of old node
+    inv = np.argsort(perm)
+    mesh = M.Mesh(dim=dim, coords=np.ascontiguousarray(g.coords[inv]), cells=perm[g.cells].astype(np.int32),
+                  boundary_nodes={k: np.sort(perm[v]).astype(np.int32) for k, v in g.boundary_nodes.items()}, box_shape=n)
+    h = mesh.min_cell_diameter()
+    lay = M.DofLayout(mesh.n_nodes, dim, blocked)
+    base = cases.kat_sneddon_3d(4)
+    prm = O.PfmParams.from_buffer_copy(bytes(base.params))
+    prm.alpha_eps, prm.constant_k = 2.0 * h, 1e-8 * h
+    phi = M.initial_values_sneddon(mesh, h)
+    sol = lay.pack(np.zeros((mesh.n_nodes, dim)), phi)
+    ch = M.hanging_constraints(mesh, lay)
+    cu = M.update_constraints(mesh, lay, M.sneddon_dirichlet_dofs(mesh, lay))
+    c = cases.perturbed(cases.Case("perm", mesh, lay, prm, sol, sol.copy(), sol.copy(), cu, ch), seed=4)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    A_ref, res_ref = _oracle_matrix(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch)
+    N = mesh.n_nodes
+    for b in range(4 if blocked else 1):
+        ncr, ncc = _block_dims(dim, blocked, b)
+        rp, ci = ctx.pattern(b)
+        rows = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+        if blocked:
+            grow = rows if b in (0, 1) else N * dim + rows
+            gcol = ci if b in (0, 2) else N * dim + ci
+        else:
+            grow, gcol = rows, ci
+        want = np.asarray(A_ref[grow, gcol]).ravel()
+        assert np.abs(values[b] - want).max() < TOL * max(1.0, np.abs(want).max()), b
+    assert np.abs(res - res_ref).max() < TOL * max(1.0, np.abs(res_ref).max())
+    ctx.close()
