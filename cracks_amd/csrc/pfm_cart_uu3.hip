@@ -39,161 +39,163 @@ namespace pfm
     __host__ __device__ constexpr int idxT3(int p, int al, int be, int g) { return 27 + p * 12 + al * 6 + be * 3 + g; }
     __host__ __device__ constexpr int sg3(int bit) { return bit ? 1 : -1; }
 
-    // r += contribution of one cell to entry (row comp C, col comp D) of vertex pair (a, b): every table entry enters
-    // through ONE FMA with a host-precombined constant (sign folded in at compile time)
-    template <int C, int D, int AX, int AY, int AZ, int BX, int BY, int BZ>
-    __device__ __forceinline__ void kuu3(const double *__restrict__ lds, const MatScal &S, double &r)
+    // ---- node phase: slot sets and their cell visits -------------------------------------------------------------
+    // The 18 slots with oz <= 0 are split over the 8 waves in z-symmetric sets (the mirror slots oz = +1 are the same
+    // instruction stream run by the upper half-wave); every set needs exactly 4 (slot, cell) visits per half:
+    //   W0: (0,0,0)  W1: (0,0,-1)  W2: (0,+-1,0)  W3: (+-1,0,0)  W4: (0,+-1,-1)  W5: (+-1,0,-1)  W6: (+-1,+-1,0)  W7: (+-1,+-1,-1)
+    struct Vis
     {
-      constexpr int a[3] = {AX, AY, AZ}, b[3] = {BX, BY, BZ};
-      constexpr int g[3] = {AX + BX, AY + BY, AZ + BZ};
+      int ox, oy, oz, ex, ey, slot, first, last; // slot = index within the set; first/last visit of that slot
+    };
+    __host__ __device__ constexpr Vis visit_of(int W, int v)
+    {
+      const int oz = (W == 0 || W == 2 || W == 3 || W == 6) ? 0 : -1;
+      const int nslot = (W < 2) ? 1 : (W < 6 ? 2 : 4);
+      int n = 0;
+      for (int sl = 0; sl < nslot; ++sl)
+        {
+          int ox = 0, oy = 0;
+          if (W == 2 || W == 4)
+            oy = sl ? 1 : -1;
+          else if (W == 3 || W == 5)
+            ox = sl ? 1 : -1;
+          else if (W >= 6)
+            {
+              ox = (sl & 1) ? 1 : -1;
+              oy = (sl & 2) ? 1 : -1;
+            }
+          int cnt = 0;
+          const int total = (ox == 0 ? 2 : 1) * (oy == 0 ? 2 : 1);
+          for (int ey = -1; ey <= 0; ++ey)
+            for (int ex = -1; ex <= 0; ++ex)
+              {
+                const int bx = -ex + ox, by = -ey + oy;
+                if (bx < 0 || bx > 1 || by < 0 || by > 1)
+                  continue;
+                if (n == v)
+                  return Vis{ox, oy, oz, ex, ey, sl, cnt == 0, cnt == total - 1};
+                ++n;
+                ++cnt;
+              }
+        }
+      return Vis{0, 0, 0, 0, 0, -1, 0, 0};
+    }
+    __host__ __device__ constexpr int nslots_of(int W) { return (W < 2) ? 1 : (W < 6 ? 2 : 4); }
+
+    // the 9 table values one visit needs for ALL nine (row comp, col comp) entries: A^k (k = 0..2), then per pair
+    // p = (lo,hi): X_p = T^p[b_lo][a_hi][g_e], Y_p = T^p[a_lo][b_hi][g_e]  (21 FMAs from 9 LDS reads)
+    template <int W, int V>
+    __device__ __forceinline__ void uu_load_visit(const double *__restrict__ lane_base, double (&tv)[9])
+    {
+      constexpr Vis vi = visit_of(W, V);
+      constexpr int a[3] = {-vi.ex, -vi.ey, 1}, b[3] = {-vi.ex + vi.ox, -vi.ey + vi.oy, 1 + vi.oz};
+      constexpr int g[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
+      const double *cell = lane_base + (vi.ey * C3X + vi.ex);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        {
+          const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
+          tv[k] = cell[idxA3(k, g[i], g[j]) * CS3];
+        }
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        {
+          const int lo = (p == 2) ? 1 : 0, hi = (p == 0) ? 1 : 2, e = 3 - lo - hi;
+          tv[3 + 2 * p] = cell[idxT3(p, b[lo], a[hi], g[e]) * CS3];
+          tv[4 + 2 * p] = cell[idxT3(p, a[lo], b[hi], g[e]) * CS3];
+        }
+    }
+
+    struct UuCoef // uniform constants of the node phase, read once per workgroup
+    {
+      double cA[3][3], cTl[3], cTm[3];
+    };
+
+    // r += entry (C, D) of one visit, same operation order as the reference formulation K = lambda G^{CD} + mu G^{DC} +
+    // mu delta_CD tr G (every table value enters through one FMA with a host-precombined constant)
+    template <int W, int V, int C, int D>
+    __device__ __forceinline__ void uu_acc_visit(const double (&tv)[9], const UuCoef &K, double &r)
+    {
+      constexpr Vis vi = visit_of(W, V);
+      constexpr int a[3] = {-vi.ex, -vi.ey, 1}, b[3] = {-vi.ex + vi.ox, -vi.ey + vi.oy, 1 + vi.oz};
       if constexpr (C == D)
         {
 #pragma unroll
           for (int k = 0; k < 3; ++k)
-            {
-              const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-              const double v = lds[idxA3(k, g[i], g[j]) * CS3];
-              r = fma((sg3(a[k]) * sg3(b[k]) > 0) ? S.cA[C][k] : -S.cA[C][k], v, r);
-            }
+            r = fma((sg3(a[k]) * sg3(b[k]) > 0) ? K.cA[C][k] : -K.cA[C][k], tv[k], r);
         }
       else
         {
-          constexpr int lo = C < D ? C : D, hi = C < D ? D : C, e = 3 - C - D, p = pair3(lo, hi);
-          constexpr int al1 = (C < D) ? b[lo] : a[lo], be1 = (C < D) ? a[hi] : b[hi]; // G^{CD}
-          constexpr int al2 = (C < D) ? a[lo] : b[lo], be2 = (C < D) ? b[hi] : a[hi]; // G^{DC}
-          const double t1 = lds[idxT3(p, al1, be1, g[e]) * CS3];
-          const double t2 = lds[idxT3(p, al2, be2, g[e]) * CS3];
-          r = fma((sg3(a[C]) * sg3(b[D]) > 0) ? S.cTl[p] : -S.cTl[p], t1, r);
-          r = fma((sg3(a[D]) * sg3(b[C]) > 0) ? S.cTm[p] : -S.cTm[p], t2, r);
+          constexpr int lo = C < D ? C : D, hi = C < D ? D : C, p = pair3(lo, hi);
+          const double t1 = (C < D) ? tv[3 + 2 * p] : tv[4 + 2 * p];
+          const double t2 = (C < D) ? tv[4 + 2 * p] : tv[3 + 2 * p];
+          r = fma((sg3(a[C]) * sg3(b[D]) > 0) ? K.cTl[p] : -K.cTl[p], t1, r);
+          r = fma((sg3(a[D]) * sg3(b[C]) > 0) ? K.cTm[p] : -K.cTm[p], t2, r);
         }
     }
 
-    // lower-layer contribution (a_z = 1, b_z = 1 + OZ) of the 4 cells around the node to entry (C, D, slot)
-    template <int C, int D, int OX, int OY, int OZ>
-    __device__ __forceinline__ double uu3_lower(const double *__restrict__ lane_base, const MatScal &S)
+    // x[l] + x[l ^ 32] in every lane, through the VALU (v_permlane32_swap) instead of two LDS bpermutes per double
+    __device__ __forceinline__ double add_across_halves(double x)
     {
-      static_assert(OZ == -1 || OZ == 0, "only slots below or in the node plane have lower-layer cells");
-      double r = 0.0;
-      auto visit = [&](auto EX, auto EY) __attribute__((always_inline)) {
-        constexpr int ex = decltype(EX)::value, ey = decltype(EY)::value;
-        constexpr int ax = -ex, ay = -ey, bx = ax + OX, by = ay + OY;
-        if constexpr (bx >= 0 && bx <= 1 && by >= 0 && by <= 1)
-          kuu3<C, D, ax, ay, 1, bx, by, 1 + OZ>(lane_base + (ey * C3X + ex), S, r);
-      };
-      using M1 = std::integral_constant<int, -1>;
-      using Z0 = std::integral_constant<int, 0>;
-      visit(M1{}, M1{});
-      visit(Z0{}, M1{});
-      visit(M1{}, Z0{});
-      visit(Z0{}, Z0{});
-      return r;
+      const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
     }
 
-    // one slot (given by its in-plane offset and OZ in {-1, 0}) of row component C for both half-waves.
-    // stage_half = the lane's staged row, shifted by 18 slots for the upper half: a slot with OZ = -1 completed by the
-    // lower half is the slot o_lo, its mirror completed by the upper half is o_lo + 18.  Slots with OZ = 0 are summed
-    // over the halves; both halves then hold the same value and store it to the same address (no exec masking).
-    // flag_half = flags of the node plane the half looks at for OZ = -1 (below / above), flag_own = own plane.
-    template <int C, int OX, int OY, int OZ, bool MASKED>
-    __device__ __forceinline__ void uu3_slot(const double *__restrict__ lane_base, const MatScal &S, double *__restrict__ stage_row,
-                                             double *__restrict__ stage_half, unsigned row_flag,
-                                             const unsigned char *__restrict__ flag_own, const unsigned char *__restrict__ flag_half)
+    // row component C of slot set W for both half-waves, from the cached table values: 28 FMAs, the cross-half adds of
+    // the oz = 0 slots, the constraint masks, 3 staged values per slot.  stage_half = the lane's staged row shifted by 18
+    // slots for the upper half (a slot with oz = -1 completed by the lower half is slot o_lo, its mirror completed by the
+    // upper half is o_lo + 18); oz = 0 slots are summed over the halves and stored by both (same value, same address).
+    template <int W, int C, bool MASKED>
+    __device__ __forceinline__ void uu_row_component(const double (&tv)[4][9], const UuCoef &K, double *__restrict__ stage_row,
+                                                     double *__restrict__ stage_half, unsigned row_flag,
+                                                     const unsigned char *__restrict__ flag_own,
+                                                     const unsigned char *__restrict__ flag_half)
     {
-      double v0 = uu3_lower<C, 0, OX, OY, OZ>(lane_base, S);
-      double v1 = uu3_lower<C, 1, OX, OY, OZ>(lane_base, S);
-      double v2 = uu3_lower<C, 2, OX, OY, OZ>(lane_base, S);
-      constexpr int o_lo = (OX + 1) + 3 * (OY + 1) + 9 * (OZ + 1);
-      if constexpr (OZ == 0)
-        {
-          v0 += __shfl_xor(v0, 32);
-          v1 += __shfl_xor(v1, 32);
-          v2 += __shfl_xor(v2, 32);
-        }
-      if constexpr (MASKED)
-        {
-          const unsigned cf = (OZ == 0 ? flag_own : flag_half)[OX + H3X * OY];
-          const bool rcon = (row_flag >> C) & 1u;
-          constexpr bool centre = (OX == 0 && OY == 0 && OZ == 0);
-          if (rcon || (cf & 1u))
-            v0 = (rcon && centre && C == 0) ? v0 : 0.0;
-          if (rcon || (cf & 2u))
-            v1 = (rcon && centre && C == 1) ? v1 : 0.0;
-          if (rcon || (cf & 4u))
-            v2 = (rcon && centre && C == 2) ? v2 : 0.0;
-        }
-      double *dst = (OZ == 0 ? stage_row : stage_half) + o_lo * 3;
-      dst[0] = v0;
-      dst[1] = v1;
-      dst[2] = v2;
-    }
-
-    // z-symmetric slot sets, 4 lower-layer cell visits per (row, column component) each
-    template <int C, int W, bool MASKED>
-    __device__ __forceinline__ void uu3_wave(const double *lane_base, const MatScal &S, double *stage_row, double *stage_half,
-                                             unsigned row_flag, const unsigned char *flag_own, const unsigned char *flag_half)
-    {
-#define PFM_S(OX, OY, OZ) uu3_slot<C, OX, OY, OZ, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half)
-      if constexpr (W == 0)
-        {
-          PFM_S(0, 0, 0);
-        }
-      else if constexpr (W == 1)
-        {
-          PFM_S(0, 0, -1);
-        }
-      else if constexpr (W == 2)
-        {
-          PFM_S(0, -1, 0);
-          PFM_S(0, 1, 0);
-        }
-      else if constexpr (W == 3)
-        {
-          PFM_S(-1, 0, 0);
-          PFM_S(1, 0, 0);
-        }
-      else if constexpr (W == 4)
-        {
-          PFM_S(0, -1, -1);
-          PFM_S(0, 1, -1);
-        }
-      else if constexpr (W == 5)
-        {
-          PFM_S(-1, 0, -1);
-          PFM_S(1, 0, -1);
-        }
-      else if constexpr (W == 6)
-        {
-          PFM_S(-1, -1, 0);
-          PFM_S(1, -1, 0);
-          PFM_S(-1, 1, 0);
-          PFM_S(1, 1, 0);
-        }
-      else
-        {
-          PFM_S(-1, -1, -1);
-          PFM_S(1, -1, -1);
-          PFM_S(-1, 1, -1);
-          PFM_S(1, 1, -1);
-        }
-#undef PFM_S
-    }
-
-    template <int C, bool MASKED>
-    __device__ __forceinline__ void uu3_dispatch(int wave, const double *lane_base, const MatScal &S, double *stage_row,
-                                                 double *stage_half, unsigned row_flag, const unsigned char *flag_own,
-                                                 const unsigned char *flag_half)
-    {
-      switch (wave)
-        {
-          case 0: uu3_wave<C, 0, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 1: uu3_wave<C, 1, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 2: uu3_wave<C, 2, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 3: uu3_wave<C, 3, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 4: uu3_wave<C, 4, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 5: uu3_wave<C, 5, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          case 6: uu3_wave<C, 6, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-          default: uu3_wave<C, 7, MASKED>(lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half); break;
-        }
+      constexpr int NS = nslots_of(W);
+      double val[NS][3];
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl)
+        val[sl][0] = val[sl][1] = val[sl][2] = 0.0;
+      static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+        constexpr int V = decltype(Vv)::value;
+        constexpr Vis vi = visit_of(W, V);
+        uu_acc_visit<W, V, C, 0>(tv[V], K, val[vi.slot][0]);
+        uu_acc_visit<W, V, C, 1>(tv[V], K, val[vi.slot][1]);
+        uu_acc_visit<W, V, C, 2>(tv[V], K, val[vi.slot][2]);
+      });
+      static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+        constexpr int V = decltype(Vv)::value;
+        constexpr Vis vi = visit_of(W, V);
+        if constexpr (vi.last)
+          {
+            double v0 = val[vi.slot][0], v1 = val[vi.slot][1], v2 = val[vi.slot][2];
+            if constexpr (vi.oz == 0)
+              {
+                v0 = add_across_halves(v0);
+                v1 = add_across_halves(v1);
+                v2 = add_across_halves(v2);
+              }
+            if constexpr (MASKED)
+              {
+                const unsigned cf = (vi.oz == 0 ? flag_own : flag_half)[vi.ox + H3X * vi.oy];
+                const bool rcon = (row_flag >> C) & 1u;
+                constexpr bool centre = (vi.ox == 0 && vi.oy == 0 && vi.oz == 0);
+                if (rcon || (cf & 1u))
+                  v0 = (rcon && centre && C == 0) ? v0 : 0.0;
+                if (rcon || (cf & 2u))
+                  v1 = (rcon && centre && C == 1) ? v1 : 0.0;
+                if (rcon || (cf & 4u))
+                  v2 = (rcon && centre && C == 2) ? v2 : 0.0;
+              }
+            constexpr int o_lo = (vi.ox + 1) + 3 * (vi.oy + 1) + 9 * (vi.oz + 1);
+            double *dst = (vi.oz == 0 ? stage_row : stage_half) + o_lo * 3;
+            dst[0] = v0;
+            dst[1] = v1;
+            dst[2] = v2;
+          }
+      });
     }
 
     // =====================================================================================

@@ -225,8 +225,10 @@ def test_bind_rejects_foreign_and_inconsistent_patterns():
     with pytest.raises(capi.PfmError) as e:
         ctx.pattern_bind(0, rp, ci)
     assert e.value.status == 1  # PFM_ERR_BAD_ARG
+    short = rp0.copy()
+    short[-1] -= 3  # row pointers that do not cover the block
     with pytest.raises(capi.PfmError):
-        ctx.pattern_bind(0, rp0[:-1], ci0)  # wrong size (row pointers end too early)
+        ctx.pattern_bind(0, short, ci0)
     # two blocks with different node orders
     pats_a = _permuted_patterns(ctx, 3, True, seed=1)
     pats_b = _permuted_patterns(ctx, 3, True, seed=2)
