@@ -30,14 +30,24 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL peer-to-peer between the ranks of a node
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-FP64_PEAK_TFLOPS = 78.6  # vector FP64 (= 1/2 of the guide's 157.3 TF FP32 figure), SURVEY.md §8(d)
+N_SIMD = 1024  # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4  # max clock (the chip sustains ~1.6-2.1 GHz under FP64 load: profiles/r02/microbench_mfma_f64_lds.txt)
 
 
-def algorithmic_flops_per_cell(dim: int, residual_only: bool) -> float:
-    """Second bound of SURVEY.md §8(d): flops of a tight constant-geometry formulation (FMA = 2)."""
-    if dim == 3:
-        return 1.9e4 if residual_only else 2.75e4  # midpoint of the 2-3.5e4 range quoted there
-    return 2.0e3 if residual_only else 4.0e3
+def measured_valu_instructions(dim: int, n: int, residual_only: bool):
+    """Second bound, from counters instead of a flop estimate: VALU wave-instructions per assembly (SQ_INSTS_VALU of a
+    separate rocprofv3 PMC pass of this very command, summary committed under profiles/).  An FP64 VALU instruction
+    occupies its SIMD for 4 cycles (16 lanes per clock), so N / (4 SIMDs x CUs) x 4 cycles is the time the kernels would
+    need if they issued nothing else and every instruction were FP64 -- an upper estimate of the issue floor (integer
+    and move instructions take 2 cycles).  None if this workload was not profiled."""
+    import glob
+
+    key = f"valu_instructions_{dim}d_{n}{'_residual' if residual_only else ''}.json"
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key)))
+    if not found:
+        return None, None
+    rec = json.load(open(found[-1]))
+    return float(sum(rec["per_launch"].values())), os.path.relpath(found[-1], ROOT)
 
 
 def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
@@ -108,8 +118,21 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
     """Time the CPU oracle (port of cracks.cc:2200-2467) on a bounded sample of the same
     workload, one thread = one reference MPI rank (cracks.cc:4587)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import subprocess
+
     import oracle_api as O
     from cracks_amd import mesh as M
+
+    # -march=native must mean THIS host: rebuild the oracle here (the .so in the tree comes from the build container)
+    build_note = "prebuilt liboracle.so (no compiler on this host)"
+    try:
+        O.build_oracle(force=True)
+        mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+        cxxflags = [ln.split("?=", 1)[1].strip() for ln in mk.splitlines() if ln.startswith("CXXFLAGS")][0]
+        cxx = subprocess.run(["g++", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+        build_note = f"rebuilt on this host: {cxx}, {cxxflags}"
+    except Exception as e:  # pragma: no cover
+        build_note += f" [{type(e).__name__}]"
 
     n = 20 if dim == 3 else 160
     if residual_only and dim == 3:
@@ -188,7 +211,7 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
             "all_cores": {"value": ncore * reps * lay.n_dofs / t_all, "unit": "DoFs/s", "cores": ncore,
                           "sample": f"{ncore} threads{quota_note} x {reps} assemblies of the same sample each, wall {t_all:.1f} s"},
             "sample": f"{n}^{dim} cells ({lay.n_dofs} DoFs), median of {len(times)} assemblies, "
-                      f"g++ -O3 -march=native, 1 thread of {os.cpu_count()} ({model}); excludes Trilinos "
+                      f"{build_note}, 1 thread of {os.cpu_count()} ({model}); excludes Trilinos "
                       f"insertion overhead the real reference pays"}
 
 
@@ -203,7 +226,6 @@ def main():
     ap.add_argument("--residual-only", action="store_true")
     ap.add_argument("--path", choices=["auto", "general", "cart", "overlay"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="compare a small instance with the oracle first")
     ap.add_argument("--checksum", action="store_true",
                     help="add partition-independent sums of the assembled values (outside the timed region): the "
                          "N-rank run must reproduce the 1-rank numbers up to round-off")
@@ -287,13 +309,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t1
     asm.synchronize()
+    k_all = asm.ctx.kernel_times_ms()
+    k_med = float(np.median(k_all)) if k_all.size else 0.0
     k_ms, k_n = asm.ctx.kernel_time_ms()
     asm.ctx.timing_enable(False)
 
-    tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+    tt = torch.tensor([elapsed, k_ms, k_med], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, k_ms = float(tt[0]), float(tt[1])
+    elapsed, k_ms, k_med = float(tt[0]), float(tt[1]), float(tt[2])
     checksum = None
     if args.checksum:
         # sums over the owned rows: every global row is owned by exactly one rank
@@ -316,6 +340,12 @@ def main():
         abytes = algorithmic_bytes_per_cell(dim, residual_only) * lp.mesh.n_cells  # this rank's launch
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_hbm_traffic(dim, n, residual_only) if world == 1 else (None, None)
+        vi, vi_src = measured_valu_instructions(dim, n, residual_only) if world == 1 else (None, None)
+        valu = None
+        if vi is not None:
+            floor_ms = vi * 4.0 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            valu = {"wave_instructions_per_launch": vi, "issue_floor_ms_if_all_fp64_at_max_clock": floor_ms,
+                    "frac_of_kernel_time": floor_ms / k_ms if k_ms > 0 else None, "source": vi_src}
         out = {
             "metric": "assembled DoFs/sec (residual+Jacobian) on 3D Sneddon" if (dim == 3 and not residual_only)
             else f"assembled DoFs/sec ({'residual-only' if residual_only else 'residual+Jacobian'}) on {dim}D Sneddon",
@@ -336,12 +366,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": abytes,
-                         # second bound: the kernels are FP64-issue bound, not HBM bound
-                         "fp64": {"achieved": algorithmic_flops_per_cell(dim, residual_only) * lp.mesh.n_cells /
-                                              (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0,
-                                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "algorithmic_flops_per_cell": algorithmic_flops_per_cell(dim, residual_only)},
-                         "kernel_ms": k_ms, "launches": k_n,
+                         # second bound: VALU issue, from counted instructions (not a flop estimate)
+                         "valu": valu,
+                         "kernel_ms": k_ms, "kernel_ms_median": k_med, "launches": k_n,
                          "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
         }
         if checksum is not None:

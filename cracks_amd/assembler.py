@@ -214,6 +214,13 @@ class Context:
         self._check(self.lib.pfm_kernel_time_ms(self._h, C.byref(ms), C.byref(n)), "pfm_kernel_time_ms")
         return ms.value, n.value
 
+    def kernel_times_ms(self, capacity: int = 4096) -> np.ndarray:
+        """Durations of the recorded launches (call before ``kernel_time_ms``, which resets the record)."""
+        buf = np.zeros(capacity)
+        n = C.c_int()
+        self._check(self.lib.pfm_kernel_times_ms(self._h, capi.np_ptr(buf, np.float64), capacity, C.byref(n)), "pfm_kernel_times_ms")
+        return buf[:min(n.value, capacity)]
+
     @property
     def kernel_path(self) -> int:
         return self.lib.pfm_ctx_kernel_path(self._h)

@@ -103,7 +103,7 @@ namespace pfm
     // the same from ONE nodal field: staggered scheme (no clamping of the old fields at the q-points), where pf_extra is
     // linear in (phi_old, phi_oldold) up to its final clamp -- pw = phi_old if use_old_timestep_pf, else
     // phi_oldold + tfac (phi_old - phi_oldold), formed per node by the caller
-    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9])
+    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9], const G1 &c_g1 = pfm::c_g1)
     {
       double a[4];
 #pragma unroll
@@ -128,7 +128,7 @@ namespace pfm
 
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
     __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScal &S, int qz,
-                                                  double wg[9])
+                                                  double wg[9], const G1 &c_g1 = pfm::c_g1)
     {
       double a[4], b[4];
 #pragma unroll

@@ -955,7 +955,8 @@ namespace pfm
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    int rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal);
+    static const bool use_uu3 = getenv("PFM_UU3") != nullptr; // round-1 (u,u) kernel, kept for A/B comparisons
+    int rc = use_uu3 ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal) : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
     if (rc)
       return rc;
     return launch_cart_phi4(v, cv, p, d_values, s, d_scal);

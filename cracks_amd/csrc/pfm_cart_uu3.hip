@@ -414,78 +414,115 @@ namespace pfm
       __syncthreads();
       stamp(2);
 
-      // ---- node phase + copy-out per row component
-      const int wave = t >> 6, lane = t & 63;
+      // ---- node phase + copy-out.  Every wave first reads the 36 table values of its slot set (4 visits x 9) in ONE
+      // batch and keeps them in registers for all three row components: 36 LDS reads per lane instead of 84, one
+      // latency instead of a chain of them, and the tables are dead afterwards -- their LDS becomes the second staging
+      // buffer, so that the copy-out of component c overlaps the arithmetic of component c + 1 (one barrier per
+      // component instead of two).
+      const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform: scalar branches between the slot sets
+      const int lane = t & 63;
       const bool upper = lane >= 32;
       const int nl_lane = lane & 31;
       const int ti = nl_lane % T3X, tj = nl_lane / T3X;
       const int hc = (ti + 1) + H3X * ((tj + 1) + H3Y * 1);
-      const bool owned = (i0 + ti) <= cv.o1[0] && (j0 + tj) <= cv.o1[1];
       const bool masked = (s_any[0] | s_any[1] | s_any[2]) != 0;
       const bool regular_tile = (NCOL == 3) && s_any[3] == 0;
       const unsigned row_flag = s_flag[hc];
       // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
       const double *lane_base = s_tab + (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1);
-      double *stage_row = s_stage + nl_lane * STG;
-      double *stage_half = stage_row + (upper ? 18 * 3 : 0);
       const unsigned char *flag_own = s_flag + hc, *flag_half = s_flag + hc + (upper ? H3X * H3Y : -H3X * H3Y);
-
-#pragma unroll 1
+      static_assert(NN3 * STG <= NNUM3 * CS3, "second staging buffer must fit in the table storage");
+      UuCoef K;
+#pragma unroll
       for (int c = 0; c < 3; ++c)
         {
-          // all 64 lanes take part (cross-half adds); stores of tiles' non-owned nodes are dropped at copy-out
-          if (masked)
-            {
-              if (c == 0)
-                uu3_dispatch<0, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-              else if (c == 1)
-                uu3_dispatch<1, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-              else
-                uu3_dispatch<2, true>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-            }
-          else if (c == 0)
-            uu3_dispatch<0, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-          else if (c == 1)
-            uu3_dispatch<1, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-          else
-            uu3_dispatch<2, false>(wave, lane_base, S, stage_row, stage_half, row_flag, flag_own, flag_half);
-          lds_barrier();
-          stamp(3);
-          if (regular_tile)
-            {
-#pragma unroll 2
-              for (int f = t; f < NN3 * STG; f += NT3)
-                {
-                  const int nl = f / STG;
-                  vals[s_rowbase[nl] + c * STG + (f - nl * STG)] = s_stage[f];
-                }
-            }
-          else
-            {
-              // rows at the faces of the box / partial tiles / next to ghost columns: thread <-> (row, lattice offset o,
-              // column component); the CSR slot of offset o is its rank among the offsets that exist, or the row's
-              // permutation of that rank
-              constexpr int rowlen = 27 * NCOL;
-              for (int f = t; f < NN3 * rowlen; f += NT3)
-                {
-                  const int nl = f / rowlen, e = f - nl * rowlen;
-                  const int o = e / NCOL, d = e - o * NCOL;
-                  const long long base = s_rowbase[nl];
-                  const unsigned mask = s_mask[nl];
-                  if (base < 0 || !((mask >> o) & 1u))
-                    continue;
-                  int sl = __popc(mask & ((1u << o) - 1u));
-                  const int deg = __popc(mask & 0x7ffffffu);
-                  if (mask >> 31) // the row is not in lattice order (ghost columns behind the owned ones, bound pattern)
-                    sl = cv.row_perm[base / (NCOL * NCOL) + sl];
-                  const double val = (d < 3) ? s_stage[nl * STG + o * 3 + d] : 0.0;
-                  vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
-                }
-            }
-          lds_barrier();
-          stamp(4);
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            K.cA[c][k] = S.cA[c][k];
+          K.cTl[c] = S.cTl[c];
+          K.cTm[c] = S.cTm[c];
         }
-      (void)owned;
+
+      auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
+        if (regular_tile)
+          {
+#pragma unroll 2
+            for (int f = t; f < NN3 * STG; f += NT3)
+              {
+                const int nl = f / STG;
+                vals[s_rowbase[nl] + c * STG + (f - nl * STG)] = stage[f];
+              }
+          }
+        else
+          {
+            // rows at the faces of the box / partial tiles / next to ghost columns: thread <-> (row, lattice offset o,
+            // column component); the CSR slot of offset o is its rank among the offsets that exist, or the row's
+            // permutation of that rank
+            constexpr int rowlen = 27 * NCOL;
+            for (int f = t; f < NN3 * rowlen; f += NT3)
+              {
+                const int nl = f / rowlen, e = f - nl * rowlen;
+                const int o = e / NCOL, d = e - o * NCOL;
+                const long long base = s_rowbase[nl];
+                const unsigned mask = s_mask[nl];
+                if (base < 0 || !((mask >> o) & 1u))
+                  continue;
+                int sl = __popc(mask & ((1u << o) - 1u));
+                const int deg = __popc(mask & 0x7ffffffu);
+                if (mask >> 31) // the row is not in lattice order (ghost columns behind the owned ones, bound pattern)
+                  sl = cv.row_perm[base / (NCOL * NCOL) + sl];
+                const double val = (d < 3) ? stage[nl * STG + o * 3 + d] : 0.0;
+                vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
+              }
+          }
+      };
+
+      // the slot set of a wave is selected by scalar branches around the set-specific code only (table reads, the
+      // arithmetic of one row component); barriers and the copy-out are shared code (instruction cache: 8 sets x 3
+      // components x 2 mask variants of straight-line code)
+      double tv[4][9];
+      using std::integral_constant;
+#define PFM_PER_SET(STMT)                                                                                                    \
+  switch (wave)                                                                                                              \
+    {                                                                                                                        \
+      case 0: { constexpr int W = 0; STMT; } break;                                                                          \
+      case 1: { constexpr int W = 1; STMT; } break;                                                                          \
+      case 2: { constexpr int W = 2; STMT; } break;                                                                          \
+      case 3: { constexpr int W = 3; STMT; } break;                                                                          \
+      case 4: { constexpr int W = 4; STMT; } break;                                                                          \
+      case 5: { constexpr int W = 5; STMT; } break;                                                                          \
+      case 6: { constexpr int W = 6; STMT; } break;                                                                          \
+      default: { constexpr int W = 7; STMT; } break;                                                                         \
+    }
+      PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) { uu_load_visit<W, decltype(Vv)::value>(lane_base, tv[decltype(Vv)::value]); }))
+      // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the table storage: written after the
+      // barrier of component 0, which every wave passes with its table values in registers
+      double *st0 = s_stage + nl_lane * STG, *st1 = s_tab + nl_lane * STG;
+      const int hs = upper ? 18 * 3 : 0;
+#define PFM_COMPONENT(C, ST)                                                                                                 \
+  if (masked)                                                                                                                \
+    {                                                                                                                        \
+      PFM_PER_SET((uu_row_component<W, C, true>(tv, K, ST, ST + hs, row_flag, flag_own, flag_half)))                         \
+    }                                                                                                                        \
+  else                                                                                                                       \
+    {                                                                                                                        \
+      PFM_PER_SET((uu_row_component<W, C, false>(tv, K, ST, ST + hs, row_flag, flag_own, flag_half)))                        \
+    }
+      PFM_COMPONENT(0, st0)
+      lds_barrier();
+      stamp(3);
+      copy_out(0, s_stage);
+      PFM_COMPONENT(1, st1)
+      lds_barrier();
+      stamp(4);
+      copy_out(1, s_tab);
+      PFM_COMPONENT(2, st0)
+      lds_barrier();
+      stamp(3);
+      copy_out(2, s_stage);
+      stamp(4);
+#undef PFM_COMPONENT
+#undef PFM_PER_SET
     }
   } // namespace
 
@@ -515,7 +552,7 @@ namespace pfm
         unsigned long long h[8] = {};
         for (size_t i = 0; i < nd; ++i)
           h[i % 8] += hall[i];
-        const char *names[5] = {"phase0", "w*g", "moments", "node(x3)", "copy-out(x3)"};
+        const char *names[5] = {"phase0", "w*g", "moments", "load+node c0,c2 (+copy c1)", "copy c0,c2 + node c1"};
         fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per tile]");
         for (int i = 0; i < 5; ++i)
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
@@ -529,6 +566,7 @@ namespace pfm
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)
   {
-    return launch_cart_uu3(v, cv, p, vals_uu, s, d_scal);
+    static const bool use_uu3 = getenv("PFM_UU3") != nullptr;
+    return use_uu3 ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -1310,6 +1310,28 @@ extern "C"
     return PFM_OK;
   }
 
+  int pfm_kernel_times_ms(pfm_ctx *c, double *ms, int capacity, int *n_launches)
+  {
+    if (!c || (capacity > 0 && !ms) || capacity < 0)
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+      return hipfail(c, e, "kernel_times sync");
+    const int n = (int)std::min<size_t>(c->ev_used, (size_t)capacity);
+    for (int k = 0; k < n; ++k)
+      {
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, c->ev_pool[k].first, c->ev_pool[k].second);
+        if (e != hipSuccess)
+          return hipfail(c, e, "hipEventElapsedTime");
+        ms[k] = t;
+      }
+    if (n_launches)
+      *n_launches = (int)c->ev_used;
+    return PFM_OK;
+  }
+
   int pfm_ctx_kernel_path(const pfm_ctx *c) { return c ? c->kernel_path : -1; }
 
   int pfm_ctx_force_path(pfm_ctx *c, int path)

@@ -99,6 +99,9 @@ namespace pfm
                        const void *d_scal);
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal);
+  // z-marching successor of launch_cart_uu3 (pfm_cart_uu4.hip); PFM_UU3=1 selects the round-1 kernel (A/B runs)
+  int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                      const void *d_scal);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal);
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,

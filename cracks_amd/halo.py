@@ -109,8 +109,17 @@ class HaloExchange:
         uid = np.ascontiguousarray(t.cpu().numpy())
         h = C.c_void_p()
         rc = ctx.lib.pfm_comm_create(C.byref(h), capi.np_ptr(uid, np.uint8), world, rank, self.send_all.device.index)
-        if rc != capi.PFM_OK:
-            raise capi.PfmError(rc, "pfm_comm_create")
+        # the choice of transport must be the same on every rank: agree on the outcome
+        ok = torch.tensor([1 if rc == capi.PFM_OK else 0], device=self.send_all.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            if rc == capi.PFM_OK:
+                ctx.lib.pfm_comm_destroy(h)
+            import warnings
+
+            warnings.warn("pfm_comm_create failed on some rank: ghost exchange falls back to torch.distributed P2P")
+            self._use_lib = False
+            return
         self._comm, self._comm_lib = h, ctx.lib
 
     def close(self):
@@ -124,6 +133,7 @@ class HaloExchange:
             self.register(ctx)
         if self._use_lib:
             self._ensure_comm(ctx)
+        if self._use_lib:
             ctx.halo_exchange(self._comm.value, self.peers)
             return
         if self.send_all.numel():

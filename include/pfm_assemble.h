@@ -200,6 +200,9 @@ int pfm_assemble(pfm_ctx *ctx, const double *sol, const double *old, const doubl
  * since the last call and resets the record. */
 int pfm_timing_enable(pfm_ctx *ctx, int on);
 int pfm_kernel_time_ms(pfm_ctx *ctx, double *mean_ms, int *n_launches);
+/* The individual durations (for a median): the first min(capacity, recorded) ones; *n_launches = recorded.  Does not
+ * reset the record (pfm_kernel_time_ms / pfm_timing_enable do). */
+int pfm_kernel_times_ms(pfm_ctx *ctx, double *ms, int capacity, int *n_launches);
 
 /* -- introspection -------------------------------------------------------------------- */
 /* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian */
