@@ -100,15 +100,21 @@ namespace pfm
       double lapM[27];                 // G_c eps sum_q w grad N_a . grad N_b by moment index g_x + 3 g_y + 9 g_z
     };
 
+    // 1-D Gauss(3) data for a RUN-TIME point index (a per-lane index into the __constant__ table would be a vector
+    // load from memory with an exposed cache round trip): same arithmetic as make_g1, bit-identical values
+    __device__ __forceinline__ double gauss_n1(int q) { return fma((double)(q - 1), 0.5 * 0.7745966692414834, 0.5); }
+    __device__ __forceinline__ double gauss_w(int q) { return (q == 1) ? 8.0 / 18.0 : 5.0 / 18.0; }
+
     // the same from ONE nodal field: staggered scheme (no clamping of the old fields at the q-points), where pf_extra is
     // linear in (phi_old, phi_oldold) up to its final clamp -- pw = phi_old if use_old_timestep_pf, else
     // phi_oldold + tfac (phi_old - phi_oldold), formed per node by the caller
-    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9], const G1 &c_g1 = pfm::c_g1)
+    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9])
     {
+      const double nz1 = gauss_n1(qz), nz0 = 1.0 - nz1, wz = gauss_w(qz); // q_z is a per-lane run-time index
       double a[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        a[v] = c_g1.n[0][qz] * pw[v] + c_g1.n[1][qz] * pw[v + 4];
+        a[v] = nz0 * pw[v] + nz1 * pw[v + 4];
 #pragma unroll
       for (int qy = 0; qy < 3; ++qy)
         {
@@ -121,21 +127,22 @@ namespace pfm
               if (!S.use_old)
                 pfx = fmin(fmax(pfx, 0.0), 1.0);
               const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz]) * g;
+              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * wz) * g;
             }
         }
     }
 
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
     __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScal &S, int qz,
-                                                  double wg[9], const G1 &c_g1 = pfm::c_g1)
+                                                  double wg[9])
     {
+      const double nz1 = gauss_n1(qz), nz0 = 1.0 - nz1, wz = gauss_w(qz);
       double a[4], b[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         {
-          a[v] = c_g1.n[0][qz] * po[v] + c_g1.n[1][qz] * po[v + 4];
-          b[v] = c_g1.n[0][qz] * poo[v] + c_g1.n[1][qz] * poo[v + 4];
+          a[v] = nz0 * po[v] + nz1 * po[v + 4];
+          b[v] = nz0 * poo[v] + nz1 * poo[v + 4];
         }
 #pragma unroll
       for (int qy = 0; qy < 3; ++qy)
@@ -162,7 +169,7 @@ namespace pfm
               if (S.use_old)
                 pfx = pfo;
               const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * c_g1.w[qz]) * g;
+              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * wz) * g;
             }
         }
     }

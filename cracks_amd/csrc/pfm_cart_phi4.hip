@@ -955,7 +955,7 @@ namespace pfm
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    static const bool use_uu3 = getenv("PFM_UU3") != nullptr; // round-1 (u,u) kernel, kept for A/B comparisons
+    static const bool use_uu3 = getenv("PFM_UU4") == nullptr; // PFM_UU4=1: the z-marching variant (pfm_cart_uu4.hip), measured equal
     int rc = use_uu3 ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal) : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
     if (rc)
       return rc;

@@ -324,30 +324,44 @@ namespace pfm
       __syncthreads();
       stamp(1);
 
-      // ---- cell phase b: moment tables, thread <-> (cell, {A^x, A^y, A^z, T^xy, T^xz, T^yz}).
+      // ---- cell phase b: moment tables, thread <-> (cell, task), 9 tasks per cell: A^x, A^y, A^z and the two halves
+      // (al = 0, 1) of T^xy, T^xz, T^yz -- 810 tasks of ~65 flops in two passes (the 540 (cell, family) tasks of round 1
+      // needed a second pass for 28 of them, at twice the work per task).  All 27 w*g values of a task are read before
+      // the first use: every s_waitcnt on the LDS is a ~130-cycle round trip.
       // The upper layer (l = 1) is written z-mirrored so that both half-waves run the same node phase.
-      for (int tt = t; tt < 6 * CS3; tt += NT3)
+      for (int tt = t; tt < 9 * CS3; tt += NT3)
         {
-          const int cs = tt % CS3, sub = tt / CS3;
+          const int cs = tt % CS3, task = tt / CS3;
           const bool mir = cs >= CL3;
           double *out = s_tab + cs;
           const double *wq = s_stage + cs;
-          if (sub < 3)
+          if (task < 3)
             {
-              const int c = sub;
+              const int c = task;
               const int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
               const int si = (c == 0) ? 3 : 1;
               const int sj = (c == 2) ? 3 : 9;
-              double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+              double r27[3][3][3];
 #pragma unroll
               for (int qj = 0; qj < 3; ++qj)
 #pragma unroll
                 for (int qi = 0; qi < 3; ++qi)
                   {
                     const int q0 = qi * si + qj * sj;
-                    s9[qj][qi] = (wq[q0 * CS3] + wq[(q0 + sc) * CS3]) + wq[(q0 + 2 * sc) * CS3];
+                    r27[qj][qi][0] = wq[q0 * CS3];
+                    r27[qj][qi][1] = wq[(q0 + sc) * CS3];
+                    r27[qj][qi][2] = wq[(q0 + 2 * sc) * CS3];
                   }
+              __builtin_amdgcn_sched_barrier(0);
+              double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+#pragma unroll
+              for (int qj = 0; qj < 3; ++qj)
+#pragma unroll
+                for (int qi = 0; qi < 3; ++qi)
+                  s9[qj][qi] = (r27[qj][qi][0] + r27[qj][qi][1]) + r27[qj][qi][2];
               const bool zj = (c != 2); // for c = x or y the second moment axis j is z
+              // mirrored: g_j -> 2 - g_j, i.e. index = base + gi*3 + (mir&&zj ? 2 - gj : gj): stride and start per lane
+              const int gj0 = (mir && zj) ? 2 : 0, gjs = (mir && zj) ? -1 : 1;
 #pragma unroll
               for (int gi = 0; gi < 3; ++gi)
                 {
@@ -359,54 +373,54 @@ namespace pfm
                   for (int gj = 0; gj < 3; ++gj)
                     {
                       const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
-                      const int gjs = (mir && zj) ? 2 - gj : gj;
-                      out[(c * 9 + gi * 3 + gjs) * CS3] = val;
+                      out[(c * 9 + gi * 3 + gj0 + gjs * gj) * CS3] = val;
                     }
                 }
             }
           else
             {
-              const int p = sub - 3; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
+              const int p = (task - 3) >> 1, al = (task - 3) & 1; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
               const int slo = (p == 2) ? 3 : 1;
               const int shi = (p == 0) ? 3 : 9;
               const int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
+              const double na0 = al ? c_g1.n[1][0] : c_g1.n[0][0], na1 = al ? c_g1.n[1][1] : c_g1.n[0][1],
+                           na2 = al ? c_g1.n[1][2] : c_g1.n[0][2];
+              double r27[3][3][3];
 #pragma unroll
-              for (int al = 0; al < 2; ++al)
+              for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                for (int qh = 0; qh < 3; ++qh)
+                  {
+                    const int q0 = qh * shi + qe * se;
+                    r27[qe][qh][0] = wq[q0 * CS3];
+                    r27[qe][qh][1] = wq[(q0 + slo) * CS3];
+                    r27[qe][qh][2] = wq[(q0 + 2 * slo) * CS3];
+                  }
+              __builtin_amdgcn_sched_barrier(0);
+              double t1[3][3]; // [q_e][q_hi]
+#pragma unroll
+              for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                for (int qh = 0; qh < 3; ++qh)
+                  t1[qe][qh] = (r27[qe][qh][0] * na0 + r27[qe][qh][1] * na1) + r27[qe][qh][2] * na2;
+              // mirrored layer: p = 0 (e = z): g -> 2 - g; p = 1, 2 (hi = z carries n_be(q_z)): be -> 1 - be and one
+              // z-derivative => sign flip
+              const bool mz = mir && p == 0, mb = mir && p != 0;
+              const int g0 = mz ? 2 : 0, gs = mz ? -1 : 1;
+              const double sgn = mb ? -1.0 : 1.0;
+#pragma unroll
+              for (int be = 0; be < 2; ++be)
                 {
-                  double t1[3][3]; // [q_e][q_hi]
+                  double t2[3];
 #pragma unroll
                   for (int qe = 0; qe < 3; ++qe)
+                    t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
+                  const int bes = mb ? 1 - be : be;
 #pragma unroll
-                    for (int qh = 0; qh < 3; ++qh)
-                      {
-                        const int q0 = qh * shi + qe * se;
-                        t1[qe][qh] = (wq[q0 * CS3] * c_g1.n[al][0] + wq[(q0 + slo) * CS3] * c_g1.n[al][1]) +
-                                     wq[(q0 + 2 * slo) * CS3] * c_g1.n[al][2];
-                      }
-#pragma unroll
-                  for (int be = 0; be < 2; ++be)
+                  for (int g = 0; g < 3; ++g)
                     {
-                      double t2[3];
-#pragma unroll
-                      for (int qe = 0; qe < 3; ++qe)
-                        t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
-#pragma unroll
-                      for (int g = 0; g < 3; ++g)
-                        {
-                          double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
-                          int bes = be, gs = g;
-                          if (mir)
-                            {
-                              if (p == 0)
-                                gs = 2 - g; // e = z
-                              else
-                                {
-                                  bes = 1 - be; // hi = z carries n_be(q_z): one z-derivative => sign flip
-                                  val = -val;
-                                }
-                            }
-                          out[(27 + p * 12 + al * 6 + bes * 3 + gs) * CS3] = val;
-                        }
+                      const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
+                      out[(27 + p * 12 + al * 6 + bes * 3 + g0 + gs * g) * CS3] = sgn * val;
                     }
                 }
             }
@@ -446,12 +460,26 @@ namespace pfm
       auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
         if (regular_tile)
           {
-#pragma unroll 2
-            for (int f = t; f < NN3 * STG; f += NT3)
+            // 6 positions per thread (the last one for t < 32 only): both LDS reads of all of them in flight before the
+            // first store -- a loop pays two dependent LDS round trips (~130 cycles each) per iteration
+            constexpr int NIT = (NN3 * STG + NT3 - 1) / NT3;
+            long long rb[NIT];
+            double val[NIT];
+            int el[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
               {
+                const int f = min(t + NT3 * i, NN3 * STG - 1);
                 const int nl = f / STG;
-                vals[s_rowbase[nl] + c * STG + (f - nl * STG)] = stage[f];
+                el[i] = f - nl * STG;
+                rb[i] = s_rowbase[nl];
+                val[i] = stage[f];
               }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+              if (t + NT3 * i < NN3 * STG)
+                vals[rb[i] + c * STG + el[i]] = val[i];
           }
         else
           {
@@ -566,7 +594,7 @@ namespace pfm
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)
   {
-    static const bool use_uu3 = getenv("PFM_UU3") != nullptr;
+    static const bool use_uu3 = getenv("PFM_UU4") == nullptr;
     return use_uu3 ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -100,24 +100,24 @@ namespace pfm
     }
     __host__ __device__ constexpr int nslots4(int W) { return (W < 2) ? 1 : (W < 6 ? 2 : 4); }
 
-    // Per-lane LDS byte addresses of the lane's cell (node offset (0,0)) in its layer slot, shifted by d z-digits for the
-    // upper half: b[d + 2], d = -2 .. +1 (lower half: all four equal).
+    // Per-lane pointers to the lane's cell (node offset (0,0)) in its layer slot, shifted by d z-digits for the upper
+    // half: b[d + 2], d = -2 .. +1 (lower half: all four equal).
     struct Bases4
     {
-      unsigned b[4];
+      const double *b[4];
     };
 
     // One table value for both half-waves: the lower half (a_z = 1, b_z = 1 + oz) needs table LO, the upper half
-    // (a_z = 0, b_z = -oz) table HI; HI - LO is a multiple of the z-digit stride by construction.  Issued as asm: plain
-    // ds_read_b64 with an immediate offset, not tracked by the compiler (uu4_wait_tables before the first use).
+    // (a_z = 0, b_z = -oz) table HI; HI - LO is a multiple of the z-digit stride by construction, so both read
+    // base[d] + LO with a compile-time offset.  (Plain loads the compiler tracks: an inline-asm ds_read is "complete" for
+    // the register allocator at the end of the statement, and under the register pressure of this kernel it spilled a
+    // destination register before the data had landed.)
     template <int LO, int HI, int CELL_OFF>
     __device__ __forceinline__ void tab_read(const Bases4 &B, double &x)
     {
       static_assert((HI - LO) % ZS4 == 0 && (HI - LO) / ZS4 >= -2 && (HI - LO) / ZS4 <= 1, "z-digit shift out of range");
       constexpr int d = (HI - LO) / ZS4;
-      constexpr int off = (LO * CL3 + CELL_OFF) * 8;
-      static_assert(off >= 0 && off < 65536, "ds offset field");
-      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x) : "v"(B.b[d + 2]), "i"(off) : "memory");
+      x = B.b[d + 2][LO * CL3 + CELL_OFF];
     }
 
     // the 9 table values one visit needs for all nine (row comp, col comp) entries: A^k (k = 0..2), then per pair
@@ -133,13 +133,13 @@ namespace pfm
       static_for<3>([&](auto Kk) __attribute__((always_inline)) {
         constexpr int k = decltype(Kk)::value;
         constexpr int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-        tab_read<numA4(k, aL[i] + bL[i], aL[j] + bL[j]), numA4(k, aU[i] + bU[i], aU[j] + bU[j]), co + 64>(B, tv[k]);
+        tab_read<numA4(k, aL[i] + bL[i], aL[j] + bL[j]), numA4(k, aU[i] + bU[i], aU[j] + bU[j]), co>(B, tv[k]);
       });
       static_for<3>([&](auto Pp) __attribute__((always_inline)) {
         constexpr int p = decltype(Pp)::value;
         constexpr int lo = (p == 2) ? 1 : 0, hi = (p == 0) ? 1 : 2, e = 3 - lo - hi;
-        tab_read<numT4(p, bL[lo], aL[hi], aL[e] + bL[e]), numT4(p, bU[lo], aU[hi], aU[e] + bU[e]), co + 64>(B, tv[3 + 2 * p]);
-        tab_read<numT4(p, aL[lo], bL[hi], aL[e] + bL[e]), numT4(p, aU[lo], bU[hi], aU[e] + bU[e]), co + 64>(B, tv[4 + 2 * p]);
+        tab_read<numT4(p, bL[lo], aL[hi], aL[e] + bL[e]), numT4(p, bU[lo], aU[hi], aU[e] + bU[e]), co>(B, tv[3 + 2 * p]);
+        tab_read<numT4(p, aL[lo], bL[hi], aL[e] + bL[e]), numT4(p, aU[lo], bU[hi], aU[e] + bU[e]), co>(B, tv[4 + 2 * p]);
       });
     }
 
@@ -255,11 +255,16 @@ namespace pfm
     static_assert(NN3 * STG <= TABL, "staging buffer 1 must fit in a layer slot");
 
     // =====================================================================================
-    template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */>
+    // ABL (profiling only, PFM_UU_ABL): 1 = no global stores, 2 = no cell layer (tables stale), 3 = no node arithmetic
+    template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */, int ABL = 0>
     __global__ __launch_bounds__(NT3, 4) void k_cart_uu4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
                                                          int zc /* node planes per chunk */, unsigned long long *__restrict__ dbg)
     {
-      const MatScal &S = *Sp; // per-launch scalars in device memory (see pfm_internal.h)
+      // Per-launch scalars in device memory (see pfm_internal.h), read through the CONSTANT address space: the buffer is
+      // not written while a kernel runs, and only constant-space loads stay scalar (s_load) inside a loop that also
+      // stores to global memory -- through a generic pointer the compiler falls back to per-lane global_load + vmcnt
+      // waits in the middle of the cell phase.
+      const auto &S = *(const __attribute__((address_space(4))) MatScal *)Sp;
       long long tclk = 0;
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
@@ -284,182 +289,262 @@ namespace pfm
       const int kB = min(kA + zc, cv.o1[2] + 1); // node planes [kA, kB)
       const bool lin = !S.monolithic;           // one combined old field is interpolated (cell_wg_plane_lin)
 
-      // ---- loaders: values travel through registers (requested early, stored to LDS later)
-      struct PlaneReg
+      // ---- loaders: a two-stage, branch-free pipeline through registers.  Stage 1 (step k): the local node id of halo
+      // node t of plane k + 3 and of row t - 64 of plane k + 2, where it needs the lattice table (ghost layers,
+      // non-lexicographic numberings).  Stage 2 (step k + 1): the nodal values / row info through that id.  Stored to LDS
+      // at the end of the cell phase of the step after.  Every load is unconditional at a clamped, always valid index (no
+      // control flow around a load: the compiler drains vmcnt at the join of a branch whose arms define the loaded
+      // value), validity is a predicate evaluated where the value is stored.
+      struct HaloPos
+      {
+        int gi, gj;
+        bool is_node, is_row;
+      };
+      auto halo_pos = [&](int t) __attribute__((always_inline)) {
+        HaloPos hp;
+        hp.is_node = t < NHP;
+        hp.is_row = t >= 64 && t < 64 + NN3;
+        const int nl = t - 64;
+        hp.gi = hp.is_row ? i0 + nl % T3X : i0 - 1 + t % H3X;
+        hp.gj = hp.is_row ? j0 + nl / T3X : j0 - 1 + t / H3X;
+        return hp;
+      };
+      auto pos_ok = [&](const HaloPos &hp, int kz) __attribute__((always_inline)) {
+        const bool node_ok = hp.is_node && hp.gi >= 0 && hp.gi < cv.NX && hp.gj >= 0 && hp.gj < cv.NY && kz >= 0 && kz < cv.NZ;
+        const bool row_ok = hp.is_row && hp.gi <= cv.o1[0] && hp.gj <= cv.o1[1] && kz >= cv.o0[2] && kz < kB;
+        return node_ok || row_ok;
+      };
+      // stage 1: halo nodes ask for plane kz, row lanes for plane kz - 1
+      auto id_request = [&](int kz, int t) __attribute__((always_inline)) -> int {
+        const HaloPos hp = halo_pos(t);
+        const int kk = hp.is_row ? kz - 1 : kz;
+        const bool ok = pos_ok(hp, kk);
+        const long long bidx = ok ? hp.gi + (long long)cv.NX * (hp.gj + (long long)cv.NY * kk) : 0;
+        return cv.local_of_box[bidx];
+      };
+      auto local_id = [&](const HaloPos &hp, int kk, int tabval) __attribute__((always_inline)) -> int {
+        const bool arith = cv.owned_lex && hp.gi >= cv.o0[0] && hp.gi <= cv.o1[0] && hp.gj >= cv.o0[1] && hp.gj <= cv.o1[1] &&
+                           kk >= cv.o0[2] && kk <= cv.o1[2];
+        const int aid = (hp.gi - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((hp.gj - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (kk - cv.o0[2]));
+        return arith ? aid : tabval;
+      };
+      struct PlaneReg // a: phi_old or row offset (low), b: phi_oldold, f: flags or neighbour mask
       {
         double a, b;
+        long long off;
         unsigned f;
       };
-      auto plane_request = [&](int kz, PlaneReg &r, int t) __attribute__((always_inline)) {
-        r.a = 0.0, r.b = 0.0, r.f = 0u;
-        if (t < NHP)
-          {
-            const int gi = i0 - 1 + t % H3X, gj = j0 - 1 + t / H3X;
-            if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
-              {
-                const int n = cart_local_id(cv, gi, gj, kz);
-                r.a = v.phi_old[n];
-                r.b = v.phi_oldold[n];
-                r.f = 0x80u | v.node_flags[n];
-              }
-          }
+      // stage 2: halo nodes load plane kz, row lanes the rows of plane kz - 1, through the ids of stage 1
+      auto plane_request = [&](int kz, PlaneReg &r, int t, int tabval) __attribute__((always_inline)) {
+        const HaloPos hp = halo_pos(t);
+        const int kk = hp.is_row ? kz - 1 : kz;
+        const bool ok = pos_ok(hp, kk);
+        const int n = ok ? local_id(hp, kk, tabval) : 0;
+        const int nn = hp.is_row ? 0 : n, nr = hp.is_row ? n : 0;
+        r.a = v.phi_old[nn];
+        r.b = v.phi_oldold[nn];
+        r.f = hp.is_row ? cv.nbr_mask[nr] : (unsigned)v.node_flags[nn];
+        r.off = v.nadj_ptr[nr];
       };
       auto plane_store = [&](int kz, const PlaneReg &r, int t) __attribute__((always_inline)) {
-        if (t < NHP)
+        const HaloPos hp = halo_pos(t);
+        const int kk = hp.is_row ? kz - 1 : kz;
+        const bool ok = pos_ok(hp, kk);
+        if (hp.is_node)
           {
             double a = r.a;
             if (lin)
               a = S.use_old ? r.a : r.b + S.tfac * (r.a - r.b);
-            s.po[kz & 3][t] = a;
-            s.poo[kz & 3][t] = r.b;
-            s.flag[kz & 3][t] = (unsigned char)r.f;
-            const unsigned long long any = __ballot((r.f & 7u) != 0);
+            const unsigned f = ok ? (0x80u | r.f) : 0u;
+            s.po[kz & 3][t] = ok ? a : 0.0;
+            s.poo[kz & 3][t] = ok ? r.b : 0.0;
+            s.flag[kz & 3][t] = (unsigned char)f;
+            const unsigned long long any = __ballot((f & 7u) != 0);
             if (t == 0)
               s.anyflag[kz & 3] = any != 0; // the 60 halo nodes live in wave 0
           }
-      };
-      struct RowReg
-      {
-        long long base;
-        unsigned mask;
-      };
-      auto rows_request = [&](int kz, RowReg &r, int t) __attribute__((always_inline)) {
-        r.base = -1, r.mask = 0u;
-        if (t >= 64 && t < 64 + NN3)
-          {
-            const int nl = t - 64, gi = i0 + nl % T3X, gj = j0 + nl / T3X;
-            if (gi <= cv.o1[0] && gj <= cv.o1[1] && kz < kB)
-              {
-                const int row = cart_local_id(cv, gi, gj, kz);
-                r.base = (long long)NCOL * NCOL * v.nadj_ptr[row];
-                r.mask = cv.nbr_mask[row];
-              }
-          }
-      };
-      auto rows_store = [&](int kz, const RowReg &r, int t) __attribute__((always_inline)) {
-        if (t >= 64 && t < 64 + NN3)
+        else if (hp.is_row)
           {
             const int nl = t - 64;
-            s.rowbase[kz & 1][nl] = r.base;
-            s.mask[kz & 1][nl] = r.mask;
-            const unsigned long long irr = __ballot(r.mask != 0x7ffffffu); // not a full lattice-ordered row of an owned node
+            const unsigned mask = ok ? r.f : 0u;
+            s.rowbase[kk & 1][nl] = ok ? (long long)NCOL * NCOL * r.off : -1;
+            s.mask[kk & 1][nl] = mask;
+            const unsigned long long irr = __ballot(mask != 0x7ffffffu); // not a full lattice-ordered row of an owned node
             if (nl == 0)
-              s.irregular[kz & 1] = irr != 0;
+              s.irregular[kk & 1] = irr != 0;
           }
       };
 
       // ---- one cell layer L (cells between node planes L and L + 1): w*g at the q-points, then the 63 moment tables
       auto cell_layer = [&](int L) __attribute__((always_inline)) {
         const int pl = L & 3, pu = (L + 1) & 3;
-        // the thread index is made opaque per phase: everything derived from it (LDS offsets of 27 reads and 9..12 writes
+        // the thread index is made opaque per phase: everything derived from it (LDS offsets of 27 reads and 6..9 writes
         // per lane) is recomputed per step instead of being hoisted out of the march and spilled
         int tq = t;
         asm volatile("" : "+v"(tq));
-        if (tq < 3 * CL3) // thread <-> (cell, z-level) -> LDS [q][cell]
+        // (a) w*g at the quadrature points: thread <-> (cell, line (q_y, q_z)), 3 q-points each -> LDS [q][cell].
+        // Short dependency chains on 405 threads instead of 9 q-points on 135: the phase is latency, not issue, bound.
+        if (tq < 9 * CL3)
           {
-            const int cs = tq % CL3, qz = tq / CL3;
+            const int cs = tq % CL3, ln = tq / CL3, qy = ln % 3, qz = ln / 3;
             const int cy = cs / C3X, cx = cs % C3X;
             const int h00 = cx + H3X * cy;
             const bool valid = (s.flag[pl][h00] & 0x80u) && (s.flag[pu][h00 + 1 + H3X] & 0x80u);
-            double wg[9];
+            double wg[3] = {0.0, 0.0, 0.0};
             if (valid)
               {
-                double po[8], poo[8];
+                // 1-D Gauss data of the lane's (q_y, q_z) by arithmetic, bit-identical to the table (make_g1): a per-lane
+                // index into constant memory would be a vector load with an exposed L2 round trip in the middle of the phase
+                const double gz = fma((double)(qz - 1), 0.5 * 0.7745966692414834, 0.5), gy = fma((double)(qy - 1), 0.5 * 0.7745966692414834, 0.5);
+                const double nz0 = 1.0 - gz, nz1 = gz, ny0 = 1.0 - gy, ny1 = gy;
+                const double wy = (qy == 1) ? 8.0 / 18.0 : 5.0 / 18.0, wz = (qz == 1) ? 8.0 / 18.0 : 5.0 / 18.0;
+                double po[8];
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
                   po[b] = s.po[(b >> 2) ? pu : pl][h00 + (b & 1) + H3X * ((b >> 1) & 1)];
-                if (lin)
-                  cell_wg_plane_lin(po, S, qz, wg);
-                else
+                // the operation order of cell_wg_plane_lin / cell_wg_plane (pfm_cart_common.h), one line of it
+                double a[4];
+#pragma unroll
+                for (int vtx = 0; vtx < 4; ++vtx)
+                  a[vtx] = nz0 * po[vtx] + nz1 * po[vtx + 4];
+                const double a0 = ny0 * a[0] + ny1 * a[2], a1 = ny0 * a[1] + ny1 * a[3];
+                double b0 = 0.0, b1 = 0.0;
+                if (!lin)
                   {
+                    double poo[8], bb[4];
 #pragma unroll
                     for (int b = 0; b < 8; ++b)
                       poo[b] = s.poo[(b >> 2) ? pu : pl][h00 + (b & 1) + H3X * ((b >> 1) & 1)];
-                    cell_wg_plane(po, poo, S, qz, wg);
+#pragma unroll
+                    for (int vtx = 0; vtx < 4; ++vtx)
+                      bb[vtx] = nz0 * poo[vtx] + nz1 * poo[vtx + 4];
+                    b0 = ny0 * bb[0] + ny1 * bb[2];
+                    b1 = ny0 * bb[1] + ny1 * bb[3];
+                  }
+#pragma unroll
+                for (int qx = 0; qx < 3; ++qx)
+                  {
+                    double pfx = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
+                    if (lin)
+                      {
+                        if (!S.use_old)
+                          pfx = fmin(fmax(pfx, 0.0), 1.0);
+                      }
+                    else
+                      {
+                        double pfo = pfx, pfoo = c_g1.n[0][qx] * b0 + c_g1.n[1][qx] * b1;
+                        if (S.monolithic)
+                          {
+                            pfo = fmax(0.0, pfo);
+                            pfoo = fmax(0.0, pfoo);
+                          }
+                        pfx = pfoo + S.tfac * (pfo - pfoo);
+                        if (pfx <= 0.0)
+                          pfx = 0.0;
+                        if (pfx >= 1.0)
+                          pfx = 1.0;
+                        if (S.use_old)
+                          pfx = pfo;
+                      }
+                    const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+                    wg[qx] = S.vol * (c_g1.w[qx] * wy * wz) * g;
                   }
               }
-            else
-              {
 #pragma unroll
-                for (int q = 0; q < 9; ++q)
-                  wg[q] = 0.0;
-              }
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-              s.stage[(qz * 9 + q) * CL3 + cs] = wg[q];
+            for (int qx = 0; qx < 3; ++qx)
+              s.stage[(ln * 3 + qx) * CL3 + cs] = wg[qx];
           }
         lds_barrier();
         asm volatile("" : "+v"(tq));
-        if (tq < 6 * CL3) // thread <-> (cell, {A^x, A^y, A^z, T^xy, T^xz, T^yz})
+        // (b) moment tables: thread <-> (cell, task), 9 tasks per cell: A^x, A^y, A^z, and the two halves (al = 0, 1) of
+        // T^xy, T^xz, T^yz: 405 threads, ~65 flops each, one pass
+        if (tq < 9 * CL3)
           {
-            const int cs = tq % CL3, sub = tq / CL3;
+            const int cs = tq % CL3, task = tq / CL3;
             double *out = s.tab[L & 1] + cs;
             const double *wq = s.stage + cs;
-            if (sub < 3)
+            if (task < 3)
               {
-                const int c = sub;
+                const int c = task;
                 const int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
                 const int si = (c == 0) ? 3 : 1;
                 const int sj = (c == 2) ? 3 : 9;
                 // table number = nB + nP g_i + nQ g_j (numA4), linear per family: per-lane strides, no select chains
                 const int nB = (c == 0) ? 0 : (c == 1) ? 3 : 54, nP = (c == 2) ? 3 : 1, nQ = (c == 2) ? 1 : ZS4;
-                double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+                // all 27 reads in flight before the first use: every s_waitcnt on the LDS is a ~130-cycle round trip, and
+                // the compiler otherwise interleaves them with the arithmetic in batches of 2..4
+                double r27[3][3][3];
 #pragma unroll
                 for (int qj = 0; qj < 3; ++qj)
 #pragma unroll
                   for (int qi = 0; qi < 3; ++qi)
                     {
                       const int q0 = qi * si + qj * sj;
-                      s9[qj][qi] = (wq[q0 * CL3] + wq[(q0 + sc) * CL3]) + wq[(q0 + 2 * sc) * CL3];
+                      r27[qj][qi][0] = wq[q0 * CL3];
+                      r27[qj][qi][1] = wq[(q0 + sc) * CL3];
+                      r27[qj][qi][2] = wq[(q0 + 2 * sc) * CL3];
                     }
+                __builtin_amdgcn_sched_barrier(0);
+                double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+#pragma unroll
+                for (int qj = 0; qj < 3; ++qj)
+#pragma unroll
+                  for (int qi = 0; qi < 3; ++qi)
+                    s9[qj][qi] = (r27[qj][qi][0] + r27[qj][qi][1]) + r27[qj][qi][2];
 #pragma unroll
                 for (int gi = 0; gi < 3; ++gi)
                   {
-                    double tq[3];
+                    double tq3[3];
 #pragma unroll
                     for (int qj = 0; qj < 3; ++qj)
-                      tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
+                      tq3[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
 #pragma unroll
                     for (int gj = 0; gj < 3; ++gj)
                       {
-                        const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
+                        const double val = tq3[0] * c_g1.m[gj][0] + tq3[1] * c_g1.m[gj][1] + tq3[2] * c_g1.m[gj][2];
                         out[(nB + nP * gi + nQ * gj) * CL3] = val; // numA4(c, gi, gj)
                       }
                   }
               }
             else
               {
-                const int p = sub - 3; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
+                const int p = (task - 3) >> 1, al = (task - 3) & 1; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
                 const int slo = (p == 2) ? 3 : 1;
                 const int shi = (p == 0) ? 3 : 9;
                 const int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
-                const int nB = (p == 0) ? 6 : (p == 1) ? 10 : 16, nP = (p == 0) ? 2 : 3, nQ = (p == 0) ? 1 : ZS4, nR = (p == 0) ? ZS4 : 1;
+                const int nB = ((p == 0) ? 6 : (p == 1) ? 10 : 16) + ((p == 0) ? 2 : 3) * al, nQ = (p == 0) ? 1 : ZS4, nR = (p == 0) ? ZS4 : 1;
+                const double na0 = al ? c_g1.n[1][0] : c_g1.n[0][0], na1 = al ? c_g1.n[1][1] : c_g1.n[0][1],
+                             na2 = al ? c_g1.n[1][2] : c_g1.n[0][2];
+                double r27[3][3][3];
 #pragma unroll
-                for (int al = 0; al < 2; ++al)
+                for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                  for (int qh = 0; qh < 3; ++qh)
+                    {
+                      const int q0 = qh * shi + qe * se;
+                      r27[qe][qh][0] = wq[q0 * CL3];
+                      r27[qe][qh][1] = wq[(q0 + slo) * CL3];
+                      r27[qe][qh][2] = wq[(q0 + 2 * slo) * CL3];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                double t1[3][3]; // [q_e][q_hi]
+#pragma unroll
+                for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                  for (int qh = 0; qh < 3; ++qh)
+                    t1[qe][qh] = (r27[qe][qh][0] * na0 + r27[qe][qh][1] * na1) + r27[qe][qh][2] * na2;
+#pragma unroll
+                for (int be = 0; be < 2; ++be)
                   {
-                    double t1[3][3]; // [q_e][q_hi]
+                    double t2[3];
 #pragma unroll
                     for (int qe = 0; qe < 3; ++qe)
+                      t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
 #pragma unroll
-                      for (int qh = 0; qh < 3; ++qh)
-                        {
-                          const int q0 = qh * shi + qe * se;
-                          t1[qe][qh] = (wq[q0 * CL3] * c_g1.n[al][0] + wq[(q0 + slo) * CL3] * c_g1.n[al][1]) +
-                                       wq[(q0 + 2 * slo) * CL3] * c_g1.n[al][2];
-                        }
-#pragma unroll
-                    for (int be = 0; be < 2; ++be)
+                    for (int g = 0; g < 3; ++g)
                       {
-                        double t2[3];
-#pragma unroll
-                        for (int qe = 0; qe < 3; ++qe)
-                          t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
-#pragma unroll
-                        for (int g = 0; g < 3; ++g)
-                          {
-                            const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
-                            out[(nB + nP * al + nQ * be + nR * g) * CL3] = val; // numT4(p, al, be, g)
-                          }
+                        const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
+                        out[(nB + nQ * be + nR * g) * CL3] = val; // numT4(p, al, be, g)
                       }
                   }
               }
@@ -474,12 +559,34 @@ namespace pfm
         asm volatile("" : "+v"(tq));
         if ((NCOL == 3) && s.irregular[par] == 0)
           {
-#pragma unroll 2
-            for (int f = tq; f < NN3 * STG; f += NT3)
+            // 6 positions per thread (the last one for tq < 32 only): both LDS reads of all of them in flight before the
+            // first store -- a loop would pay two dependent LDS round trips per iteration
+            constexpr int NIT = (NN3 * STG + NT3 - 1) / NT3;
+            long long rb[NIT];
+            double val[NIT];
+            int el[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
               {
+                const int f = min(tq + NT3 * i, NN3 * STG - 1);
                 const int nl = f / STG;
-                vals[s.rowbase[par][nl] + c * STG + (f - nl * STG)] = stage[f];
+                el[i] = f - nl * STG;
+                rb[i] = s.rowbase[par][nl];
+                val[i] = stage[f];
               }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+              if (tq + NT3 * i < NN3 * STG)
+                {
+                  if constexpr (ABL == 1)
+                    {
+                      if (val[i] == 1.2345e300)
+                        vals[rb[i] + c * STG + el[i]] = val[i];
+                    }
+                  else
+                    vals[rb[i] + c * STG + el[i]] = val[i];
+                }
           }
         else
           {
@@ -507,17 +614,18 @@ namespace pfm
 
       // ---- start-up of the chunk: planes kA - 1, kA, kA + 1, rows of plane kA, cell layer kA - 1
       stamp(-1);
+      int id_next; // stage-1 result in flight: ids of plane k + 3 / rows of plane k + 2 at the top of step k
       {
+        // planes kA - 1, kA, kA + 1 and the rows of plane kA (the row lanes of a request for plane kz serve plane kz - 1)
         PlaneReg p0, p1, p2;
-        RowReg r0;
-        plane_request(kA - 1, p0, t);
-        plane_request(kA, p1, t);
-        plane_request(kA + 1, p2, t);
-        rows_request(kA, r0, t);
-        plane_store(kA - 1, p0, t);
-        plane_store(kA, p1, t);
-        plane_store(kA + 1, p2, t);
-        rows_store(kA, r0, t);
+        const int i0r = id_request(kA - 1, t), i1r = id_request(kA, t), i2r = id_request(kA + 1, t);
+        id_next = id_request(kA + 2, t);
+        plane_request(kA - 1, p0, t, i0r);
+        plane_request(kA, p1, t, i1r);
+        plane_request(kA + 1, p2, t, i2r);
+        plane_store(kA - 1, p0, t); // row lanes: rows of plane kA - 2, overwritten below
+        plane_store(kA, p1, t);     // rows of plane kA - 1 (never read)
+        plane_store(kA + 1, p2, t); // rows of plane kA
       }
       __syncthreads();
       stamp(0);
@@ -529,20 +637,22 @@ namespace pfm
         {
           // plane k + 2 and the rows of plane k + 1: requested now, stored before this step's first node barrier
           PlaneReg pn;
-          RowReg rn;
           int tl = t; // opaque per step: nothing derived from the thread index is kept (and spilled) across the march
           asm volatile("" : "+v"(tl));
-          plane_request(k + 2, pn, tl);
-          rows_request(k + 1, rn, tl);
+          plane_request(k + 2, pn, tl, id_next); // plane k + 2, rows of plane k + 1: ids were requested one step ago
+          id_next = id_request(k + 3, tl);
           stamp(0);
-          cell_layer(k); // ends with a barrier: tables of layer k complete, w*g scratch free
+          if constexpr (ABL != 2)
+            cell_layer(k); // ends with a barrier: tables of layer k complete, w*g scratch free
           stamp(2);
 
-          // the requests have had the whole cell phase to land; their ring slots ((k + 2) & 3 = (k - 2) & 3, rows
-          // (k + 1) & 1) are dead since the previous step and are first read after this step's barriers
           asm volatile("" : "+v"(tl));
+          // The requests of the step's top have had the cell phase to land (a global load takes ~3 us while the chip
+          // streams 2.8 TB/s of stores: part of that wait is still exposed here; consuming later would keep 8 more
+          // registers live through the node phase, which is at the 128-register limit).  No store of this step has been
+          // issued yet, so the wait is for the loads alone.  Ring slots (k + 2) & 3 = (k - 2) & 3 and rows (k + 1) & 1 are
+          // dead since the previous step and are first read in the next one.
           plane_store(k + 2, pn, tl);
-          rows_store(k + 1, rn, tl);
 
           // ---- node phase
           const int lane = tl & 63;
@@ -570,12 +680,11 @@ namespace pfm
           // upper half: layer k, same (x,y) cell, z-digit shifts
           Bases4 B;
           {
-            const unsigned cellb = (unsigned)(((tj + 1) * C3X + (ti + 1) - 64) * 8);
-            const unsigned lo_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)s.tab[(k - 1) & 1] + cellb;
-            const unsigned up_b = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)s.tab[k & 1] + cellb;
+            const int cellb = (tj + 1) * C3X + (ti + 1);
+            const double *lo_b = s.tab[(k - 1) & 1] + cellb, *up_b = s.tab[k & 1] + cellb;
 #pragma unroll
             for (int d = -2; d <= 1; ++d)
-              B.b[d + 2] = upper ? up_b + (unsigned)(d * ZS4 * CL3 * 8) : lo_b;
+              B.b[d + 2] = upper ? up_b + d * ZS4 * CL3 : lo_b;
           }
           double tv[4][9];
 #define PFM_PER_SET(STMT)                                                                                                    \
@@ -590,15 +699,17 @@ namespace pfm
       case 6: { constexpr int W = 6; STMT; } break;                                                                          \
       default: { constexpr int W = 7; STMT; } break;                                                                         \
     }
-          // 36 reads in flight, one wait (inside the case: register copies at the join must see landed data)
+          // all 36 reads of the wave's slot set issued before the first use
           PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) { uu4_load_visit<W, decltype(Vv)::value>(B, tv[decltype(Vv)::value]); });
-                      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0))
+                      __builtin_amdgcn_sched_barrier(0))
           // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the slot of layer k - 1: written after
           // the barrier of component 0, which every wave passes with its table values in registers
           double *st0 = s.stage + nl_lane * STG, *st1 = s.tab[(k - 1) & 1] + nl_lane * STG;
           const int hs = upper ? 18 * 3 : 0;
 #define PFM_COMPONENT(C, ST)                                                                                                 \
-  if (masked)                                                                                                                \
+  if constexpr (ABL == 3)                                                                                                    \
+    ;                                                                                                                        \
+  else if (masked)                                                                                                                \
     {                                                                                                                        \
       PFM_PER_SET((uu4_row_component<W, C, true>(tv, K, upper_sign, ST, ST + hs, row_flag, flag_own, flag_half)))            \
     }                                                                                                                        \
@@ -662,6 +773,16 @@ namespace pfm
         for (int i = 0; i < 5; ++i)
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
         fprintf(stderr, "\n");
+      }
+    else if (getenv("PFM_UU_ABL")) // profiling only: ablations
+      {
+        const int abl = atoi(getenv("PFM_UU_ABL"));
+        if (abl == 1)
+          hipLaunchKernelGGL((k_cart_uu4<3, false, 1>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, zc, nullptr);
+        else if (abl == 2)
+          hipLaunchKernelGGL((k_cart_uu4<3, false, 2>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, zc, nullptr);
+        else
+          hipLaunchKernelGGL((k_cart_uu4<3, false, 3>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, zc, nullptr);
       }
     else
       hipLaunchKernelGGL(k_cart_uu4<3>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, zc, nullptr);

@@ -99,7 +99,8 @@ namespace pfm
                        const void *d_scal);
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal);
-  // z-marching successor of launch_cart_uu3 (pfm_cart_uu4.hip); PFM_UU3=1 selects the round-1 kernel (A/B runs)
+  // z-marching variant of launch_cart_uu3 (pfm_cart_uu4.hip): bitwise identical results, measured equal in time;
+  // selected by PFM_UU4=1 (A/B runs, tests/test_gpu_cart.py runs both)
   int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,

@@ -260,3 +260,36 @@ def test_cart_residual_with_old_timestep_phase_field(dim, n):
     _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
     r, _, _ = oracle(c, True)
     assert linf_scaled(res_pde, r.residual_pde) < TOL and linf_scaled(res_tot, r.residual_total) < TOL
+
+
+def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
+    """pfm_cart_uu4.hip (z-marching (u,u) kernel, PFM_UU4=1) against the default k_cart_uu3: same summation order, so
+    every (u,u) value must be the same bit pattern -- on a box with several tiles, partial tiles, z-chunks, constraint
+    flags and both layouts.  The variant is chosen when the library is first used, hence two processes."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
+        "import test_gpu_cart as T\n"
+        "from gpu_util import make_context\n"
+        "out = []\n"
+        "for blocked in (True, False):\n"
+        "    for n in ((19, 9, 40), (6, 6, 6)):\n"
+        "        c = T.box_case(3, n, -10.0, 10.0, blocked)\n"
+        "        ctx = make_context(c)\n"
+        "        values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)\n"
+        "        out.append(values[0])\n"
+        "np.save(sys.argv[1], np.concatenate(out))\n")
+    res = {}
+    for tag, env in (("uu3", {}), ("uu4", {"PFM_UU4": "1"})):
+        f = tmp_path / f"{tag}.npy"
+        e = dict(os.environ, **env)
+        e.pop("PFM_UU4", None) if not env else None
+        subprocess.run([sys.executable, str(script), str(f)], check=True, env=e, timeout=600)
+        res[tag] = np.load(f)
+    assert res["uu3"].shape == res["uu4"].shape
+    assert np.array_equal(res["uu3"], res["uu4"])
