@@ -362,7 +362,9 @@ def main():
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
                                    f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (%d nnz/row-node-comp)' % (4 * 3 ** dim)}",
                        "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
-                       "setup_s": round(t_setup, 2)},
+                       "setup_s": round(t_setup, 2),  # mesh + synthetic state in numpy + context
+                       # pfm_ctx_create alone: what a setup_system() after refine_mesh costs (cracks.cc:4148)
+                       "ctx_create_s": round(asm.ctx.create_seconds, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": abytes,

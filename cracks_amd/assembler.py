@@ -74,7 +74,10 @@ class Context:
             for k, v in enumerate(mesh.box_shape):
                 d.box_cells[k] = int(v)
         self._h = C.c_void_p()
+        import time as _time
+        _t0 = _time.perf_counter()
         rc = self.lib.pfm_ctx_create(C.byref(self._h), C.byref(d), int(device))
+        self.create_seconds = _time.perf_counter() - _t0  # pfm_ctx_create alone (synchronous): the cost after every refine_mesh
         if rc != capi.PFM_OK:
             msg = self.lib.pfm_last_error(self._h).decode() if self._h else ""
             if self._h:

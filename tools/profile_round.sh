@@ -1,0 +1,71 @@
+#!/bin/bash
+# usage: tools/profile_round.sh <tag>      (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r02')
+# One pass over everything the round's DESIGN/VERDICT numbers come from; results under gpurun_out/<tag>/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+tag=${1:-rXX}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err
+python bench.py --residual-only --no-cpu-baseline > $O/bench_216cube_residual_only.json 2>/dev/null
+python bench.py --dim 2 --residual-only --no-cpu-baseline > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
+python bench.py --dim 2 --no-cpu-baseline > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
+PFM_UU4=1 python bench.py --no-cpu-baseline > $O/bench_216cube_uu4.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+run_prof () { # name, extra rocprof args..., -- bench args
+  name=$1; shift
+  rm -rf $O/$name
+  timeout 600 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1
+}
+run_prof stats --stats --output-format csv -d $O/stats -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+cp $O/stats/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube.csv 2>/dev/null
+run_prof stats_res --stats --output-format csv -d $O/stats_res -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --residual-only
+cp $O/stats_res/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube_residual_only.csv 2>/dev/null
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
+run_prof pmc_sq --pmc $SQ --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+cp $O/pmc_sq/p_counter_collection.csv $O/rocprofv3_pmc_SQ_216cube.csv 2>/dev/null
+run_prof pmc_lds --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/pmc_lds -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+cp $O/pmc_lds/p_counter_collection.csv $O/rocprofv3_pmc_LDS_216cube.csv 2>/dev/null
+for ctr in WRITE_SIZE FETCH_SIZE; do
+  run_prof pmc_$ctr --pmc $ctr --output-format csv -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  cp $O/pmc_$ctr/p_counter_collection.csv $O/rocprofv3_pmc_${ctr}_216cube.csv 2>/dev/null
+done
+python - <<PY
+import csv, collections, json, re
+O = "$O"
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
+        if m and "pfm" in r["Kernel_Name"]:
+            acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+# HBM traffic (FETCH_SIZE doubled on gfx950, KiB units: MI355X_MICROARCH.md, HBM section)
+res = collections.defaultdict(dict)
+for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
+    for k, d in per_kernel(f"{O}/rocprofv3_pmc_{ctr}_216cube.csv").items():
+        res[k][ctr.lower().replace("_size", "_bytes")] = d[ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
+keep = ("k_cart_residual3", "k_cart_uu3", "k_cart_uu4", "k_cart_phi4", "k_state_set")
+json.dump({"args": "--steps 3 --warmup 1 --no-cpu-baseline", "per_launch": {k: v for k, v in res.items() if k in keep}},
+          open(f"{O}/hbm_traffic_3d_216.json", "w"), indent=1)
+sq = per_kernel(f"{O}/rocprofv3_pmc_SQ_216cube.csv")
+json.dump({"counter": "SQ_INSTS_VALU (wave-instructions per launch)", "per_launch": {k: v["SQ_INSTS_VALU"] for k, v in sq.items() if k in keep and k != "k_state_set"}},
+          open(f"{O}/valu_instructions_3d_216.json", "w"), indent=1)
+for k, d in sq.items():
+    if k in keep:
+        wc = d["SQ_WAVE_CYCLES"]
+        print(k, "VALU/wave-cycle %.3f  wait %.3f  issue-stall %.3f  active-any %.3f  INSTS_VALU %.3e" % (
+            d["SQ_ACTIVE_INST_VALU"] / wc, d["SQ_WAIT_ANY"] / wc, d["SQ_WAIT_INST_ANY"] / wc, d["SQ_ACTIVE_INST_ANY"] / wc, d["SQ_INSTS_VALU"]))
+for k, d in res.items():
+    if k in keep:
+        print(k, {a: "%.3e" % b for a, b in d.items()})
+PY
+rm -rf $O/stats $O/stats_res $O/pmc_sq $O/pmc_lds $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE
+grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
+python -c "
+import json
+for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residual_only','bench_2d_1000sq_jacobian','bench_216cube_uu4'):
+    try:
+        d=json.load(open('$O/'+f+'.json')); r=d['roofline']; print(f, 'ms/step %.3f kernel_ms %.3f median %.3f frac %.4f value %.3e ctx_create %s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['frac'], d['value'], d['config'].get('ctx_create_s')))
+    except Exception as e: print(f, 'FAILED', e)
+"
