@@ -462,6 +462,17 @@ namespace pfm
                   for (int c = 0; c < 4; ++c)
                     X0[c] = X1[c][0] = X1[c][1] = X2[c][0] = X2[c][1] = 0.0;
                   XS[0] = XS[1] = 0.0;
+                  // along x every interpolated quantity is linear: value(q_x) = v0 + n_1(q_x) (v1 - v0), one FMA per
+                  // q-point instead of a multiply and an FMA (the differences are formed once per line)
+                  double dDy[4], dDz[4];
+#pragma unroll
+                  for (int f = 0; f < 4; ++f)
+                    {
+                      dDy[f] = Dy[f][1] - Dy[f][0];
+                      dDz[f] = Dz[f][1] - Dz[f][0];
+                    }
+                  const double dpf = L[3][1] - L[3][0], dpo = L[4][1] - L[4][0], dpoo = L[5][1] - L[5][0];
+                  const double mu2 = 2 * S.mu;
 #pragma unroll
                   for (int qx = 0; qx < 3; ++qx)
                     {
@@ -473,14 +484,14 @@ namespace pfm
                       for (int c = 0; c < 3; ++c)
                         {
                           gu[c][0] = Dx[c];
-                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
-                          gu[c][2] = nx0 * Dz[c][0] + nx1 * Dz[c][1];
+                          gu[c][1] = fma(nx1, dDy[c], Dy[c][0]);
+                          gu[c][2] = fma(nx1, dDz[c], Dz[c][0]);
                         }
                       gpf[0] = Dx[3];
-                      gpf[1] = nx0 * Dy[3][0] + nx1 * Dy[3][1];
-                      gpf[2] = nx0 * Dz[3][0] + nx1 * Dz[3][1];
-                      double pf = nx0 * L[3][0] + nx1 * L[3][1];
-                      double pfo = nx0 * L[4][0] + nx1 * L[4][1]; // LIN: the combined field
+                      gpf[1] = fma(nx1, dDy[3], Dy[3][0]);
+                      gpf[2] = fma(nx1, dDz[3], Dz[3][0]);
+                      double pf = fma(nx1, dpf, L[3][0]);
+                      double pfo = fma(nx1, dpo, L[4][0]); // LIN: the combined field
                       double pen = 0.0, pfx;
                       if constexpr (LIN)
                         {
@@ -490,7 +501,7 @@ namespace pfm
                         }
                       else
                         {
-                          double pfoo = nx0 * L[5][0] + nx1 * L[5][1];
+                          double pfoo = fma(nx1, dpoo, L[5][0]);
                           if (S.monolithic)
                             {
                               pf = fmax(0.0, pf);
@@ -507,14 +518,15 @@ namespace pfm
                             pfx = pfo;
                         }
                       const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-                      const double e01 = 0.5 * (gu[0][1] + gu[1][0]), e02 = 0.5 * (gu[0][2] + gu[2][0]),
-                                   e12 = 0.5 * (gu[1][2] + gu[2][1]);
+                      // sigma+ = lambda tr(E) I + 2 mu E; with t_ab = g_ab + g_ba: sigma_ab = mu t_ab and
+                      // sigma : E = sum_a sigma_aa g_aa + sum_{a<b} sigma_ab t_ab
+                      const double t01 = gu[0][1] + gu[1][0], t02 = gu[0][2] + gu[2][0], t12 = gu[1][2] + gu[2][1];
                       const double trE = gu[0][0] + gu[1][1] + gu[2][2];
-                      const double lt = S.lam * trE, mu2 = 2 * S.mu;
-                      const double s00 = lt + mu2 * gu[0][0], s11 = lt + mu2 * gu[1][1], s22 = lt + mu2 * gu[2][2];
-                      const double s01 = mu2 * e01, s02 = mu2 * e02, s12 = mu2 * e12;
-                      const double spE = s00 * gu[0][0] + s11 * gu[1][1] + s22 * gu[2][2] +
-                                         2.0 * (s01 * e01 + s02 * e02 + s12 * e12);
+                      const double lt = S.lam * trE;
+                      const double s00 = fma(mu2, gu[0][0], lt), s11 = fma(mu2, gu[1][1], lt), s22 = fma(mu2, gu[2][2], lt);
+                      const double s01 = S.mu * t01, s02 = S.mu * t02, s12 = S.mu * t12;
+                      const double spE = fma(s00, gu[0][0], fma(s11, gu[1][1], s22 * gu[2][2])) +
+                                         fma(s01, t01, fma(s02, t02, s12 * t12));
                       const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;
                       // Z = (g sigma+ - (alpha_B-1) p pfx^2 I) JxW (symmetric)
                       const double z00 = gJ * s00 - pd, z11 = gJ * s11 - pd, z22 = gJ * s22 - pd;
