@@ -663,8 +663,11 @@ namespace pfm
     int rc = ensure_tab();
     if (rc)
       return rc;
-    if (p.decompose_stress_matrix > 0 && p.timestep_number > 0)
+    const bool split = p.decompose_stress_matrix > 0 && p.timestep_number > 0; // cracks.cc:2294
+    if (split)
       return PFM_ERR_UNSUPPORTED; // the host routes split runs to the general path
+    if (v.dim == 2 && !residual_only)
+      return launch_cart2d(v, cv, p, residual_only, d_values, res_pde, res_tot, s); // 2-D Jacobian + residual
     const Scal S = make_scal(p, cv, v.dim);
     const int bs = 256;
     const long long OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = v.dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;

@@ -946,7 +946,7 @@ namespace pfm
                          zc, nullptr);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
-  bool cart_matrix_supported(int dim) { return dim == 3; }
+  bool cart_matrix_supported(int dim) { return dim == 2 || dim == 3; }
 
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
   // (same stream) and clears the structurally zero (u,phi) block (cracks.cc:2333-2337) along with its (phi,u) stores

@@ -1166,7 +1166,7 @@ extern "C"
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
-    if (cart && !residual_only && c->scal_dirty)
+    if (cart && !residual_only && c->v.dim == 3 && c->scal_dirty)
       {
         // off the hot path: once per pfm_set_params, complete before any kernel of any stream may read it
         int rcs = upload_mat_scal(c->prm, c->cv, c->d_scal, c->stream);

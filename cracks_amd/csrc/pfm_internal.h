@@ -82,6 +82,9 @@ namespace pfm
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
                            hipStream_t s_residual, void *d_scal);
   bool cart_matrix_supported(int dim);
+  // 2-D boxes: row-owner Jacobian + residual, stress split included (pfm_cart2d.hip)
+  int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
+                    double *res_pde, double *res_tot, hipStream_t s);
   // z-chunk length of a marching kernel: `tiles` columns, `planes` node planes, one redundant cell layer per chunk,
   // `per_cu` resident workgroups per CU.  Maximises (fill of the last dispatch round) x (useful layers per chunk).
   int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu);

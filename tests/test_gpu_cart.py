@@ -293,3 +293,58 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
         res[tag] = np.load(f)
     assert res["uu3"].shape == res["uu4"].shape
     assert np.array_equal(res["uu3"], res["uu4"])
+
+
+# ---- 2-D row-owner Jacobian (pfm_cart2d.hip): BASELINE config 2 with the matrix, tests/sneddon_2d_1.prm on a uniform mesh
+BOXES_2D = [(2, (12, 7), (-3.0, 1.0), (1.0, 2.0)), (2, (17, 17), -10.0, 10.0), (2, (130, 5), -10.0, 10.0), (2, (1, 9), 0.0, 1.0)]
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("dim,n,lo,hi", BOXES_2D)
+@pytest.mark.parametrize("monolithic", [False, True])
+def test_cart2d_full_matrix_matches_oracle(dim, n, lo, hi, blocked, monolithic):
+    c = box_case(dim, n, lo, hi, blocked, monolithic=monolithic)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    _full(c, path=1)
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("kappa_zero", [False, True])
+def test_cart2d_random_constraints_and_placeholders(blocked, kappa_zero):
+    """Random homogeneous constraints (interior dofs included), pressure on; kappa = 0 with g = 0 in whole cells: the
+    constrained rows must take deal.II's mean-|diagonal| placeholder (the slow path of the 2-D kernel)."""
+    c = box_case(2, (41, 23), (-1.0, 0.0), (1.5, 1.0), blocked, seed=7)
+    rng = np.random.default_rng(9)
+    lay = c.layout
+    node, comp = lay.node_comp_of_dof()
+    pick = np.where(comp == 2, rng.random(lay.n_dofs) < 0.2, rng.random(lay.n_dofs) < 0.08)
+    dd = np.union1d(M.sneddon_dirichlet_dofs(c.mesh, lay), np.nonzero(pick)[0])
+    c.cu = M.update_constraints(c.mesh, lay, dd)
+    c.params.pressure = 3.0e-3
+    if kappa_zero:
+        c.params.constant_k = 0.0
+        far = c.mesh.coords[:, 1] > 0.6
+        for v in (c.old, c.oldold):
+            v[lay.dof(np.nonzero(far)[0], 2)] = 0.0
+    _full(c, path=1)
+    # overwrite semantics + bitwise reproducibility of the row-owner kernel
+    ctx = make_context(c)
+    v0, r0, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    v1, r1, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    assert all(np.array_equal(a, b) for a, b in zip(v0, v1)) and np.array_equal(r0, r1)
+
+
+def test_cart2d_split_runs_stay_on_the_general_family():
+    """decompose_stress_matrix > 0 and timestep_number > 0 on a 2-D lattice: correct through the general family."""
+    c = box_case(2, (9, 8), 0.0, 1.0, False)
+    c.params.decompose_stress_matrix = 1.0
+    c.params.decompose_stress_rhs = 1.0
+    c.params.timestep_number = 2
+    ctx = make_context(c)
+    values, res_pde, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+    r, rp, ci = oracle(c, False)
+    A_ref = sp.csr_matrix((r.values, ci, rp), shape=(c.layout.n_dofs,) * 2)
+    A = blocks_to_global(ctx, c.layout, values)
+    A.sort_indices()
+    assert linf_scaled(A.data, A_ref.data) < 1e-11 and linf_scaled(res_pde, r.residual_pde) < 1e-11
