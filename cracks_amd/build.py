@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpfm_hip.so")
 SOURCES = ["pfm_host.cpp", "pfm_kernels.hip"]
-HEADERS = ["pfm_internal.h", "pfm_cart_common.h", os.path.join("..", "..", "include", "pfm_assemble.h"),
+HEADERS = ["pfm_internal.h", "pfm_cart_common.h", "pfm_split.h", os.path.join("..", "..", "include", "pfm_assemble.h"),
            os.path.join("..", "..", "include", "pfm_params.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -142,6 +142,13 @@ namespace pfm
             continue;
           if (dim == 3 && (ck < 0 || ck >= cv.NZ - 1))
             continue;
+          double lam = S.lam, mu = S.mu;
+          if (cv.cell_lam) // heterogeneous material, cracks.cc:2207-2216
+            {
+              const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * (dim == 3 ? ck : 0));
+              lam = cv.cell_lam[cidx];
+              mu = cv.cell_mu[cidx];
+            }
           // nodal values of the cell: [field][vertex]; fields u(dim), phi, phi_old, phi_oldold
           double U[dim + 3][nv];
 #pragma unroll
@@ -262,7 +269,7 @@ namespace pfm
 #pragma unroll
                         for (int b = 0; b < dim; ++b)
                           {
-                            const double sp = S.lam * trE * (a == b ? 1.0 : 0.0) + 2 * S.mu * E[a][b];
+                            const double sp = lam * trE * (a == b ? 1.0 : 0.0) + 2 * mu * E[a][b];
                             spE += sp * E[a][b];
                             Z[a][b] = (g * sp - (a == b ? S.aB1 * S.p * pfx * pfx : 0.0)) * JxW;
                           }
@@ -418,6 +425,13 @@ namespace pfm
           if (col_ok && ck >= 0 && ck < cv.NZ - 1)
             {
               const double *Ulo = &s_U[lo][0][hb], *Uhi = &s_U[hi][0][hb];
+              double lam = S.lam, mu = S.mu;
+              if (cv.cell_lam) // heterogeneous material, cracks.cc:2207-2216
+                {
+                  const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+                  lam = cv.cell_lam[cidx];
+                  mu = cv.cell_mu[cidx];
+                }
               double Dy[4][2]; // d/dy at x-vertex 0/1: depends on the z-level only
 #pragma unroll 1
               for (int p = 0; p < 9; ++p)
@@ -472,7 +486,7 @@ namespace pfm
                       dDz[f] = Dz[f][1] - Dz[f][0];
                     }
                   const double dpf = L[3][1] - L[3][0], dpo = L[4][1] - L[4][0], dpoo = L[5][1] - L[5][0];
-                  const double mu2 = 2 * S.mu;
+                  const double mu2 = 2 * mu;
 #pragma unroll
                   for (int qx = 0; qx < 3; ++qx)
                     {
@@ -522,9 +536,9 @@ namespace pfm
                       // sigma : E = sum_a sigma_aa g_aa + sum_{a<b} sigma_ab t_ab
                       const double t01 = gu[0][1] + gu[1][0], t02 = gu[0][2] + gu[2][0], t12 = gu[1][2] + gu[2][1];
                       const double trE = gu[0][0] + gu[1][1] + gu[2][2];
-                      const double lt = S.lam * trE;
+                      const double lt = lam * trE;
                       const double s00 = fma(mu2, gu[0][0], lt), s11 = fma(mu2, gu[1][1], lt), s22 = fma(mu2, gu[2][2], lt);
-                      const double s01 = S.mu * t01, s02 = S.mu * t02, s12 = S.mu * t12;
+                      const double s01 = mu * t01, s02 = mu * t02, s12 = mu * t12;
                       const double spE = fma(s00, gu[0][0], fma(s11, gu[1][1], s22 * gu[2][2])) +
                                          fma(s01, t01, fma(s02, t02, s12 * t12));
                       const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;

@@ -32,6 +32,7 @@ namespace pfm
     struct Cell2 // nodal data of one cell: [vertex]
     {
       double u[2][4], ph[4], pho[4], phoo[4];
+      double lam, mu; // Lame coefficients of the cell (cracks.cc:2207-2216)
     };
 
     struct Prm2 // resolved scalars
@@ -104,7 +105,7 @@ namespace pfm
             }
           double sp[2][2], sm[2][2];
           if constexpr (SPLIT)
-            ortho_ok &= split_stress(E, trE, P.lam, P.mu, sp, sm);
+            ortho_ok &= split_stress(E, trE, C.lam, C.mu, sp, sm);
           else
             {
 #pragma unroll
@@ -112,7 +113,7 @@ namespace pfm
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                   {
-                    sp[i][j] = P.lam * trE * (i == j ? 1.0 : 0.0) + 2 * P.mu * E[i][j];
+                    sp[i][j] = C.lam * trE * (i == j ? 1.0 : 0.0) + 2 * C.mu * E[i][j];
                     sm[i][j] = 0.0;
                   }
             }
@@ -141,7 +142,7 @@ namespace pfm
                     const double trEL = gN[b][d];
                     double spL[2][2], smL[2][2];
                     if constexpr (SPLIT)
-                      ortho_ok &= split_stress_lin(E, trE, EL, trEL, P.lam, P.mu, spL, smL);
+                      ortho_ok &= split_stress_lin(E, trE, EL, trEL, C.lam, C.mu, spL, smL);
                     else
                       {
 #pragma unroll
@@ -149,7 +150,7 @@ namespace pfm
 #pragma unroll
                           for (int j = 0; j < 2; ++j)
                             {
-                              spL[i][j] = P.lam * trEL * (i == j ? 1.0 : 0.0) + 2 * P.mu * EL[i][j];
+                              spL[i][j] = C.lam * trEL * (i == j ? 1.0 : 0.0) + 2 * C.mu * EL[i][j];
                               smL[i][j] = 0.0;
                             }
                       }
@@ -315,6 +316,13 @@ namespace pfm
         if (ci < 0 || ci >= cv.NX - 1 || cj < 0 || cj >= cv.NY - 1)
           return;
         Cell2 C;
+        C.lam = P.lam;
+        C.mu = P.mu;
+        if (cv.cell_lam)
+          {
+            C.lam = cv.cell_lam[ci + (long long)(cv.NX - 1) * cj];
+            C.mu = cv.cell_mu[ci + (long long)(cv.NX - 1) * cj];
+          }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           {

@@ -156,11 +156,11 @@ namespace pfm
     // ---- role d: (phi,u) entries of column component D of one cell.  The x- and y-contractions are factored
     // (X, Y accumulators); the z-contraction is folded into the push, one push per z-level of q-points, so the
     // 54 numbers C^{dk}[al][g_i][g_j] never have to be held in registers.
-    template <int D>
+    template <int D, bool HET>
     __device__ __forceinline__ void pu_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
-                                            bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
+                                            double cell_muh, double cell_la, bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
     {
-      const double c_muh = S.c_muh, c_la = S.c_la, cdiag = S.cdiag;
+      const double c_muh = HET ? cell_muh : S.c_muh, c_la = HET ? cell_la : S.c_la, cdiag = S.cdiag;
       double V[4][8]; // u_x u_y u_z phi at the cell's vertices
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -305,8 +305,9 @@ namespace pfm
     }
 
     // ---- role 3: (phi,phi) entries of one cell, same scheme; returns the 8 diagonal entries of the element matrix
+    template <bool HET>
     __device__ __forceinline__ void pp_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
-                                            bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
+                                            double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
                                             double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
                                             double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
     {
@@ -382,7 +383,7 @@ namespace pfm
                       const double s01 = gu[0][1] + gu[1][0], s02 = gu[0][2] + gu[2][0], s12 = gu[1][2] + gu[2][1];
                       const double EE = (gu[0][0] * gu[0][0] + gu[1][1] * gu[1][1] + gu[2][2] * gu[2][2]) +
                                         0.5 * (s01 * s01 + s02 * s02 + s12 * s12);
-                      const double spE = S.lam * trE * trE + 2 * S.mu * EE;       // sigma+ : E
+                      const double spE = (HET ? cell_lam : S.lam) * trE * trE + 2 * (HET ? cell_mu : S.mu) * EE;       // sigma+ : E
                       const double pen = (!use_pen || (pf - pfo) < 0.0) ? 0.0 : S.gamma_fac; // cracks.cc:2311-2315, 2370
                       const double cq = S.omk * spE + S.gc_eps - S.aB1p2 * trE + pen;
                       const double wc = (wyz * c_g1.w[qx]) * cq;
@@ -435,7 +436,8 @@ namespace pfm
     }
 
     // =====================================================================================
-    template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */>
+    template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */,
+              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */>
     __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
                                                           double *__restrict__ vals_up /* blocked layout: structurally zero (u,phi) block, cleared here */,
@@ -590,16 +592,25 @@ namespace pfm
           dst.hi_m1 = s.pu[np];
           dst.hi_z0 = s.pu[2 + np];
           const double *Ulo = &s.U[lo][0][hb], *Uhi = &s.U[hi][0][hb];
+          double lam = 0.0, mu = 0.0, c_muh = 0.0, c_la = 0.0;
+          if (HET && cell_ok) // heterogeneous material, cracks.cc:2207-2216
+            {
+              const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+              lam = cv.cell_lam[cidx];
+              mu = cv.cell_mu[cidx];
+              c_muh = 2.0 * (1.0 - S.kappa) * mu;
+              c_la = 2.0 * (1.0 - S.kappa) * lam;
+            }
           if (role == 0)
-            pu_role<0>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+            pu_role<0, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else if (role == 1)
-            pu_role<1>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+            pu_role<1, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else if (role == 2)
-            pu_role<2>(Ulo, Uhi, S, cell_ok, dst, nl0, cx, cy);
+            pu_role<2, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else
             {
               double Mdiag[8];
-              pp_role(Ulo, Uhi, S, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+              pp_role<HET>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
               double avg = 0.0, patch = 0.0;
               if (cell_ok)
                 {
@@ -652,7 +663,17 @@ namespace pfm
                       double usum = 0.0;
 #pragma unroll
                       for (int k = 0; k < 3; ++k)
-                        usum += (S.cA[0][k] + S.cA[1][k] + S.cA[2][k]) * 2.0 * gk[k];
+                        {
+                          double ca = S.cA[0][k] + S.cA[1][k] + S.cA[2][k];
+                          if constexpr (HET) // MatScal::cA with this cell's coefficients
+                            {
+                              ca = 0.0;
+#pragma unroll
+                              for (int c = 0; c < 3; ++c)
+                                ca += (k == c ? lam + 2 * mu : mu) * S.ih[k] * S.ih[k];
+                            }
+                          usum += ca * 2.0 * gk[k];
+                        }
                       avg = (dsum + usum) / 32.0;
                       patch = (gsum == 0.0) ? avg : 0.0;
                     }
@@ -912,7 +933,13 @@ namespace pfm
     const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
     const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
-    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+    if (cv.cell_lam && v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL((k_cart_phi4<4, 0, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr, zc,
+                         nullptr);
+    else if (cv.cell_lam)
+      hipLaunchKernelGGL((k_cart_phi4<3, 0, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0],
+                         d_values[1], zc, nullptr);
+    else if (v.layout == PFM_LAYOUT_INTERLEAVED)
       hipLaunchKernelGGL(k_cart_phi4<4>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr, zc, nullptr);
     else if (getenv("PFM_PHI_CLK")) // profiling only
       {
@@ -956,7 +983,7 @@ namespace pfm
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
     static const bool use_uu3 = getenv("PFM_UU4") == nullptr; // PFM_UU4=1: the z-marching variant (pfm_cart_uu4.hip), measured equal
-    int rc = use_uu3 ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal) : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
+    int rc = (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal) : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
     if (rc)
       return rc;
     return launch_cart_phi4(v, cv, p, d_values, s, d_scal);

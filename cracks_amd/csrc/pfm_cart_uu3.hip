@@ -109,16 +109,40 @@ namespace pfm
     struct UuCoef // uniform constants of the node phase, read once per workgroup
     {
       double cA[3][3], cTl[3], cTm[3];
+      double gA[3], cT[3]; // heterogeneous material: the geometric factors alone, 1 / h_k^2 and 1 / (h_lo h_hi)
     };
 
     // r += entry (C, D) of one visit, same operation order as the reference formulation K = lambda G^{CD} + mu G^{DC} +
     // mu delta_CD tr G (every table value enters through one FMA with a host-precombined constant)
-    template <int W, int V, int C, int D>
-    __device__ __forceinline__ void uu_acc_visit(const double (&tv)[9], const UuCoef &K, double &r)
+    // HET: lam, mu = Lame coefficients of the visited cell (cracks.cc:2207-2216); the constants of MatScal are formed
+    // per visit from the geometric factors
+    template <int W, int V, int C, int D, bool HET>
+    __device__ __forceinline__ void uu_acc_visit(const double (&tv)[9], const UuCoef &K, double lam, double mu, double &r)
     {
       constexpr Vis vi = visit_of(W, V);
       constexpr int a[3] = {-vi.ex, -vi.ey, 1}, b[3] = {-vi.ex + vi.ox, -vi.ey + vi.oy, 1 + vi.oz};
-      if constexpr (C == D)
+      if constexpr (HET)
+        {
+          if constexpr (C == D)
+            {
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                {
+                  const double ca = (k == C ? lam + 2 * mu : mu) * K.gA[k];
+                  r = fma((sg3(a[k]) * sg3(b[k]) > 0) ? ca : -ca, tv[k], r);
+                }
+            }
+          else
+            {
+              constexpr int lo = C < D ? C : D, hi = C < D ? D : C, p = pair3(lo, hi);
+              const double t1 = (C < D) ? tv[3 + 2 * p] : tv[4 + 2 * p];
+              const double t2 = (C < D) ? tv[4 + 2 * p] : tv[3 + 2 * p];
+              const double cl = K.cT[p] * lam, cm = K.cT[p] * mu;
+              r = fma((sg3(a[C]) * sg3(b[D]) > 0) ? cl : -cl, t1, r);
+              r = fma((sg3(a[D]) * sg3(b[C]) > 0) ? cm : -cm, t2, r);
+            }
+        }
+      else if constexpr (C == D)
         {
 #pragma unroll
           for (int k = 0; k < 3; ++k)
@@ -147,8 +171,9 @@ namespace pfm
     // the oz = 0 slots, the constraint masks, 3 staged values per slot.  stage_half = the lane's staged row shifted by 18
     // slots for the upper half (a slot with oz = -1 completed by the lower half is slot o_lo, its mirror completed by the
     // upper half is o_lo + 18); oz = 0 slots are summed over the halves and stored by both (same value, same address).
-    template <int W, int C, bool MASKED>
-    __device__ __forceinline__ void uu_row_component(const double (&tv)[4][9], const UuCoef &K, double *__restrict__ stage_row,
+    template <int W, int C, bool MASKED, bool HET>
+    __device__ __forceinline__ void uu_row_component(const double (&tv)[4][9], const UuCoef &K, const double (&lamv)[4],
+                                                     const double (&muv)[4], double *__restrict__ stage_row,
                                                      double *__restrict__ stage_half, unsigned row_flag,
                                                      const unsigned char *__restrict__ flag_own,
                                                      const unsigned char *__restrict__ flag_half)
@@ -161,9 +186,9 @@ namespace pfm
       static_for<4>([&](auto Vv) __attribute__((always_inline)) {
         constexpr int V = decltype(Vv)::value;
         constexpr Vis vi = visit_of(W, V);
-        uu_acc_visit<W, V, C, 0>(tv[V], K, val[vi.slot][0]);
-        uu_acc_visit<W, V, C, 1>(tv[V], K, val[vi.slot][1]);
-        uu_acc_visit<W, V, C, 2>(tv[V], K, val[vi.slot][2]);
+        uu_acc_visit<W, V, C, 0, HET>(tv[V], K, lamv[V], muv[V], val[vi.slot][0]);
+        uu_acc_visit<W, V, C, 1, HET>(tv[V], K, lamv[V], muv[V], val[vi.slot][1]);
+        uu_acc_visit<W, V, C, 2, HET>(tv[V], K, lamv[V], muv[V], val[vi.slot][2]);
       });
       static_for<4>([&](auto Vv) __attribute__((always_inline)) {
         constexpr int V = decltype(Vv)::value;
@@ -199,7 +224,8 @@ namespace pfm
     }
 
     // =====================================================================================
-    template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */>
+    template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */,
+              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */>
     __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
                                                          unsigned long long *__restrict__ dbg)
     {
@@ -222,6 +248,7 @@ namespace pfm
       __shared__ unsigned char s_flag[NH3];
       __shared__ long long s_rowbase[NN3];
       __shared__ unsigned s_mask[NN3]; // neighbour mask of the row (bit o: lattice offset o exists)
+      __shared__ double s_lam[HET ? CS3 : 1], s_mu[HET ? CS3 : 1]; // Lame coefficients of the tile's cells
       __shared__ int s_any[4]; // waves 0..2: some node of the halo carries a displacement flag; [3]: some row is not full
       static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
 
@@ -277,6 +304,20 @@ namespace pfm
           const unsigned long long irr = __ballot(mask != 0x7ffffffu); // fewer than 27 neighbours, or not an owned node
           if (nl == 0)
             s_any[3] = irr != 0;
+        }
+      else if (HET && t >= 320 && t < 320 + CS3)
+        {
+          const int cs = t - 320, l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
+          const int ci = i0 - 1 + cx, cj = j0 - 1 + cy, ck = k - 1 + l;
+          double la = 0.0, mu = 0.0;
+          if (ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1 && ck >= 0 && ck < cv.NZ - 1)
+            {
+              const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+              la = cv.cell_lam[cidx];
+              mu = cv.cell_mu[cidx];
+            }
+          s_lam[HET ? cs : 0] = la;
+          s_mu[HET ? cs : 0] = mu;
         }
       __syncthreads();
       stamp(0);
@@ -455,6 +496,8 @@ namespace pfm
             K.cA[c][k] = S.cA[c][k];
           K.cTl[c] = S.cTl[c];
           K.cTm[c] = S.cTm[c];
+          K.gA[c] = S.ih[c] * S.ih[c];
+          K.cT[c] = S.cT[c];
         }
 
       auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
@@ -522,7 +565,18 @@ namespace pfm
       case 6: { constexpr int W = 6; STMT; } break;                                                                          \
       default: { constexpr int W = 7; STMT; } break;                                                                         \
     }
-      PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) { uu_load_visit<W, decltype(Vv)::value>(lane_base, tv[decltype(Vv)::value]); }))
+      double lamv[4] = {0.0, 0.0, 0.0, 0.0}, muv[4] = {0.0, 0.0, 0.0, 0.0}; // HET: coefficients of the 4 visited cells
+      PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+        constexpr int V = decltype(Vv)::value;
+        uu_load_visit<W, V>(lane_base, tv[V]);
+        if constexpr (HET)
+          {
+            constexpr Vis vi = visit_of(W, V);
+            const int cs = (int)(lane_base - s_tab) + (vi.ey * C3X + vi.ex);
+            lamv[V] = s_lam[cs];
+            muv[V] = s_mu[cs];
+          }
+      }))
       // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the table storage: written after the
       // barrier of component 0, which every wave passes with its table values in registers
       double *st0 = s_stage + nl_lane * STG, *st1 = s_tab + nl_lane * STG;
@@ -530,11 +584,11 @@ namespace pfm
 #define PFM_COMPONENT(C, ST)                                                                                                 \
   if (masked)                                                                                                                \
     {                                                                                                                        \
-      PFM_PER_SET((uu_row_component<W, C, true>(tv, K, ST, ST + hs, row_flag, flag_own, flag_half)))                         \
+      PFM_PER_SET((uu_row_component<W, C, true, HET>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half)))                         \
     }                                                                                                                        \
   else                                                                                                                       \
     {                                                                                                                        \
-      PFM_PER_SET((uu_row_component<W, C, false>(tv, K, ST, ST + hs, row_flag, flag_own, flag_half)))                        \
+      PFM_PER_SET((uu_row_component<W, C, false, HET>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half)))                        \
     }
       PFM_COMPONENT(0, st0)
       lds_barrier();
@@ -565,7 +619,11 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
-    if (v.layout == PFM_LAYOUT_INTERLEAVED)
+    if (cv.cell_lam && v.layout == PFM_LAYOUT_INTERLEAVED)
+      hipLaunchKernelGGL((k_cart_uu3<4, false, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+    else if (cv.cell_lam)
+      hipLaunchKernelGGL((k_cart_uu3<3, false, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+    else if (v.layout == PFM_LAYOUT_INTERLEAVED)
       hipLaunchKernelGGL(k_cart_uu3<4>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
     else if (getenv("PFM_UU_CLK")) // profiling only
       {
@@ -595,6 +653,6 @@ namespace pfm
                           void *d_scal)
   {
     static const bool use_uu3 = getenv("PFM_UU4") == nullptr;
-    return use_uu3 ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
+    return (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -382,6 +382,26 @@ namespace
       }
     cv.local_of_box = dev_upload(c, L.local_of_box.data(), L.local_of_box.size());
     upload_row_tables(c, mask, perm, any_perm);
+    cv.cell_lam = cv.cell_mu = nullptr;
+    if (m->cell_lambda && m->cell_mu)
+      {
+        // heterogeneous material: the row-owner kernels address cells by lattice position
+        const int nv = 1 << m->dim;
+        const int64_t CX = NX - 1, CY = NY - 1;
+        std::vector<double> la((size_t)m->n_cells), mu((size_t)m->n_cells);
+        parallel_for(m->n_cells, [&](int64_t cb, int64_t ce) {
+          for (int64_t cell = cb; cell < ce; ++cell)
+            {
+              const int64_t b0 = box_of_local[m->cell_nodes[cell * nv]]; // vertex 0 = lower corner (detect_lattice)
+              const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / ((int64_t)NX * NY);
+              const int64_t at = i + CX * (j + CY * k);
+              la[at] = m->cell_lambda[cell];
+              mu[at] = m->cell_mu[cell];
+            }
+        });
+        cv.cell_lam = dev_upload(c, la.data(), la.size());
+        cv.cell_mu = dev_upload(c, mu.data(), mu.size());
+      }
     cv.owned_lex = 1;
     {
       const int64_t OWX = o1[0] - o0[0] + 1, OWY = o1[1] - o0[1] + 1;
@@ -550,6 +570,67 @@ extern "C"
               xs[(size_t)d * N + n] = m->coords[(size_t)n * dim + d];
           v.coords = dev_upload(c, xs.data(), xs.size());
         }
+        {
+          // Colour classes of the general cell kernel: cells of one class share no node and are assembled by one
+          // launch with plain read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter
+          // of a 2-D Jacobian took 1.1 of 1.2 ms).  Lattice: parity of the cell's lattice position; otherwise greedy
+          // in cell order.  Cells with a hanging vertex go to the last class, which keeps the atomics.
+          std::vector<uint8_t> col((size_t)NC);
+          int n_col = 0;
+          if (lattice_ok)
+            {
+              const int64_t NX = lattice.NX, NY = lattice.NY;
+              parallel_for(NC, [&](int64_t cb, int64_t ce) {
+                for (int64_t cell = cb; cell < ce; ++cell)
+                  {
+                    const int64_t b0 = lattice.box_of_local[m->cell_nodes[cell * nv]];
+                    const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / (NX * NY);
+                    col[cell] = (uint8_t)((i & 1) + 2 * (j & 1) + 4 * (k & 1));
+                  }
+              });
+              n_col = dim == 3 ? 8 : 4;
+            }
+          else
+            {
+              std::vector<uint64_t> used((size_t)N, 0);
+              for (int64_t cell = 0; cell < NC; ++cell)
+                {
+                  uint64_t mask = 0;
+                  bool hanging = false;
+                  for (int a = 0; a < nv; ++a)
+                    {
+                      const int32_t n = m->cell_nodes[cell * nv + a];
+                      mask |= used[n];
+                      hanging = hanging || (!hn_index.empty() && hn_index[n] >= 0);
+                    }
+                  int k = 63;
+                  if (!hanging && ~mask != 0)
+                    k = __builtin_ctzll(~mask);
+                  if (k < 62)
+                    {
+                      for (int a = 0; a < nv; ++a)
+                        used[m->cell_nodes[cell * nv + a]] |= 1ull << k;
+                      n_col = std::max(n_col, k + 1);
+                    }
+                  col[cell] = (uint8_t)std::min(k, 63);
+                }
+              for (int64_t cell = 0; cell < NC; ++cell)
+                if (col[cell] >= 62)
+                  col[cell] = (uint8_t)n_col; // hanging vertices (or more than 62 classes): the atomic class
+            }
+          c->color_ptr.assign((size_t)n_col + 2, 0);
+          for (int64_t cell = 0; cell < NC; ++cell)
+            ++c->color_ptr[col[cell] + 1];
+          for (int k = 0; k <= n_col; ++k)
+            c->color_ptr[k + 1] += c->color_ptr[k];
+          std::vector<int32_t> order((size_t)NC);
+          {
+            std::vector<long long> fill(c->color_ptr.begin(), c->color_ptr.end() - 1);
+            for (int64_t cell = 0; cell < NC; ++cell)
+              order[fill[col[cell]]++] = (int32_t)cell;
+          }
+          v.color_cells = dev_upload(c, order.data(), order.size());
+        }
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
           {
@@ -608,7 +689,7 @@ extern "C"
       }
     try
       {
-        c->cart_ok = lattice_ok && !m->cell_lambda && !m->cell_mu && build_cart(c, m, lattice);
+        c->cart_ok = lattice_ok && build_cart(c, m, lattice);
         if (!c->cart_ok)
           c->lat = Lattice{}; // the host lattice tables are only kept for pfm_pattern_bind on the cartesian path
         if (hipDeviceSynchronize() != hipSuccess)
@@ -1177,7 +1258,7 @@ extern "C"
         c->scal_dirty = false;
       }
     int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal)
-                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream);
+                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr);
     if (fork)
       {
         e = hipEventRecord(c->ev_join, s_res);

@@ -22,6 +22,8 @@ namespace pfm
     const long long *nadj_ptr; // [n_owned+1]  node graph (rows = owned nodes, sorted columns)
     const int32_t *nadj;
     const uint8_t *cslot;      // [n_cells][nv*nv] slot of vertex b's node in the row of vertex a's node
+    const int32_t *color_cells; // [n_cells] cell ids sorted by colour class (pfm_ctx::color_ptr): no two cells of a class
+                                // share a node, so the general cell kernel adds into the rows without atomics
     const int32_t *hn_index;   // [n_nodes] -> k (hanging table) or -1; nullptr when the mesh is conforming
     const long long *hn_ptr;
     const int32_t *hn_parents;
@@ -47,6 +49,8 @@ namespace pfm
     const uint8_t *row_perm;     // rows whose order is not the lattice order (bit 31 of nbr_mask: e.g. ghost columns
                                  // sorted behind the owned ones): CSR slot of the r-th existing offset =
                                  // row_perm[nadj_ptr[row] + r]; nullptr when no row needs it
+    const double *cell_lam, *cell_mu; // per-cell Lame coefficients (cracks.cc:2207-2216) in lattice cell order
+                                      // ci + (NX-1) (cj + (NY-1) ck); nullptr: the scalars of pfm_params
   };
 
   // host copy of the lattice tables of a uniform box (kept for pfm_pattern_bind)
@@ -108,9 +112,11 @@ namespace pfm
                       const void *d_scal);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal);
+  // color_ptr[n_classes + 1]: ranges of DevView::color_cells, one launch per class; the LAST class holds the cells with
+  // hanging vertices (their rows are distributed to the parents, which other vertices of the same cell may be: atomics)
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
-                              hipStream_t s);
+                              hipStream_t s, const std::vector<long long> &color_ptr);
 } // namespace pfm
 
 struct pfm_ctx
@@ -129,6 +135,7 @@ struct pfm_ctx
   // host copies needed for pattern queries
   std::vector<long long> h_nadj_ptr;
   std::vector<int32_t> h_nadj;
+  std::vector<long long> color_ptr; // colour classes of the general cell kernel (DevView::color_cells)
   // owned device allocations
   std::vector<void *> allocs;
   int64_t device_bytes = 0;

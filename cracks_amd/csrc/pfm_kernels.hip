@@ -9,7 +9,10 @@
 // (dim+1) x dpc row block of the element matrix that belongs to vertex a
 // (cracks.cc:2308-2389, rows j = (a,*), all trial dofs i) and the (dim+1) residual
 // entries (cracks.cc:2393-2432), then scatters through the constraints
-// (cracks.cc:2439-2464) with hardware FP64 atomics.  A 256-thread workgroup covers
+// (cracks.cc:2439-2464).  Cells are processed in colour classes (no two cells of a class share a node, one launch per
+// class): the rows of a vertex are then private to its lane and are updated with plain batched read-modify-writes;
+// only the class of the cells with hanging vertices adds with hardware FP64 atomics (device-scope atomics run at
+// ~3e10 /s on MI355X and were 90 % of the kernel time when every entry used them).  A 256-thread workgroup covers
 // 256/2^dim cells; their nodal inputs are staged once in LDS (SoA over the cell index,
 // so the 2^dim lanes of a cell read one broadcast address and neighbouring cells hit
 // consecutive banks).
@@ -151,17 +154,49 @@ namespace pfm
       return (int)(k - lo);
     }
 
-    __device__ __forceinline__ void atomic_add(double *p, double x)
+    // rows of a colour class belong to one cell each: plain read-modify-write; the class of the cells with hanging
+    // vertices adds with global_atomic_add_f64
+    template <bool ATOMIC>
+    __device__ __forceinline__ void add_to(double *p, double x)
     {
-      unsafeAtomicAdd(p, x); // global_atomic_add_f64
+      if constexpr (ATOMIC)
+        unsafeAtomicAdd(p, x);
+      else
+        *p += x;
+    }
+
+    // value of lane (quad base + b) in all four lanes of a quad (DPP quad_perm: no LDS traffic); b is a constant after
+    // unrolling
+    __device__ __forceinline__ double quad_bcast(double x, int b)
+    {
+      int lo = __double2loint(x), hi = __double2hiint(x);
+      switch (b)
+        {
+          case 0:
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x00, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x00, 0xf, 0xf, true);
+            break;
+          case 1:
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0x55, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0x55, 0xf, 0xf, true);
+            break;
+          case 2:
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0xaa, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0xaa, 0xf, 0xf, true);
+            break;
+          default:
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0xff, 0xf, 0xf, true);
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0xff, 0xf, 0xf, true);
+            break;
+        }
+      return __hiloint2double(hi, lo);
     }
 
     // ------------------------------------------------------------ the cell kernel
-    template <int dim, bool FULL, bool SPLIT>
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC>
     __global__ __launch_bounds__(256) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
-                                                              double *__restrict__ res_pde,
-                                                              double *__restrict__ res_tot,
-                                                              int residual_only)
+                                                              double *res_pde, double *res_tot,
+                                                              int residual_only, long long class_begin, long long class_size)
     {
       constexpr int nv = 1 << dim, nc = dim + 1, nq = (dim == 2 ? 9 : 27), dpc = nv * nc;
       constexpr int CPB = 256 / nv; // cells per workgroup
@@ -170,9 +205,11 @@ namespace pfm
       __shared__ double s_p[3][nv][CPB]; // phi, phi_old, phi_oldold
 
       const int tid = threadIdx.x;
-      const int a = tid % nv, cl = tid / nv;
-      const long long cell = (long long)blockIdx.x * CPB + cl;
-      const bool active = cell < v.n_cells;
+      const int a = tid % nv, cl0 = tid / nv;
+      const int cl = cl0;
+      const long long at = (long long)blockIdx.x * CPB + cl;
+      const bool active = at < class_size;
+      const long long cell = active ? v.color_cells[class_begin + at] : 0;
       int A = 0;
       if (active)
         {
@@ -250,8 +287,11 @@ namespace pfm
         }
       bool ortho_ok = true;
 
+#pragma unroll 1
       for (int q = 0; q < nq; ++q)
         {
+          int cl = cl0;
+          asm volatile("" : "+v"(cl)); // the cell's nodal data are re-read from LDS per q-point, not pinned in registers
           // ---- fe_values.reinit at q: J, J^-1, JxW (MappingQ1)
           double J[dim][dim];
 #pragma unroll
@@ -399,6 +439,37 @@ namespace pfm
               spE += sp[i][j] * E[i][j];
 
           // ---- Jacobian rows of vertex a, cracks.cc:2308-2389
+          // Stress split (2-D): the linearised split of trial dof (b, d) is the expensive part of a q-point (divisions,
+          // cracks.cc:1976-2109) and does not depend on the test vertex: the lane of vertex a evaluates it for b = a only
+          // and the four lanes of the cell exchange the results (a quad of the wave), instead of every lane evaluating
+          // all eight.
+          double mine[SPLIT && FULL ? dim : 1][9];
+          if constexpr (FULL && SPLIT)
+            {
+#pragma unroll
+              for (int d = 0; d < dim; ++d)
+                {
+                  double EL[dim][dim], spL[dim][dim], smL[dim][dim];
+#pragma unroll
+                  for (int i = 0; i < dim; ++i)
+#pragma unroll
+                    for (int j = 0; j < dim; ++j)
+                      EL[i][j] = 0.5 * ((i == d ? gNa[j] : 0.0) + (j == d ? gNa[i] : 0.0));
+                  ortho_ok &= split_stress_lin(E, trE, EL, gNa[d], lam, mu, spL, smL);
+                  double spLE = 0.0, spEL = 0.0;
+#pragma unroll
+                  for (int i = 0; i < dim; ++i)
+#pragma unroll
+                    for (int j = 0; j < dim; ++j)
+                      {
+                        spLE += spL[i][j] * E[i][j];
+                        spEL += sp[i][j] * EL[i][j];
+                        mine[d][i * dim + j] = spL[i][j];
+                        mine[d][4 + i * dim + j] = smL[i][j];
+                      }
+                  mine[d][8] = spLE + spEL;
+                }
+            }
           if constexpr (FULL)
             {
 #pragma unroll
@@ -418,9 +489,18 @@ namespace pfm
                           EL[i][j] = 0.5 * ((i == d ? gN[b][j] : 0.0) + (j == d ? gN[b][i] : 0.0));
                       const double trEL = gN[b][d]; // == divergence_u_LinU
                       double spL[dim][dim], smL[dim][dim];
+                      double sum_split = 0.0; // spL:E + sp:EL as evaluated by the lane of vertex b
                       if constexpr (SPLIT)
                         {
-                          ortho_ok &= split_stress_lin(E, trE, EL, trEL, lam, mu, spL, smL);
+#pragma unroll
+                          for (int i = 0; i < dim; ++i)
+#pragma unroll
+                            for (int j = 0; j < dim; ++j)
+                              {
+                                spL[i][j] = quad_bcast(mine[d][i * dim + j], b);
+                                smL[i][j] = quad_bcast(mine[d][4 + i * dim + j], b);
+                              }
+                          sum_split = quad_bcast(mine[d][8], b);
                         }
                       else
                         {
@@ -448,15 +528,19 @@ namespace pfm
                         }
                       // row (a, phi)
                       double spLE = 0.0, spEL = 0.0;
+                      if constexpr (!SPLIT)
+                        {
 #pragma unroll
-                      for (int i = 0; i < dim; ++i)
+                          for (int i = 0; i < dim; ++i)
 #pragma unroll
-                        for (int j = 0; j < dim; ++j)
-                          {
-                            spLE += spL[i][j] * E[i][j];
-                            spEL += sp[i][j] * EL[i][j];
-                          }
-                      Kpu[b][d] += ((1 - kappa) * (spLE + spEL) * pf * Na - 2.0 * aB1 * p * (pf * trEL) * Na) * JxW;
+                            for (int j = 0; j < dim; ++j)
+                              {
+                                spLE += spL[i][j] * E[i][j];
+                                spEL += sp[i][j] * EL[i][j];
+                              }
+                        }
+                      const double lin = SPLIT ? sum_split : spLE + spEL;
+                      Kpu[b][d] += ((1 - kappa) * lin * pf * Na - 2.0 * aB1 * p * (pf * trEL) * Na) * JxW;
                     }
                   // trial dof i = (b, phi): rows (a, c<dim) get exactly 0 (cracks.cc:2333-2337)
                   {
@@ -502,6 +586,121 @@ namespace pfm
         atomicMax(v.status, (int)PFM_ERR_NOT_ORTHOGONAL);
 
       // =============================== scatter through the constraints (cracks.cc:2439-2464)
+      if constexpr (!ATOMIC)
+        {
+          // Colour class without hanging vertices: the rows of node A are touched by this thread only during this
+          // launch.  Every batch of read-modify-writes loads all its old values before the first store (the adds of a
+          // batch hit distinct entries; one HBM/L2 round trip per batch instead of one per entry).
+          const bool owned = A < v.n_owned; // rows of ghost nodes belong to another rank
+          const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
+          const unsigned fA = v.node_flags[A];
+          if (owned)
+            {
+            double *pr[nc], *pt[nc], o_r[nc], o_t[nc];
+#pragma unroll
+            for (int c = 0; c < nc; ++c)
+              {
+                const long long di = dof_index<dim>(v, A, c);
+                pr[c] = res_pde + di;
+                pt[c] = res_tot + di;
+                o_r[c] = *pr[c];
+                if (residual_only)
+                  o_t[c] = *pt[c];
+              }
+#pragma unroll
+            for (int c = 0; c < nc; ++c)
+              {
+                const bool con = (fA >> c) & 1u;
+                if (!con)
+                  *pr[c] = o_r[c] + R[c];
+                if (residual_only && (!con || !total_via_update))
+                  *pt[c] = o_t[c] + R[c];
+              }
+          }
+          if constexpr (FULL)
+            {
+              const uint8_t *cs = v.cslot + (long long)cell * nv * nv;
+              const long long off = owned ? v.nadj_ptr[A] : 0, deg = owned ? v.nadj_ptr[A + 1] - off : 0;
+              const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
+              // entry (row comp c, slot s, col comp d) of node A's rows, see val_ptr
+              auto entry = [&](int c, int s_, int d) __attribute__((always_inline)) -> double * {
+                if (il)
+                  return vals.b[0] + (nc * nc * off + (long long)c * nc * deg + (long long)s_ * nc + d);
+                if (c < dim)
+                  return d < dim ? vals.b[0] + (dim * dim * off + (long long)c * dim * deg + (long long)s_ * dim + d)
+                                 : vals.b[1] + (dim * off + (long long)c * deg + s_);
+                return d < dim ? vals.b[2] + (dim * off + (long long)s_ * dim + d) : vals.b[3] + (off + s_);
+              };
+              double diag[nc];
+#pragma unroll
+              for (int b = 0; b < nv; ++b)
+                {
+                  const int B = v.conn[(long long)b * v.n_cells + cell];
+                  const unsigned fQ = v.node_flags[B];
+                  const int slot = (int)cs[a * nv + b];
+                  if (b == a)
+                    {
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        diag[c] = fabs(Kuu[b][c][c]);
+                      diag[dim] = fabs(Kpp[b]);
+                    }
+                  if (!owned)
+                    continue;
+                  constexpr int NE = dim * dim + dim + 1;
+                  double *pe[NE], oe[NE], ke[NE];
+                  bool on[NE];
+#pragma unroll
+                  for (int c = 0; c < dim; ++c)
+#pragma unroll
+                    for (int d = 0; d < dim; ++d)
+                      {
+                        pe[c * dim + d] = entry(c, slot, d);
+                        ke[c * dim + d] = Kuu[b][c][d];
+                        on[c * dim + d] = !((fA >> c) & 1u) && !((fQ >> d) & 1u);
+                      }
+#pragma unroll
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      pe[dim * dim + d] = entry(dim, slot, d);
+                      ke[dim * dim + d] = Kpu[b][d];
+                      on[dim * dim + d] = !((fA >> dim) & 1u) && !((fQ >> d) & 1u);
+                    }
+                  pe[NE - 1] = entry(dim, slot, dim);
+                  ke[NE - 1] = Kpp[b];
+                  on[NE - 1] = !((fA >> dim) & 1u) && !((fQ >> dim) & 1u);
+#pragma unroll
+                  for (int e = 0; e < NE; ++e)
+                    oe[e] = *pe[e];
+#pragma unroll
+                  for (int e = 0; e < NE; ++e)
+                    if (on[e])
+                      *pe[e] = oe[e] + ke[e];
+                }
+              // diagonal of constrained rows (deal.II distribute_local_to_global): |K_ii| or, when that is zero, the
+              // mean |diagonal| of the element matrix
+              double dsum = 0.0;
+#pragma unroll
+              for (int c = 0; c < nc; ++c)
+                dsum += diag[c];
+#pragma unroll
+              for (int m = 1; m < nv; m <<= 1)
+                dsum += __shfl_xor(dsum, m, nv);
+              const double avg = dsum / (double)dpc;
+              if (fA && owned)
+                {
+                  const int slot = (int)cs[a * nv + a];
+#pragma unroll
+                  for (int c = 0; c < nc; ++c)
+                    if ((fA >> c) & 1u)
+                      {
+                        double *pd = entry(c, slot, c);
+                        *pd += diag[c] != 0.0 ? diag[c] : avg;
+                      }
+                }
+            }
+          return;
+        }
       const uint8_t *cs = v.cslot + (long long)cell * nv * nv;
       const int kA = v.hn_index ? v.hn_index[A] : -1;
       const long long rb = kA < 0 ? 0 : v.hn_ptr[kA];
@@ -522,9 +721,9 @@ namespace pfm
               const long long di = dof_index<dim>(v, P, c);
               const bool con = (fP >> c) & 1u;
               if (!con)
-                atomic_add(res_pde + di, wP * R[c]);
+                add_to<ATOMIC>(res_pde + di, wP * R[c]);
               if (residual_only && (!con || !total_via_update))
-                atomic_add(res_tot + di, wP * R[c]);
+                add_to<ATOMIC>(res_tot + di, wP * R[c]);
             }
         }
 
@@ -568,16 +767,16 @@ namespace pfm
 #pragma unroll
                           for (int d = 0; d < dim; ++d)
                             if (!((fQ >> d) & 1u))
-                              atomic_add(val_ptr<dim>(v, vals, P, c, slot, d), w * Kuu[b][c][d]);
+                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, c, slot, d), w * Kuu[b][c][d]);
                         }
                       if (!((fP >> dim) & 1u))
                         {
 #pragma unroll
                           for (int d = 0; d < dim; ++d)
                             if (!((fQ >> d) & 1u))
-                              atomic_add(val_ptr<dim>(v, vals, P, dim, slot, d), w * Kpu[b][d]);
+                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, d), w * Kpu[b][d]);
                           if (!((fQ >> dim) & 1u))
-                            atomic_add(val_ptr<dim>(v, vals, P, dim, slot, dim), w * Kpp[b]);
+                            add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, dim), w * Kpp[b]);
                         }
                     }
                 }
@@ -598,7 +797,7 @@ namespace pfm
 #pragma unroll
               for (int c = 0; c < nc; ++c)
                 if (kA >= 0 || ((fA >> c) & 1u))
-                  atomic_add(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
+                  add_to<ATOMIC>(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
             }
         }
     }
@@ -842,7 +1041,8 @@ namespace pfm
   }
 
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
-                              double *const *d_values, double *res_pde, double *res_tot, hipStream_t s)
+                              double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
+                              const std::vector<long long> &color_ptr)
   {
     int rc = ensure_tables();
     if (rc)
@@ -856,38 +1056,56 @@ namespace pfm
     const bool split = (p.decompose_stress_matrix > 0 && p.timestep_number > 0);
     // The reference gates the split on decompose_stress_matrix only (cracks.cc:2294); a
     // non-zero decompose_stress_rhs without it multiplies a zero stress_term_minus.
+    if (v.dim == 3 && split)
+      return PFM_ERR_UNSUPPORTED;
     const int nv = 1 << v.dim, cpb = 256 / nv;
-    const unsigned nb = (unsigned)((v.n_cells + cpb - 1) / cpb);
-    const dim3 grid(nb), block(256);
-#define PFM_LAUNCH(DIM, FULLV, SPLITV) \
-  hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV>), grid, block, 0, s, v, p, vals, res_pde, res_tot, residual_only)
-    if (v.dim == 2)
+    const int n_classes = (int)color_ptr.size() - 1;
+    // one launch per colour class, in class order (stream order = the summation order of a row: reproducible);
+    // the last class (cells with hanging vertices) adds atomically
+    for (int k = 0; k < n_classes; ++k)
       {
-        if (residual_only)
+        const long long c0 = color_ptr[k], cn = color_ptr[k + 1] - c0;
+        if (cn == 0)
+          continue;
+        const bool atomic = k == n_classes - 1;
+        const dim3 grid((unsigned)((cn + cpb - 1) / cpb)), block(256);
+#define PFM_LAUNCH(DIM, FULLV, SPLITV)                                                                                       \
+  do                                                                                                                         \
+    {                                                                                                                        \
+      if (atomic)                                                                                                            \
+        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,  \
+                           residual_only, c0, cn);                                                                           \
+      else                                                                                                                   \
+        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
+                           residual_only, c0, cn);                                                                           \
+    }                                                                                                                        \
+  while (0)
+        if (v.dim == 2)
           {
-            if (split)
-              PFM_LAUNCH(2, false, true);
+            if (residual_only)
+              {
+                if (split)
+                  PFM_LAUNCH(2, false, true);
+                else
+                  PFM_LAUNCH(2, false, false);
+              }
             else
-              PFM_LAUNCH(2, false, false);
+              {
+                if (split)
+                  PFM_LAUNCH(2, true, true);
+                else
+                  PFM_LAUNCH(2, true, false);
+              }
           }
         else
           {
-            if (split)
-              PFM_LAUNCH(2, true, true);
+            if (residual_only)
+              PFM_LAUNCH(3, false, false);
             else
-              PFM_LAUNCH(2, true, false);
+              PFM_LAUNCH(3, true, false);
           }
-      }
-    else
-      {
-        if (split)
-          return PFM_ERR_UNSUPPORTED;
-        if (residual_only)
-          PFM_LAUNCH(3, false, false);
-        else
-          PFM_LAUNCH(3, true, false);
-      }
 #undef PFM_LAUNCH
+      }
     return check_launch();
   }
 } // namespace pfm

@@ -38,7 +38,8 @@ def oracle(c, residual_only):
     rp = ci = None
     if not residual_only:
         rp, ci = M.dof_sparsity(c.mesh, c.layout)
-    r = O.assemble(c.mesh, c.layout, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, residual_only, rp, ci)
+    r = O.assemble(c.mesh, c.layout, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, residual_only, rp, ci,
+                   c.cell_lambda, c.cell_mu)
     assert r.err == 0
     return r, rp, ci
 
@@ -348,3 +349,54 @@ def test_cart2d_split_runs_stay_on_the_general_family():
     A = blocks_to_global(ctx, c.layout, values)
     A.sort_indices()
     assert linf_scaled(A.data, A_ref.data) < 1e-11 and linf_scaled(res_pde, r.residual_pde) < 1e-11
+
+
+# ---- heterogeneous material on the row-owner kernels (cracks.cc:2207-2216): per-cell Lame coefficients, cells handed
+# over in a shuffled order (the kernels address them by lattice position)
+def heterogeneous(c, seed=5, free_ratio=False):
+    rng = np.random.default_rng(seed)
+    c.mesh.cells = np.ascontiguousarray(c.mesh.cells[rng.permutation(c.mesh.n_cells)])
+    E = 1.0 + rng.uniform(1.0, 10.0, c.mesh.n_cells)  # func_emodulus + 1.0 (cracks.cc:2209-2210)
+    c.cell_mu = E / (2.0 * (1 + 0.2))
+    c.cell_lambda = (2 * 0.2 * c.cell_mu) / (1.0 - 2 * 0.2)
+    if free_ratio:  # the ABI takes any pair per cell
+        c.cell_lambda = rng.uniform(0.05, 4.0, c.mesh.n_cells)
+    return c
+
+
+HET_BOXES = [(3, (9, 5, 11), (-1.0, 0.0, 2.0), (2.0, 1.5, 2.7)), (3, (16, 9, 30), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0)),
+             (2, (12, 7), (-3.0, 1.0), (1.0, 2.0)), (2, (33, 18), -10.0, 10.0)]
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("dim,n,lo,hi", HET_BOXES)
+def test_cart_heterogeneous_material_full(dim, n, lo, hi, blocked):
+    c = heterogeneous(box_case(dim, n, lo, hi, blocked), free_ratio=(n[0] == 9))
+    assert make_context(c).kernel_path == 1, "a box with per-cell Lame coefficients stays on the cartesian family"
+    _full(c, path=1)
+
+
+@pytest.mark.parametrize("dim,n,lo,hi", HET_BOXES)
+@pytest.mark.parametrize("monolithic", [False, True])
+def test_cart_heterogeneous_material_residual(dim, n, lo, hi, monolithic):
+    c = heterogeneous(box_case(dim, n, lo, hi, True, monolithic=monolithic), seed=11)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+    _, res_pde, res_tot = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(res_pde, r.residual_pde) < TOL
+    assert linf_scaled(res_tot, r.residual_total) < TOL
+
+
+def test_cart_heterogeneous_material_mean_diagonal_and_constraints():
+    c = box_case(3, (6, 5, 4), -10.0, 10.0, True, monolithic=True)
+    c.params.constant_k = 0.0
+    node, comp = c.layout.node_comp_of_dof()
+    is_phi = comp == 3
+    dead = c.mesh.coords[node[is_phi]][:, 0] < 0.0
+    o = c.old.copy()
+    o[np.nonzero(is_phi)[0][dead]] = 0.0
+    c.old, c.oldold = o, o.copy()
+    phi_dofs = np.nonzero(is_phi)[0]
+    c.cu = M.update_constraints(c.mesh, c.layout, M.sneddon_dirichlet_dofs(c.mesh, c.layout), phi_dofs[::5])
+    _full(heterogeneous(c, free_ratio=True), path=1)
