@@ -23,6 +23,7 @@
 #include <fstream>
 #include <new>
 #include <thread>
+#include <chrono>
 
 using namespace pfm;
 
@@ -443,10 +444,29 @@ int64_t pfm_ctx::block_nnz(int b) const
     }
 }
 
+namespace
+{
+  // PFM_CTX_TIMING=1: wall time of the phases of pfm_ctx_create on stderr (tuning only)
+  struct PhaseClock
+  {
+    const bool on = getenv("PFM_CTX_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+      if (!on)
+        return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[pfm_ctx_create] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+      t0 = t1;
+    }
+  };
+} // namespace
+
 extern "C"
 {
   int pfm_ctx_create(pfm_ctx **out, const pfm_mesh_desc *m, int device)
   {
+    PhaseClock clk;
     if (!out || !m || (m->dim != 2 && m->dim != 3) ||
         (m->layout != PFM_LAYOUT_INTERLEAVED && m->layout != PFM_LAYOUT_BLOCKED) ||
         m->n_nodes <= 0 || m->n_owned_nodes < 0 || m->n_owned_nodes > m->n_nodes || m->n_cells < 0 ||
@@ -476,6 +496,7 @@ extern "C"
       if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
         return fail(c, PFM_ERR_BAD_ARG, "cell_nodes out of range");
 
+    clk.mark("argument checks");
     Lattice &lattice = c->lat;
     bool lattice_ok = false;
     try
@@ -499,6 +520,7 @@ extern "C"
         // ---- node graph over the constraint-resolved cells, rows = owned nodes, columns ascending by local node id
         // (ghost nodes, numbered after the owned ones, come last: the order of a host CSR sorted by local column id).
         lattice_ok = detect_lattice(m, lattice);
+        clk.mark("detect_lattice");
         if (lattice_ok)
           lattice_graph(c, dim, NO, lattice);
         else
@@ -552,6 +574,7 @@ extern "C"
               }
           }
         std::vector<int32_t> &nadj = c->h_nadj;
+        clk.mark("node graph");
 
         // ---- device mirrors (SoA)
         {
@@ -570,6 +593,7 @@ extern "C"
               xs[(size_t)d * N + n] = m->coords[(size_t)n * dim + d];
           v.coords = dev_upload(c, xs.data(), xs.size());
         }
+        clk.mark("conn + coords upload");
         {
           // Colour classes of the general cell kernel: cells of one class share no node and are assembled by one
           // launch with plain read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter
@@ -631,6 +655,7 @@ extern "C"
           }
           v.color_cells = dev_upload(c, order.data(), order.size());
         }
+        clk.mark("colour classes");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
           {
@@ -641,6 +666,7 @@ extern "C"
         v.nadj = dev_upload(c, nadj.data(), nadj.size());
         // slot table of the general kernel family: position of vertex b's node in the row of vertex a's node,
         // searched on the device (64 row searches per hex: 8 s on one host core at 1e7 cells)
+        clk.mark("graph upload");
         v.cslot = dev_alloc<uint8_t>(c, (size_t)NC * nv * nv);
         if (launch_build_cslot(v, nullptr) != PFM_OK)
           throw HipFail{hipGetLastError(), "cslot kernel"};
@@ -689,12 +715,15 @@ extern "C"
       }
     try
       {
+        clk.mark("cslot launch, state buffers");
         c->cart_ok = lattice_ok && build_cart(c, m, lattice);
+        clk.mark("build_cart");
         if (!c->cart_ok)
           c->lat = Lattice{}; // the host lattice tables are only kept for pfm_pattern_bind on the cartesian path
         if (hipDeviceSynchronize() != hipSuccess)
           throw HipFail{hipGetLastError(), "context build"};
         c->d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
+        clk.mark("device synchronize");
       }
     catch (const HipFail &f)
       {

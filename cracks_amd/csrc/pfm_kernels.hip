@@ -470,7 +470,50 @@ namespace pfm
                   mine[d][8] = spLE + spEL;
                 }
             }
-          if constexpr (FULL)
+          if constexpr (FULL && !SPLIT)
+            {
+              // Unsplit law sigma+ = lambda tr(E) I + 2 mu E (sigma- = 0): the linearised stress of trial dof (b, d)
+              // contracted with the test gradient is  lambda gN_b[d] gN_a[c] + mu (gN_b[c] gN_a[d] + delta_cd gN_b.gN_a),
+              // and sigma+_LinU : E = sigma+ : E_LinU = sum_k sigma+[d][k] gN_b[k]  (cracks.cc:2340-2349, 2357-2376 with
+              // the tensors written out: 47 instead of ~190 operations per trial vertex and q-point in 3-D)
+              const double gw = g * JxW;
+              double LA[dim], MA[dim];
+#pragma unroll
+              for (int c = 0; c < dim; ++c)
+                {
+                  LA[c] = lam * gw * gNa[c];
+                  MA[c] = mu * gw * gNa[c];
+                }
+              const double mgw = mu * gw;
+              const double cpu = 2.0 * (1 - kappa) * pf * Na * JxW, cdiv = 2.0 * aB1 * p * pf * Na * JxW;
+              const double cpp = ((1 - kappa) * spE + Gc / eps) * Na * JxW, cgg = Gc * eps * JxW, cdu = 2.0 * aB1 * p * divu * Na * JxW;
+              const bool pen_on = !((pf - pfo) < 0.0); // shadowed variable, cracks.cc:2311-2315
+              const double cpen = penal_fac * Na * JxW;
+#pragma unroll
+              for (int b = 0; b < nv; ++b)
+                {
+                  const double Nb = refN<dim>(q, b);
+                  double t = 0.0;
+#pragma unroll
+                  for (int k = 0; k < dim; ++k)
+                    t += gN[b][k] * gNa[k];
+#pragma unroll
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      double sv = 0.0;
+#pragma unroll
+                      for (int k = 0; k < dim; ++k)
+                        sv += sp[d][k] * gN[b][k];
+                      Kpu[b][d] += cpu * sv - cdiv * gN[b][d];
+#pragma unroll
+                      for (int c = 0; c < dim; ++c)
+                        Kuu[b][c][d] += LA[c] * gN[b][d] + MA[d] * gN[b][c] + (c == d ? mgw * t : 0.0);
+                    }
+                  Kpp[b] += cpen * (pen_on ? Nb : 0.0);
+                  Kpp[b] += (cpp - cdu) * Nb + cgg * t;
+                }
+            }
+          if constexpr (FULL && SPLIT)
             {
 #pragma unroll
               for (int b = 0; b < nv; ++b)
