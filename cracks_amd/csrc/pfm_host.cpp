@@ -22,6 +22,7 @@
 #include <cstring>
 #include <fstream>
 #include <new>
+#include <mutex>
 #include <thread>
 #include <chrono>
 
@@ -48,18 +49,6 @@ namespace
     return static_cast<T *>(p);
   }
 
-  template <class T>
-  T *dev_upload(pfm_ctx *c, const T *h, size_t n)
-  {
-    T *d = dev_alloc<T>(c, n);
-    if (n)
-      {
-        hipError_t e = hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
-        if (e != hipSuccess)
-          throw HipFail{e, "hipMemcpy H2D"};
-      }
-    return d;
-  }
 
   int fail(pfm_ctx *c, int code, const std::string &msg)
   {
@@ -109,6 +98,77 @@ namespace
       th.emplace_back([&fn, n, nt, t] { fn(n * t / nt, n * (t + 1) / nt); });
     for (auto &x : th)
       x.join();
+  }
+
+  // Host -> device copy of caller-owned (pageable) memory.  hipMemcpy from pageable memory ran at ~3.6 GB/s on the
+  // test box; large tables go through two pinned staging buffers filled by the host threads (parallel memcpy) while
+  // the previous chunk is on the bus.
+  hipError_t h2d(void *d, const void *h, size_t bytes)
+  {
+    constexpr size_t CHUNK = 32u << 20;
+    if (bytes < (4u << 20))
+      return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+    static thread_local struct Stage
+    {
+      void *buf[2] = {nullptr, nullptr};
+      hipEvent_t ev[2] = {nullptr, nullptr};
+      bool ok = false, tried = false;
+      ~Stage()
+      {
+        for (int i = 0; i < 2; ++i)
+          {
+            if (buf[i])
+              (void)hipHostFree(buf[i]);
+            if (ev[i])
+              (void)hipEventDestroy(ev[i]);
+          }
+      }
+    } st;
+    if (!st.tried)
+      {
+        st.tried = true;
+        st.ok = hipHostMalloc(&st.buf[0], CHUNK, hipHostMallocDefault) == hipSuccess &&
+                hipHostMalloc(&st.buf[1], CHUNK, hipHostMallocDefault) == hipSuccess &&
+                hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming) == hipSuccess;
+      }
+    if (!st.ok)
+      return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+    bool used[2] = {false, false};
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += CHUNK, k ^= 1)
+      {
+        const size_t nb = std::min(CHUNK, bytes - off);
+        if (used[k])
+          {
+            const hipError_t e = hipEventSynchronize(st.ev[k]);
+            if (e != hipSuccess)
+              return e;
+          }
+        const char *src = static_cast<const char *>(h) + off;
+        char *dst = static_cast<char *>(st.buf[k]);
+        parallel_for((int64_t)nb, [&](int64_t b, int64_t e) { memcpy(dst + b, src + b, (size_t)(e - b)); });
+        hipError_t e = hipMemcpyAsync(static_cast<char *>(d) + off, st.buf[k], nb, hipMemcpyHostToDevice, nullptr);
+        if (e == hipSuccess)
+          e = hipEventRecord(st.ev[k], nullptr);
+        if (e != hipSuccess)
+          return e;
+        used[k] = true;
+      }
+    return hipStreamSynchronize(nullptr);
+  }
+
+  template <class T>
+  T *dev_upload(pfm_ctx *c, const T *h, size_t n)
+  {
+    T *d = dev_alloc<T>(c, n);
+    if (n)
+      {
+        hipError_t e = h2d(d, h, n * sizeof(T));
+        if (e != hipSuccess)
+          throw HipFail{e, "hipMemcpy H2D"};
+      }
+    return d;
   }
   // Lattice of a uniform Cartesian box: node n <-> lattice index box_of_local[n] (x fastest), cells in deal.II
   // vertex order, every lattice cell present exactly once.  false whenever any check fails.
@@ -217,7 +277,8 @@ namespace
   // is local, detect_lattice).  Also fills the host copies of the cartesian row tables (row_order_tables).
   void lattice_graph(pfm_ctx *c, int dim, int32_t NO, const Lattice &L)
   {
-    const int NX = L.NX, NY = L.NY, NZ = L.NZ, no = dim == 3 ? 27 : 9;
+    const int NX = L.NX, NY = L.NY, NZ = L.NZ;
+    (void)dim;
     std::vector<long long> &ptr = c->h_nadj_ptr;
     ptr.assign((size_t)NO + 1, 0);
     parallel_for(NO, [&](int64_t nb, int64_t ne) {
@@ -231,24 +292,65 @@ namespace
     });
     for (int32_t n = 0; n < NO; ++n)
       ptr[n + 1] += ptr[n];
+    c->h_nadj.clear();
+    c->graph_lazy = true; // rows are materialised by ensure_host_graph
+  }
+
+  // neighbours of owned lattice node n in lattice-offset order; returns their number, mask bit o = offset o exists
+  int lattice_row(const Lattice &L, int dim, int64_t n, int32_t (&q)[27], uint32_t &mask)
+  {
+    const int NX = L.NX, NY = L.NY, NZ = L.NZ, no = dim == 3 ? 27 : 9;
+    const int64_t b = L.box_of_local[n];
+    const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+    int deg = 0;
+    mask = 0;
+    for (int o = 0; o < no; ++o)
+      {
+        const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+        if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+          continue;
+        mask |= 1u << o;
+        q[deg++] = L.local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
+      }
+    return deg;
+  }
+
+  // the canonical rows (ascending local node id) of a lattice context whose host graph has not been materialised
+  void ensure_host_graph(pfm_ctx *c)
+  {
+    if (!c->graph_lazy)
+      return;
+    const int32_t NO = c->v.n_owned;
+    const int dim = c->v.dim;
+    const std::vector<long long> &ptr = c->h_nadj_ptr;
     c->h_nadj.resize((size_t)ptr[NO]);
     parallel_for(NO, [&](int64_t nb, int64_t ne) {
+      int32_t q[27];
+      uint32_t mask;
       for (int64_t n = nb; n < ne; ++n)
         {
-          const int64_t b = L.box_of_local[n];
-          const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
+          const int deg = lattice_row(c->lat, dim, n, q, mask);
           int32_t *row = c->h_nadj.data() + ptr[n];
-          int deg = 0;
-          for (int o = 0; o < no; ++o)
-            {
-              const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
-              if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
-                continue;
-              row[deg++] = L.local_of_box[ii + (int64_t)NX * (jj + (int64_t)NY * kk)];
-            }
-          std::sort(row, row + deg);
+          std::copy(q, q + deg, row);
+          if (!std::is_sorted(row, row + deg))
+            std::sort(row, row + deg);
         }
     });
+    c->graph_lazy = false;
+  }
+
+  // device copy of the node graph + slot table of the general cell kernel (lattice contexts: on first use)
+  void ensure_general_tables(pfm_ctx *c)
+  {
+    if (c->general_ready)
+      return;
+    ensure_host_graph(c);
+    DevView &v = c->v;
+    v.nadj = dev_upload(c, c->h_nadj.data(), c->h_nadj.size());
+    v.cslot = dev_alloc<uint8_t>(c, (size_t)v.n_cells * (size_t)(1 << v.dim) * (size_t)(1 << v.dim));
+    if (launch_build_cslot(v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
+      throw HipFail{hipGetLastError(), "cslot kernel"};
+    c->general_ready = true;
   }
 
   // Cartesian row tables from the CURRENT order of the node-graph rows (pfm_ctx_create: ascending local id;
@@ -268,8 +370,18 @@ namespace
         {
           const int64_t b = L.box_of_local[n];
           const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
-          const int32_t *row = c->h_nadj.data() + c->h_nadj_ptr[n];
           const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
+          int32_t canon[27];
+          const int32_t *row = canon;
+          if (c->graph_lazy) // canonical order = ascending local id, not materialised
+            {
+              uint32_t m0;
+              const int dg = lattice_row(L, dim, n, canon, m0);
+              if (!std::is_sorted(canon, canon + dg))
+                std::sort(canon, canon + dg);
+            }
+          else
+            row = c->h_nadj.data() + c->h_nadj_ptr[n];
           uint32_t mk = 0;
           int rank = 0;
           bool lattice_order = true;
@@ -305,8 +417,17 @@ namespace
             continue;
           const int64_t b = L.box_of_local[n];
           const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((int64_t)NX * NY));
-          const int32_t *row = c->h_nadj.data() + c->h_nadj_ptr[n];
           const int deg = (int)(c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n]);
+          int32_t canon[27];
+          const int32_t *row = canon;
+          if (c->graph_lazy)
+            {
+              uint32_t m0;
+              const int dg = lattice_row(L, dim, n, canon, m0);
+              std::sort(canon, canon + dg);
+            }
+          else
+            row = c->h_nadj.data() + c->h_nadj_ptr[n];
           int rank = 0;
           for (int o = 0; o < no; ++o)
             {
@@ -331,13 +452,13 @@ namespace
     CartView &cv = c->cv;
     if (!cv.nbr_mask)
       cv.nbr_mask = dev_alloc<uint32_t>(c, mask.size());
-    if (!mask.empty() && hipMemcpy(const_cast<uint32_t *>(cv.nbr_mask), mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+    if (!mask.empty() && h2d(const_cast<uint32_t *>(cv.nbr_mask), mask.data(), mask.size() * sizeof(uint32_t)) != hipSuccess)
       throw HipFail{hipGetLastError(), "hipMemcpy nbr_mask"};
     if (any_perm)
       {
         if (!c->d_row_perm)
           c->d_row_perm = dev_alloc<uint8_t>(c, perm.size());
-        if (hipMemcpy(c->d_row_perm, perm.data(), perm.size(), hipMemcpyHostToDevice) != hipSuccess)
+        if (h2d(c->d_row_perm, perm.data(), perm.size()) != hipSuccess)
           throw HipFail{hipGetLastError(), "hipMemcpy row_perm"};
       }
     cv.row_perm = any_perm ? c->d_row_perm : nullptr;
@@ -352,16 +473,28 @@ namespace
     const std::vector<int32_t> &box_of_local = L.box_of_local;
     // owned nodes must form a sub-box
     int o0[3] = {1 << 30, 1 << 30, 1 << 30}, o1[3] = {-1, -1, -1};
-    for (int32_t n = 0; n < NO; ++n)
-      {
-        const int64_t b = box_of_local[n];
-        const int idx[3] = {(int)(b % NX), (int)((b / NX) % NY), (int)(b / ((int64_t)NX * NY))};
+    {
+      std::mutex mx;
+      parallel_for(NO, [&](int64_t nb, int64_t ne) {
+        int l0[3] = {1 << 30, 1 << 30, 1 << 30}, l1[3] = {-1, -1, -1};
+        for (int64_t n = nb; n < ne; ++n)
+          {
+            const int64_t b = box_of_local[n];
+            const int idx[3] = {(int)(b % NX), (int)((b / NX) % NY), (int)(b / ((int64_t)NX * NY))};
+            for (int d = 0; d < 3; ++d)
+              {
+                l0[d] = std::min(l0[d], idx[d]);
+                l1[d] = std::max(l1[d], idx[d]);
+              }
+          }
+        std::lock_guard<std::mutex> lock(mx);
         for (int d = 0; d < 3; ++d)
           {
-            o0[d] = std::min(o0[d], idx[d]);
-            o1[d] = std::max(o1[d], idx[d]);
+            o0[d] = std::min(o0[d], l0[d]);
+            o1[d] = std::max(o1[d], l1[d]);
           }
-      }
+      });
+    }
     if (NO == 0)
       return false;
     if ((int64_t)(o1[0] - o0[0] + 1) * (o1[1] - o0[1] + 1) * (o1[2] - o0[2] + 1) != NO)
@@ -406,13 +539,17 @@ namespace
     cv.owned_lex = 1;
     {
       const int64_t OWX = o1[0] - o0[0] + 1, OWY = o1[1] - o0[1] + 1;
-      for (int32_t n = 0; n < NO && cv.owned_lex; ++n)
-        {
-          const int64_t b = box_of_local[n];
-          const int64_t i = b % NX, j = (b / NX) % NY, k = b / ((int64_t)NX * NY);
-          if ((i - o0[0]) + OWX * ((j - o0[1]) + OWY * (k - o0[2])) != n)
-            cv.owned_lex = 0;
-        }
+      std::atomic<bool> lex{true};
+      parallel_for(NO, [&](int64_t nb, int64_t ne) {
+        for (int64_t n = nb; n < ne && lex; ++n)
+          {
+            const int64_t b = box_of_local[n];
+            const int64_t i = b % NX, j = (b / NX) % NY, k = b / ((int64_t)NX * NY);
+            if ((i - o0[0]) + OWX * ((j - o0[1]) + OWY * (k - o0[2])) != n)
+              lex = false;
+          }
+      });
+      cv.owned_lex = lex ? 1 : 0;
     }
     return true;
   }
@@ -492,9 +629,19 @@ extern "C"
     v.n_cells = NC;
     c->n_blocks = (m->layout == PFM_LAYOUT_BLOCKED) ? 4 : 1;
 
-    for (int64_t i = 0; i < NC * nv; ++i)
-      if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
+    {
+      std::atomic<bool> in_range{true};
+      parallel_for(NC * nv, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i)
+          if (m->cell_nodes[i] < 0 || m->cell_nodes[i] >= N)
+            {
+              in_range = false;
+              return;
+            }
+      });
+      if (!in_range)
         return fail(c, PFM_ERR_BAD_ARG, "cell_nodes out of range");
+    }
 
     clk.mark("argument checks");
     Lattice &lattice = c->lat;
@@ -578,20 +725,35 @@ extern "C"
 
         // ---- device mirrors (SoA)
         {
-          std::vector<int32_t> conn((size_t)NC * nv);
-          parallel_for(NC, [&](int64_t cb, int64_t ce) {
-            for (int64_t cell = cb; cell < ce; ++cell)
-              for (int a = 0; a < nv; ++a)
-                conn[(size_t)a * NC + cell] = m->cell_nodes[cell * nv + a];
-          });
-          v.conn = dev_upload(c, conn.data(), conn.size());
-        }
-        {
-          std::vector<double> xs((size_t)N * dim);
-          for (int32_t n = 0; n < N; ++n)
-            for (int d = 0; d < dim; ++d)
-              xs[(size_t)d * N + n] = m->coords[(size_t)n * dim + d];
-          v.coords = dev_upload(c, xs.data(), xs.size());
+          // host order (cell-major / node-major) -> SoA on the device: the raw tables are uploaded as they are and
+          // transposed by a kernel (a host transposition of 8e7 + 3e7 entries cost 0.25 s at 1e7 cells)
+          int32_t *raw = nullptr;
+          if (NC > 0 && hipMalloc((void **)&raw, sizeof(int32_t) * (size_t)NC * nv) != hipSuccess)
+            throw HipFail{hipGetLastError(), "hipMalloc"};
+          int32_t *conn = dev_alloc<int32_t>(c, (size_t)NC * nv);
+          clk.mark("  conn buffers");
+          hipError_t e2 = NC > 0 ? h2d(raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
+          clk.mark("  conn h2d");
+          const int rct = e2 == hipSuccess ? launch_aos_to_soa_i32(raw, conn, NC, nv, nullptr) : PFM_ERR_HIP;
+          double *rawx = nullptr;
+          if (hipMalloc((void **)&rawx, sizeof(double) * (size_t)N * dim) != hipSuccess)
+            {
+              (void)hipFree(raw);
+              throw HipFail{hipGetLastError(), "hipMalloc"};
+            }
+          double *xs = dev_alloc<double>(c, (size_t)N * dim);
+          clk.mark("  coords buffers");
+          e2 = h2d(rawx, m->coords, sizeof(double) * (size_t)N * dim);
+          clk.mark("  coords h2d");
+          const int rcx = e2 == hipSuccess ? launch_aos_to_soa_f64(rawx, xs, N, dim, nullptr) : PFM_ERR_HIP;
+          const hipError_t es = hipDeviceSynchronize();
+          clk.mark("  transposes");
+          (void)hipFree(raw);
+          (void)hipFree(rawx);
+          if (rct != PFM_OK || rcx != PFM_OK || es != hipSuccess)
+            throw HipFail{hipGetLastError(), "mesh table upload"};
+          v.conn = conn;
+          v.coords = xs;
         }
         clk.mark("conn + coords upload");
         {
@@ -663,13 +825,20 @@ extern "C"
             v.cell_mu = dev_upload(c, m->cell_mu, (size_t)NC);
           }
         v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
-        v.nadj = dev_upload(c, nadj.data(), nadj.size());
-        // slot table of the general kernel family: position of vertex b's node in the row of vertex a's node,
-        // searched on the device (64 row searches per hex: 8 s on one host core at 1e7 cells)
-        clk.mark("graph upload");
-        v.cslot = dev_alloc<uint8_t>(c, (size_t)NC * nv * nv);
-        if (launch_build_cslot(v, nullptr) != PFM_OK)
-          throw HipFail{hipGetLastError(), "cslot kernel"};
+        // node graph columns + slot table of the general kernel family (position of vertex b's node in the row of
+        // vertex a's node, searched on the device: 64 row searches per hex, 8 s on one host core at 1e7 cells); a
+        // lattice context builds them when the general family is first used
+        v.nadj = nullptr;
+        v.cslot = nullptr;
+        c->general_ready = !c->graph_lazy;
+        if (c->general_ready)
+          {
+            v.nadj = dev_upload(c, nadj.data(), nadj.size());
+            clk.mark("graph upload");
+            v.cslot = dev_alloc<uint8_t>(c, (size_t)NC * nv * nv);
+            if (launch_build_cslot(v, nullptr) != PFM_OK)
+              throw HipFail{hipGetLastError(), "cslot kernel"};
+          }
         v.hn_index = nullptr;
         v.hn_ptr = nullptr;
         v.hn_parents = nullptr;
@@ -719,7 +888,10 @@ extern "C"
         c->cart_ok = lattice_ok && build_cart(c, m, lattice);
         clk.mark("build_cart");
         if (!c->cart_ok)
-          c->lat = Lattice{}; // the host lattice tables are only kept for pfm_pattern_bind on the cartesian path
+          {
+            ensure_general_tables(c); // needs the lattice tables when the graph is still lazy
+            c->lat = Lattice{};       // the host lattice tables are only kept on the cartesian path
+          }
         if (hipDeviceSynchronize() != hipSuccess)
           throw HipFail{hipGetLastError(), "context build"};
         c->d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
@@ -841,6 +1013,14 @@ extern "C"
       }
     (void)coff;
     (void)phi_col;
+    try
+      {
+        ensure_host_graph(const_cast<pfm_ctx *>(c)); // a cache: the pattern itself does not change
+      }
+    catch (const std::bad_alloc &)
+      {
+        return PFM_ERR_NOMEM;
+      }
     int64_t pos = 0, row = 0;
     rowptr[0] = 0;
     for (int32_t n = 0; n < c->v.n_owned; ++n)
@@ -879,6 +1059,14 @@ extern "C"
     auto rp = [&](int64_t r) -> int64_t { return rp64 ? rp64[r] : (int64_t)rp32[r]; };
     if (rp(0) != 0 || rp(c->block_rows(block)) != c->block_nnz(block))
       return fail(c, PFM_ERR_BAD_ARG, "pfm_pattern_bind: row pointers do not describe this block (size mismatch)");
+    try
+      {
+        ensure_host_graph(c);
+      }
+    catch (const std::bad_alloc &)
+      {
+        return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+      }
     std::vector<int32_t> order(c->h_nadj.size());
     std::atomic<int> bad{0}; // 1: structure, 2: column set
     std::atomic<bool> changed{false};
@@ -942,11 +1130,14 @@ extern "C"
         try
           {
             c->h_nadj.swap(order);
-            if (!c->h_nadj.empty() &&
-                hipMemcpy(const_cast<int32_t *>(c->v.nadj), c->h_nadj.data(), c->h_nadj.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-              throw HipFail{hipGetLastError(), "hipMemcpy nadj"};
-            if (launch_build_cslot(c->v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
-              throw HipFail{hipGetLastError(), "cslot kernel"};
+            if (c->general_ready) // else: built from the new order when the general family is first used
+              {
+                if (!c->h_nadj.empty() &&
+                    hipMemcpy(const_cast<int32_t *>(c->v.nadj), c->h_nadj.data(), c->h_nadj.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+                  throw HipFail{hipGetLastError(), "hipMemcpy nadj"};
+                if (launch_build_cslot(c->v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
+                  throw HipFail{hipGetLastError(), "cslot kernel"};
+              }
             if (c->cart_ok)
               {
                 std::vector<uint32_t> mask;
@@ -1222,6 +1413,21 @@ extern "C"
     hipError_t e = hipSuccess;
     const bool split = c->prm.decompose_stress_matrix > 0 && c->prm.timestep_number > 0; // cracks.cc:2294
     const bool cart = c->kernel_path == 1 && !split && (residual_only || cart_matrix_supported(c->v.dim));
+    if (!cart && !c->general_ready)
+      {
+        try
+          {
+            ensure_general_tables(c);
+          }
+        catch (const HipFail &f)
+          {
+            return hipfail(c, f.e, f.what);
+          }
+        catch (const std::bad_alloc &)
+          {
+            return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+          }
+      }
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing)

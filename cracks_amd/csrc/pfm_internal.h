@@ -72,6 +72,9 @@ namespace pfm
                        const double *d_oldold, hipStream_t s);
   // fills v.cslot from the current order of the node-graph rows (context creation, pfm_pattern_bind)
   int launch_build_cslot(const DevView &v, hipStream_t s);
+  // d_out[a * n + i] = d_in[i * w + a] (mesh tables: host AoS -> device SoA)
+  int launch_aos_to_soa_i32(const int32_t *d_in, int32_t *d_out, long long n, int w, hipStream_t s);
+  int launch_aos_to_soa_f64(const double *d_in, double *d_out, long long n, int w, hipStream_t s);
   int launch_check_finite(const DevView &v, const double *d, int64_t n, hipStream_t s);
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
   // all peers at once: d_nodes = concatenated lists, d_ptr[n_peers + 1] = their offsets (device)
@@ -135,6 +138,11 @@ struct pfm_ctx
   // host copies needed for pattern queries
   std::vector<long long> h_nadj_ptr;
   std::vector<int32_t> h_nadj;
+  // Lattice meshes: the 27-wide host node graph (h_nadj), its device copy (v.nadj) and the slot table of the general
+  // cell kernel (v.cslot) are 1.1 + 1.1 + 0.65 GB at 1e7 cells and are only needed by pfm_pattern_get / _bind and by the
+  // general family: built on first use (ensure_host_graph, ensure_general_tables in pfm_host.cpp)
+  bool graph_lazy = false;    // h_nadj not materialised yet (h_nadj_ptr is)
+  bool general_ready = true;  // v.nadj and v.cslot exist on the device
   std::vector<long long> color_ptr; // colour classes of the general cell kernel (DevView::color_cells)
   // owned device allocations
   std::vector<void *> allocs;

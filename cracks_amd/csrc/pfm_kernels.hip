@@ -1018,6 +1018,35 @@ namespace pfm
     return check_launch();
   }
 
+  namespace
+  {
+    // out[a * n + i] = in[i * w + a]: AoS (host order) -> SoA (device order) of the mesh tables
+    template <class T>
+    __global__ void k_aos_to_soa(const T *__restrict__ in, T *__restrict__ out, long long n, int w)
+    {
+      const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (idx >= n * w)
+        return;
+      const long long i = idx / w;
+      const int a = (int)(idx - i * w);
+      out[(long long)a * n + i] = in[idx];
+    }
+  } // namespace
+  int launch_aos_to_soa_i32(const int32_t *d_in, int32_t *d_out, long long n, int w, hipStream_t s)
+  {
+    if (n * w == 0)
+      return PFM_OK;
+    hipLaunchKernelGGL(k_aos_to_soa<int32_t>, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, s, d_in, d_out, n, w);
+    return check_launch();
+  }
+  int launch_aos_to_soa_f64(const double *d_in, double *d_out, long long n, int w, hipStream_t s)
+  {
+    if (n * w == 0)
+      return PFM_OK;
+    hipLaunchKernelGGL(k_aos_to_soa<double>, dim3((unsigned)((n * w + 255) / 256)), dim3(256), 0, s, d_in, d_out, n, w);
+    return check_launch();
+  }
+
   int launch_build_cslot(const DevView &v, hipStream_t s)
   {
     const int nv = 1 << v.dim;
