@@ -96,6 +96,16 @@ namespace pfm
       return s;
     }
 
+    // local node id of lattice node (i,j,k): arithmetic for lexicographically numbered owned nodes (checked at
+    // context creation), table look-up otherwise (ghost layers)
+    __device__ __forceinline__ int cart_local_id3(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.owned_lex && i >= cv.o0[0] && i <= cv.o1[0] && j >= cv.o0[1] && j <= cv.o1[1] && k >= cv.o0[2] && k <= cv.o1[2])
+        return (i - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((j - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (k - cv.o0[2]));
+      return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+    }
+
+
     // =====================================================================================
     // Residual, row owner (cracks.cc:2393-2432 gathered per test vertex).  One wave covers 63
     // x-consecutive owned nodes of one lattice row (+ 1 halo lane): lane l evaluates the q-point state
@@ -154,9 +164,8 @@ namespace pfm
 #pragma unroll
           for (int b = 0; b < nv; ++b)
             {
-              const long long bidx = (ci + (b & 1)) + (long long)cv.NX * ((cj + ((b >> 1) & 1)) +
-                                                                            (long long)cv.NY * (ck + ((b >> 2) & 1)));
-              const int n = cv.local_of_box[bidx];
+              // arithmetic for owned nodes (no index load in front of the field loads)
+              const int n = cart_local_id3(cv, ci + (b & 1), cj + ((b >> 1) & 1), dim == 3 ? ck + ((b >> 2) & 1) : 0);
 #pragma unroll
               for (int d = 0; d < dim; ++d)
                 U[d][b] = v.u[d][n];
@@ -314,7 +323,7 @@ namespace pfm
         R[c] = R0[c] + __shfl_up(R1[c], 1);
       if (lane == 0 || xi >= OWX)
         return;
-      const int row = cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+      const int row = cart_local_id3(cv, i, j, k);
       // constrained scatter degenerates to a masked store (cracks.cc:2440-2456)
       const unsigned fl = v.node_flags[row];
 #pragma unroll
@@ -340,15 +349,6 @@ namespace pfm
     // adds its 4 cell columns in a fixed order and writes its rows exactly once.  Nodal values live in a
     // two-plane LDS ring: every plane is read from HBM/L2 once per tile.
     // =====================================================================================
-    // local node id of lattice node (i,j,k): arithmetic for lexicographically numbered owned nodes (checked at
-    // context creation), table look-up otherwise (ghost layers)
-    __device__ __forceinline__ int cart_local_id3(const CartView &cv, int i, int j, int k)
-    {
-      if (cv.owned_lex && i >= cv.o0[0] && i <= cv.o1[0] && j >= cv.o0[1] && j <= cv.o1[1] && k >= cv.o0[2] && k <= cv.o1[2])
-        return (i - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((j - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (k - cv.o0[2]));
-      return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
-    }
-
     constexpr int RTX = 16, RTY = 16;           // cell columns per workgroup = threads
     constexpr int RNX = RTX - 1, RNY = RTY - 1; // owned nodes per tile plane
     constexpr int RHX = RTX + 1, RHY = RTY + 1; // nodal halo per plane
