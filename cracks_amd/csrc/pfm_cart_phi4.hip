@@ -437,12 +437,13 @@ namespace pfm
 
     // =====================================================================================
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */,
-              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */>
+              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
+              bool RES = false /* also writes the phase-field rows of the residual (res_pde) */>
     __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
                                                           double *__restrict__ vals_up /* blocked layout: structurally zero (u,phi) block, cleared here */,
                                                           int zc /* node planes per chunk */,
-                                                          unsigned long long *__restrict__ dbg)
+                                                          unsigned long long *__restrict__ dbg, double *__restrict__ res_pde)
     {
       __shared__ Lds4 s;
       const MatScal &S = *Sp; // per-launch scalars live in device memory: loaded where used, not pinned in SGPRs
@@ -560,6 +561,7 @@ namespace pfm
       __syncthreads();
       if (t < NPH && s.flag[(kA - 1) & 3][t])
         s.anyflag[(kA - 1) & 3] = 1;
+      double r_m1 = 0.0; // RES, wave 3, lane <-> node: the oz = -1 part of K_phiphi phi of the next plane
 #pragma unroll 1
       for (int ck = kA - 1; ck < kB; ++ck)
         {
@@ -690,6 +692,51 @@ namespace pfm
                     lds_add(&ex[1], patch);
                   }
               });
+              if constexpr (RES)
+                {
+                  // Phase-field rows of the residual from the (phi,phi) rows of the matrix: with the unclamped phase field
+                  // of the staggered scheme every term of cracks.cc:2412-2431 but -G_c/eps N_a is the matching term of
+                  // cracks.cc:2370-2383 times phi_b, i.e.  R_phi = G_c/eps sum_q N_a JxW - K_phiphi phi  (UNMASKED rows).
+                  // All (phi,phi) pushes come from this wave, so its staged rows are complete here without a barrier;
+                  // lane <-> node; the oz = -1 part of a plane is formed one step earlier, while phi of the plane below is
+                  // still in the ring, and carried in a register.
+                  int lq = lane;
+                  asm volatile("" : "+v"(lq));
+                  const int nl = min(lq, NPN - 1), nx = nl % PN, ny = nl / PN, hn = (nx + 1) + PH * (ny + 1);
+                  const double *phi_lo = &s.U[lo][3][hn], *phi_hi = &s.U[hi][3][hn];
+                  if (ck >= kA)
+                    {
+                      double sum = r_m1;
+                      const double *z0 = s.pp[2 + cp] + nl * 9, *p1 = s.pp[4] + nl * 9;
+#pragma unroll
+                      for (int o9 = 0; o9 < 9; ++o9)
+                        {
+                          const int nb = (o9 % 3 - 1) + PH * (o9 / 3 - 1);
+                          sum = fma(z0[o9], phi_lo[nb], sum);
+                          sum = fma(p1[o9], phi_hi[nb], sum);
+                        }
+                      const long long off = s.off[cp][nl];
+                      if (lq < NPN && off >= 0)
+                        {
+                          const int gi = i0 + nx, gj = j0 + ny;
+                          const int ncell = ((gi > 0) + (gi < cv.NX - 1)) * ((gj > 0) + (gj < cv.NY - 1)) * ((ck > 0) + (ck < cv.NZ - 1));
+                          const double mass = S.gc_eps * (S.vol * 0.125) * (double)ncell;
+                          const bool con = (s.flag[ck & 3][hn] >> 3) & 1u;
+                          const int row = cart_local_id(cv, gi, gj, ck);
+                          const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + 3 : (long long)v.n_owned * 3 + row;
+                          res_pde[di] = con ? 0.0 : mass - sum;
+                        }
+                    }
+                  if (ck + 1 < kB)
+                    {
+                      const double *m1 = s.pp[np] + nl * 9;
+                      double sum = 0.0;
+#pragma unroll
+                      for (int o9 = 0; o9 < 9; ++o9)
+                        sum = fma(m1[o9], phi_lo[(o9 % 3 - 1) + PH * (o9 / 3 - 1)], sum);
+                      r_m1 = sum;
+                    }
+                }
             }
           if constexpr (CLK == 2)
             {
@@ -917,7 +964,7 @@ namespace pfm
   }
 
   int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
-                       const void *d_scal)
+                       const void *d_scal, double *res_pde)
   {
     const MatScal *S = static_cast<const MatScal *>(d_scal);
     if (v.dim != 3)
@@ -933,14 +980,27 @@ namespace pfm
     const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
     const int nch = (OWZ + zc - 1) / zc;
     const unsigned nb = (unsigned)(ntx * nty * nch);
-    if (cv.cell_lam && v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL((k_cart_phi4<4, 0, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr, zc,
-                         nullptr);
-    else if (cv.cell_lam)
-      hipLaunchKernelGGL((k_cart_phi4<3, 0, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0],
-                         d_values[1], zc, nullptr);
-    else if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_phi4<4>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, nullptr, nullptr, d_values[0], nullptr, zc, nullptr);
+    const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
+    const dim3 grid(xcd_grid(nb)), block(NT4);
+#define PFM_PHI4(NC, HETV, RESV)                                                                                                  \
+  hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),            \
+                     (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 ? d_values[1] : nullptr), zc, nullptr, res_pde)
+    if (il)
+      {
+        if (het)
+          PFM_PHI4(4, true, false); // heterogeneous material: the residual kernel runs
+        else
+          {
+            if (res)
+              PFM_PHI4(4, false, true);
+            else
+              PFM_PHI4(4, false, false);
+          }
+      }
+    else if (het)
+      PFM_PHI4(3, true, false); // heterogeneous material: the residual kernel runs
+    else if (res)
+      PFM_PHI4(3, false, true);
     else if (getenv("PFM_PHI_CLK")) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
@@ -950,10 +1010,10 @@ namespace pfm
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
         if (atoi(getenv("PFM_PHI_CLK")) == 2)
           hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
-                             d_values[0], d_values[1], zc, d_dbg);
+                             d_values[0], d_values[1], zc, d_dbg, nullptr);
         else
           hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
-                             d_values[0], d_values[1], zc, d_dbg);
+                             d_values[0], d_values[1], zc, d_dbg, nullptr);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[16] = {};
@@ -969,8 +1029,8 @@ namespace pfm
         fprintf(stderr, "\n");
       }
     else
-      hipLaunchKernelGGL(k_cart_phi4<3>, dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3], d_values[0], d_values[1],
-                         zc, nullptr);
+      PFM_PHI4(3, false, false);
+#undef PFM_PHI4
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   bool cart_matrix_supported(int dim) { return dim == 2 || dim == 3; }
@@ -978,14 +1038,15 @@ namespace pfm
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
   // (same stream) and clears the structurally zero (u,phi) block (cracks.cc:2333-2337) along with its (phi,u) stores
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
-                         void *d_scal)
+                         void *d_scal, double *res_pde)
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
     static const bool use_uu3 = getenv("PFM_UU4") == nullptr; // PFM_UU4=1: the z-marching variant (pfm_cart_uu4.hip), measured equal
-    int rc = (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal) : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
+    int rc = (use_uu3 || cv.cell_lam || res_pde) ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde)
+                                                 : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
     if (rc)
       return rc;
-    return launch_cart_phi4(v, cv, p, d_values, s, d_scal);
+    return launch_cart_phi4(v, cv, p, d_values, s, d_scal, res_pde);
   }
 } // namespace pfm

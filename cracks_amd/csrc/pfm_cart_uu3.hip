@@ -171,13 +171,18 @@ namespace pfm
     // the oz = 0 slots, the constraint masks, 3 staged values per slot.  stage_half = the lane's staged row shifted by 18
     // slots for the upper half (a slot with oz = -1 completed by the lower half is slot o_lo, its mirror completed by the
     // upper half is o_lo + 18); oz = 0 slots are summed over the halves and stored by both (same value, same address).
-    template <int W, int C, bool MASKED, bool HET>
-    __device__ __forceinline__ void uu_row_component(const double (&tv)[4][9], const UuCoef &K, const double (&lamv)[4],
-                                                     const double (&muv)[4], double *__restrict__ stage_row,
-                                                     double *__restrict__ stage_half, unsigned row_flag,
-                                                     const unsigned char *__restrict__ flag_own,
-                                                     const unsigned char *__restrict__ flag_half)
+    // RES: also returns (in every lane of the node) this slot set's part of  sum_j K[(node,C),(j,d)] u_(j,d)  over the
+    // UNMASKED entries -- the displacement residual is  R_u = (alpha_B-1) p sum_q pfx^2 dN/dx_C JxW - K_uu u  for the
+    // unsplit law (sigma+ is linear in u; cracks.cc:2393-2410 against 2340-2368)
+    template <int W, int C, bool MASKED, bool HET, bool RES>
+    __device__ __forceinline__ double uu_row_component(const double (&tv)[4][9], const UuCoef &K, const double (&lamv)[4],
+                                                       const double (&muv)[4], double *__restrict__ stage_row,
+                                                       double *__restrict__ stage_half, unsigned row_flag,
+                                                       const unsigned char *__restrict__ flag_own,
+                                                       const unsigned char *__restrict__ flag_half,
+                                                       const double *__restrict__ u_own, const double *__restrict__ u_half)
     {
+      double dot_plane = 0.0, dot_half = 0.0;
       constexpr int NS = nslots_of(W);
       double val[NS][3];
 #pragma unroll
@@ -202,6 +207,15 @@ namespace pfm
                 v1 = add_across_halves(v1);
                 v2 = add_across_halves(v2);
               }
+            if constexpr (RES)
+              {
+                const double *un = (vi.oz == 0 ? u_own : u_half) + (vi.ox + H3X * vi.oy);
+                const double part = fma(v2, un[2 * NH3], fma(v1, un[NH3], v0 * un[0]));
+                if constexpr (vi.oz == 0)
+                  dot_plane += part; // the same value in both halves
+                else
+                  dot_half += part;
+              }
             if constexpr (MASKED)
               {
                 const unsigned cf = (vi.oz == 0 ? flag_own : flag_half)[vi.ox + H3X * vi.oy];
@@ -221,13 +235,21 @@ namespace pfm
             dst[2] = v2;
           }
       });
+      if constexpr (RES)
+        {
+          constexpr bool has_half = !(W == 0 || W == 2 || W == 3 || W == 6);
+          return has_half ? add_across_halves(dot_half) : dot_plane;
+        }
+      else
+        return 0.0;
     }
 
     // =====================================================================================
     template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */,
-              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */>
+              bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
+              bool RES = false /* also writes the displacement rows of the residual (res_pde) */>
     __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
-                                                         unsigned long long *__restrict__ dbg)
+                                                         unsigned long long *__restrict__ dbg, double *__restrict__ res_pde)
     {
       const MatScal &S = *Sp; // per-launch scalars in device memory (see pfm_internal.h)
       long long tclk = 0;
@@ -249,6 +271,9 @@ namespace pfm
       __shared__ long long s_rowbase[NN3];
       __shared__ unsigned s_mask[NN3]; // neighbour mask of the row (bit o: lattice offset o exists)
       __shared__ double s_lam[HET ? CS3 : 1], s_mu[HET ? CS3 : 1]; // Lame coefficients of the tile's cells
+      __shared__ double s_u[RES ? 3 * NH3 : 1];                    // displacements of the halo nodes [component][node]
+      __shared__ double s_part[RES ? 2 * 8 * NN3 : 1];             // K u per [component & 1][wave = slot set][node]
+      __shared__ double s_pres[RES ? 3 * NN3 : 1];                 // pressure part of the residual [component][node]
       __shared__ int s_any[4]; // waves 0..2: some node of the halo carries a displacement flag; [3]: some row is not full
       static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
 
@@ -268,7 +293,7 @@ namespace pfm
           const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / (H3X * H3Y);
           const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = k - 1 + lk;
           int n = -1;
-          double a = 0.0, b = 0.0;
+          double a = 0.0, b = 0.0, uu[3] = {0.0, 0.0, 0.0};
           unsigned char f = 0;
           if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ)
             {
@@ -276,8 +301,20 @@ namespace pfm
               a = v.phi_old[n];
               b = v.phi_oldold[n];
               f = v.node_flags[n];
+              if constexpr (RES)
+                {
+                  uu[0] = v.u[0][n];
+                  uu[1] = v.u[1][n];
+                  uu[2] = v.u[2][n];
+                }
               if (!S.monolithic) // one combined field is interpolated in the cell phase (cell_wg_plane_lin)
                 a = S.use_old ? a : b + S.tfac * (a - b);
+            }
+          if constexpr (RES)
+            {
+              s_u[t] = uu[0];
+              s_u[(RES ? NH3 : 0) + t] = uu[1];
+              s_u[(RES ? 2 * NH3 : 0) + t] = uu[2];
             }
           s_node[t] = n;
           s_po[t] = a;
@@ -548,6 +585,41 @@ namespace pfm
           }
       };
 
+      // RES: pressure part of the displacement residual, (alpha_B-1) p sum_q pfx^2 dN_a/dx_c JxW, from the A^c tables of
+      // the 8 cells around the node (slot set 0 visits exactly those): sum_q w g n_ai n_aj is the sum of the four moments
+      // A^c[a_i + b_i][a_j + b_j] (n_0 + n_1 = 1), and vol w pfx^2 = (w g - kappa vol w) / (1 - kappa)
+      if constexpr (RES)
+        {
+          if (wave == 0)
+            {
+              double pres[3] = {0.0, 0.0, 0.0};
+              const double kv4 = S.kappa * S.vol * 0.25;
+              static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+                constexpr Vis vi = visit_of(0, decltype(Vv)::value);
+                constexpr int a[3] = {-vi.ex, -vi.ey, 1};
+                const double *cell = lane_base + (vi.ey * C3X + vi.ex);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  {
+                    const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
+                    const double s4 = (cell[idxA3(k, a[i], a[j]) * CS3] + cell[idxA3(k, a[i] + 1, a[j]) * CS3]) +
+                                      (cell[idxA3(k, a[i], a[j] + 1) * CS3] + cell[idxA3(k, a[i] + 1, a[j] + 1) * CS3]);
+                    const double mom = s4 - (s4 != 0.0 ? kv4 : 0.0); // absent cell: all tables are zero
+                    const bool neg = (k == 2) ? upper : (a[k] == 0);   // sign of dN_a/dx_k (upper layer: z-mirrored tables)
+                    pres[k] += neg ? -mom : mom;
+                  }
+              });
+              const double pc = S.aB1 * S.p / (1.0 - S.kappa);
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                {
+                  const double pk = add_across_halves(pres[k]) * (pc * S.ih[k]);
+                  if (!upper)
+                    s_pres[RES ? k * NN3 + nl_lane : 0] = pk; // read behind the barrier of component 0 at the earliest
+                }
+            }
+        }
+      __builtin_amdgcn_sched_barrier(0); // the pressure part is finished before the table batch is requested
       // the slot set of a wave is selected by scalar branches around the set-specific code only (table reads, the
       // arithmetic of one row component); barriers and the copy-out are shared code (instruction cache: 8 sets x 3
       // components x 2 mask variants of straight-line code)
@@ -577,31 +649,58 @@ namespace pfm
             muv[V] = s_mu[cs];
           }
       }))
+      const double *u_own = s_u + (RES ? hc : 0), *u_half = s_u + (RES ? hc + (upper ? H3X * H3Y : -H3X * H3Y) : 0);
       // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the table storage: written after the
       // barrier of component 0, which every wave passes with its table values in registers
       double *st0 = s_stage + nl_lane * STG, *st1 = s_tab + nl_lane * STG;
       const int hs = upper ? 18 * 3 : 0;
+      double ku = 0.0;
+      // residual row of component c: sum of the 8 slot sets in a fixed order, constrained rows get 0 (cracks.cc:2440-2456)
+      auto residual_out = [&](int c) __attribute__((always_inline)) {
+        if constexpr (RES)
+          {
+            if (t < NN3 && s_rowbase[t] >= 0)
+              {
+                double sum = -s_pres[RES ? c * NN3 + t : 0];
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                  sum += s_part[((c & 1) * 8 + w) * NN3 + t]; // component 2 reuses buffer 0 behind the barrier of component 1
+                const int li = t % T3X, lj = t / T3X;
+                const int row = cart_local_id(cv, i0 + li, j0 + lj, k);
+                const bool con = (s_flag[(li + 1) + H3X * ((lj + 1) + H3Y * 1)] >> c) & 1u;
+                const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + c : (long long)row * 3 + c;
+                res_pde[di] = con ? 0.0 : -sum;
+              }
+          }
+      };
 #define PFM_COMPONENT(C, ST)                                                                                                 \
   if (masked)                                                                                                                \
     {                                                                                                                        \
-      PFM_PER_SET((uu_row_component<W, C, true, HET>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half)))                         \
+      PFM_PER_SET((ku = uu_row_component<W, C, true, HET, RES>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half, \
+                                                               u_own, u_half)))                                             \
     }                                                                                                                        \
   else                                                                                                                       \
     {                                                                                                                        \
-      PFM_PER_SET((uu_row_component<W, C, false, HET>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half)))                        \
-    }
+      PFM_PER_SET((ku = uu_row_component<W, C, false, HET, RES>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half, \
+                                                                u_own, u_half)))                                            \
+    }                                                                                                                        \
+  if (RES && !upper)                                                                                                         \
+    s_part[RES ? ((C & 1) * 8 + wave) * NN3 + nl_lane : 0] = ku;
       PFM_COMPONENT(0, st0)
       lds_barrier();
       stamp(3);
       copy_out(0, s_stage);
+      residual_out(0);
       PFM_COMPONENT(1, st1)
       lds_barrier();
       stamp(4);
       copy_out(1, s_tab);
+      residual_out(1);
       PFM_COMPONENT(2, st0)
       lds_barrier();
       stamp(3);
       copy_out(2, s_stage);
+      residual_out(2);
       stamp(4);
 #undef PFM_COMPONENT
 #undef PFM_PER_SET
@@ -609,7 +708,7 @@ namespace pfm
   } // namespace
 
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal)
+                      const void *d_scal, double *res_pde)
   {
     int rc = ensure_g1();
     if (rc)
@@ -619,20 +718,17 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const unsigned nb = (unsigned)(ntx * nty * OWZ);
-    if (cv.cell_lam && v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL((k_cart_uu3<4, false, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
-    else if (cv.cell_lam)
-      hipLaunchKernelGGL((k_cart_uu3<3, false, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
-    else if (v.layout == PFM_LAYOUT_INTERLEAVED)
-      hipLaunchKernelGGL(k_cart_uu3<4>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
-    else if (getenv("PFM_UU_CLK")) // profiling only
+    const dim3 grid(xcd_grid(nb)), block(NT3);
+    const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
+#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, 0, s, v, cv, S, vals_uu, nullptr, res_pde)
+    if (getenv("PFM_UU_CLK") && !il && !het && !res) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
         const size_t nd = (size_t)xcd_grid(nb) * 8;
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_cart_uu3<3, true>), dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, d_dbg);
+        hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[8] = {};
@@ -644,8 +740,31 @@ namespace pfm
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
         fprintf(stderr, "\n");
       }
+    else if (il)
+      {
+        if (het)
+          PFM_UU3(4, true, false); // heterogeneous material: the residual kernel runs
+        else
+          {
+            if (res)
+              PFM_UU3(4, false, true);
+            else
+              PFM_UU3(4, false, false);
+          }
+      }
     else
-      hipLaunchKernelGGL(k_cart_uu3<3>, dim3(xcd_grid(nb)), dim3(NT3), 0, s, v, cv, S, vals_uu, nullptr);
+      {
+        if (het)
+          PFM_UU3(3, true, false); // heterogeneous material: the residual kernel runs
+        else
+          {
+            if (res)
+              PFM_UU3(3, false, true);
+            else
+              PFM_UU3(3, false, false);
+          }
+      }
+#undef PFM_UU3
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   // entry point used by the debug overlay (pfm_ctx_force_path(ctx, 2)) and by launch_cart_matrix
@@ -653,6 +772,6 @@ namespace pfm
                           void *d_scal)
   {
     static const bool use_uu3 = getenv("PFM_UU4") == nullptr;
-    return (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
+    return (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal, nullptr) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -106,9 +106,10 @@ namespace pfm
   // after every pfm_set_params, pfm_ctx::scal_dirty)
   int upload_mat_scal(const pfm_params &p, const CartView &cv, void *d_scal, hipStream_t s);
   int launch_cart_phi4(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
-                       const void *d_scal);
+                       const void *d_scal, double *res_pde);
+  // res_pde != nullptr: the kernel also writes the displacement rows of the residual (from its matrix rows, see the kernel)
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal);
+                      const void *d_scal, double *res_pde);
   // z-marching variant of launch_cart_uu3 (pfm_cart_uu4.hip): bitwise identical results, measured equal in time;
   // selected by PFM_UU4=1 (A/B runs, tests/test_gpu_cart.py runs both)
   int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
