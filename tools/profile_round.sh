@@ -10,7 +10,12 @@ python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err
 python bench.py --residual-only --no-cpu-baseline > $O/bench_216cube_residual_only.json 2>/dev/null
 python bench.py --dim 2 --residual-only --no-cpu-baseline > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
 python bench.py --dim 2 --no-cpu-baseline > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
-PFM_UU4=1 python bench.py --no-cpu-baseline > $O/bench_216cube_uu4.json 2>/dev/null
+PFM_UU4=1 PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline > $O/bench_216cube_uu4.json 2>/dev/null
+PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline > $O/bench_216cube_residual_kernel.json 2>/dev/null
+python bench.py --n 100 --path general --no-cpu-baseline --steps 5 > $O/bench_100cube_general.json 2>/dev/null
+python bench.py --dim 2 --path general --no-cpu-baseline > $O/bench_2d_1000sq_general.json 2>/dev/null
+python tools/bench_extra.py config5 --levels 8 --meshes 5 --world 1 --out $O/config5_miehe_amr.json > /dev/null 2>&1
+(cd tools/microbench && [ -x ./lat ] && timeout 120 ./lat > $O/microbench_load_latency.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
 run_prof () { # name, extra rocprof args..., -- bench args
   name=$1; shift
@@ -64,7 +69,7 @@ rm -rf $O/stats $O/stats_res $O/pmc_sq $O/pmc_lds $O/pmc_WRITE_SIZE $O/pmc_FETCH
 grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
 python -c "
 import json
-for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residual_only','bench_2d_1000sq_jacobian','bench_216cube_uu4'):
+for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residual_only','bench_2d_1000sq_jacobian','bench_216cube_uu4','bench_216cube_residual_kernel','bench_100cube_general','bench_2d_1000sq_general'):
     try:
         d=json.load(open('$O/'+f+'.json')); r=d['roofline']; print(f, 'ms/step %.3f kernel_ms %.3f median %.3f frac %.4f value %.3e ctx_create %s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['frac'], d['value'], d['config'].get('ctx_create_s')))
     except Exception as e: print(f, 'FAILED', e)
