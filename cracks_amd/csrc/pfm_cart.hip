@@ -339,6 +339,208 @@ namespace pfm
 
 
     // =====================================================================================
+    // 2-D residual, y-marching cell columns (cracks.cc:2393-2432), no LDS and no barrier.
+    //
+    // A wave (= a workgroup) owns 62 x-consecutive nodes over a chunk of node rows; lane l <-> the cell column between
+    // nodes i0 - 1 + l and i0 + l (lane 63 only contributes its node's values).  Marching up in y, a lane loads ONE node
+    // per row (the next row is requested before the current cell is evaluated), gets the right-hand vertices from lane
+    // l + 1 (DPP shift), evaluates its cell once, keeps the part that belongs to the upper node row for the next step and
+    // completes node row j from its own a_x = 0 parts and the a_x = 1 parts of lane l - 1.  Every cell is evaluated once
+    // per chunk (the first-generation kernel below evaluates it for both node rows it touches), every nodal value is
+    // read once per tile, and a wave waits for one memory round trip per row that the evaluation of the previous row
+    // covers.  LIN: one combined old phase field as in k_cart_residual3.
+    // =====================================================================================
+    constexpr int R2N = 62; // owned nodes per wave
+    template <bool LIN>
+    __global__ __launch_bounds__(64) void k_cart_residual2m(DevView v, CartView cv, Scal S, double *__restrict__ res_pde,
+                                                            double *__restrict__ res_tot, int write_total, int zc)
+    {
+      constexpr int NF = LIN ? 4 : 5; // u_x u_y phi + (combined old field | phi_old phi_oldold)
+      const int lane = threadIdx.x;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1;
+      const int ntx = (OWX + R2N - 1) / R2N;
+      const int tix = (int)(blockIdx.x % ntx), chunk = (int)(blockIdx.x / ntx);
+      const int i = cv.o0[0] + tix * R2N - 1 + lane; // this lane's node column = left vertex of its cell column
+      const int jA = cv.o0[1] + chunk * zc;
+      const int jB = min(jA + zc, cv.o1[1] + 1); // node rows [jA, jB)
+      const bool node_in = i >= 0 && i < cv.NX;
+      const bool col_ok = lane < 63 && i >= 0 && i < cv.NX - 1;
+      const bool owner = lane >= 1 && lane <= R2N && i <= cv.o1[0];
+      const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1];
+      const double vol = cv.h[0] * cv.h[1];
+
+      auto load_row = [&](int j, double (&val)[NF]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          val[f] = 0.0;
+        if (node_in && j >= 0 && j < cv.NY)
+          {
+            const int n = cart_local_id3(cv, i, j, 0);
+            val[0] = v.u[0][n];
+            val[1] = v.u[1][n];
+            val[2] = v.phi[n];
+            const double po = v.phi_old[n], poo = v.phi_oldold[n];
+            if constexpr (LIN)
+              val[3] = S.use_old ? po : poo + S.tfac * (po - poo);
+            else
+              {
+                val[3] = po;
+                val[4] = poo;
+              }
+          }
+      };
+      double lo[NF], up[NF], carry[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+      load_row(jA - 1, lo);
+#pragma unroll 1
+      for (int cj = jA - 1; cj < jB; ++cj)
+        {
+          load_row(cj + 1, up);
+          double R[2][2][3]; // [ax][ay][component]
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+            R[a & 1][a >> 1][0] = R[a & 1][a >> 1][1] = R[a & 1][a >> 1][2] = 0.0;
+          // right-hand vertices: the nodes of lane + 1
+          double lo1[NF], up1[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            {
+              lo1[f] = __shfl_down(lo[f], 1);
+              up1[f] = __shfl_down(up[f], 1);
+            }
+          if (col_ok && cj >= 0 && cj < cv.NY - 1)
+            {
+              double lam = S.lam, mu = S.mu;
+              if (cv.cell_lam) // heterogeneous material, cracks.cc:2207-2216
+                {
+                  lam = cv.cell_lam[i + (long long)(cv.NX - 1) * cj];
+                  mu = cv.cell_mu[i + (long long)(cv.NX - 1) * cj];
+                }
+              double Dy[3][2], dDy[3]; // d/dy at x-vertex 0/1 (constant along y) and its x-difference
+#pragma unroll
+              for (int f = 0; f < 3; ++f)
+                {
+                  Dy[f][0] = (up[f] - lo[f]) * ihy;
+                  Dy[f][1] = (up1[f] - lo1[f]) * ihy;
+                  dDy[f] = Dy[f][1] - Dy[f][0];
+                }
+              const double mu2 = 2 * mu;
+#pragma unroll 1
+              for (int qy = 0; qy < 3; ++qy)
+                {
+                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy];
+                  const double wy = vol * c_t1.w[qy];
+                  double L0[NF], dL[NF];
+#pragma unroll
+                  for (int f = 0; f < NF; ++f)
+                    {
+                      L0[f] = ny0 * lo[f] + ny1 * up[f];
+                      dL[f] = (ny0 * lo1[f] + ny1 * up1[f]) - L0[f];
+                    }
+                  const double Dx0 = dL[0] * ihx, Dx1 = dL[1] * ihx, Dxp = dL[2] * ihx;
+                  double X0[3] = {0.0, 0.0, 0.0}, X1[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, XS[2] = {0.0, 0.0};
+#pragma unroll
+                  for (int qx = 0; qx < 3; ++qx)
+                    {
+                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
+                      const double JxW = wy * c_t1.w[qx];
+                      const double g00 = Dx0, g10 = Dx1;
+                      const double g01 = fma(nx1, dDy[0], Dy[0][0]), g11 = fma(nx1, dDy[1], Dy[1][0]);
+                      const double gp0 = Dxp, gp1 = fma(nx1, dDy[2], Dy[2][0]);
+                      double pf = fma(nx1, dL[2], L0[2]);
+                      double pfo = fma(nx1, dL[3], L0[3]); // LIN: the combined field
+                      double pen = 0.0, pfx;
+                      if constexpr (LIN)
+                        {
+                          pfx = pfo;
+                          if (!S.use_old)
+                            pfx = fmin(fmax(pfx, 0.0), 1.0);
+                        }
+                      else
+                        {
+                          double pfoo = fma(nx1, dL[NF - 1], L0[NF - 1]);
+                          if (S.monolithic)
+                            {
+                              pf = fmax(0.0, pf);
+                              pfo = fmax(0.0, pfo);
+                              pfoo = fmax(0.0, pfoo);
+                            }
+                          pen = fmax(0.0, pf - pfo);
+                          pfx = pfoo + S.tfac * (pfo - pfoo);
+                          if (pfx <= 0.0)
+                            pfx = 0.0;
+                          if (pfx >= 1.0)
+                            pfx = 1.0;
+                          if (S.use_old)
+                            pfx = pfo;
+                        }
+                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
+                      const double t01 = g01 + g10, trE = g00 + g11;
+                      const double lt = lam * trE;
+                      const double s00 = fma(mu2, g00, lt), s11 = fma(mu2, g11, lt), s01 = mu * t01;
+                      const double spE = fma(s00, g00, s11 * g11) + s01 * t01;
+                      const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;
+                      const double z00 = gJ * s00 - pd, z11 = gJ * s11 - pd, z01 = gJ * s01;
+                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
+                                         2.0 * S.aB1 * S.p * pf * trE) *
+                                        JxW;
+                      const double ge = S.Gc * S.eps * JxW;
+                      const double F[3][2] = {{z00, z01}, {z01, z11}, {ge * gp0, ge * gp1}};
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        {
+                          X0[c] += F[c][0];
+                          X1[c][0] += F[c][1] * nx0;
+                          X1[c][1] += F[c][1] * nx1;
+                        }
+                      XS[0] += rq * nx0;
+                      XS[1] += rq * nx1;
+                    }
+#pragma unroll
+                  for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax)
+                      {
+                        double tA = (ax ? ihx : -ihx) * X0[c];
+                        if (c == 2)
+                          tA += XS[ax];
+                        const double tB = ihy * X1[c][ax];
+                        R[ax][0][c] -= ny0 * tA - tB;
+                        R[ax][1][c] -= ny1 * tA + tB;
+                      }
+                }
+            }
+          // node row cj: own a_x = 0 parts + the a_x = 1 parts of the cell column on the left (lane - 1)
+          double tot[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            tot[c] = (R[0][0][c] + carry[0][c]) + __shfl_up(R[1][0][c] + carry[1][c], 1);
+          if (cj >= jA && owner)
+            {
+              const int row = cart_local_id3(cv, i, cj, 0);
+              const unsigned fl = v.node_flags[row];
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                {
+                  const bool con = (fl >> c) & 1u;
+                  const long long di = dof_index_c<2>(v, row, c);
+                  res_pde[di] = con ? 0.0 : tot[c]; // constrained scatter = masked store (cracks.cc:2440-2456)
+                  if (write_total)
+                    res_tot[di] = (con && S.total_via_update) ? 0.0 : tot[c];
+                }
+            }
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            {
+              carry[0][c] = R[0][1][c];
+              carry[1][c] = R[1][1][c];
+            }
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            lo[f] = up[f];
+        }
+    }
+
+    // =====================================================================================
     // 3-D residual, z-marching cell columns (cracks.cc:2393-2432).
     //
     // A workgroup owns a 15 x 15 column of nodes over a chunk of z-planes; thread <-> one of the 16 x 16
@@ -697,7 +899,22 @@ namespace pfm
     const long long n_waves = OWY * OWZ * ((OWX + 62) / 63);
     const unsigned nb = (unsigned)((n_waves + 3) / 4);
     if (v.dim == 2)
-      hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+      {
+        static const bool first_gen = getenv("PFM_RES2_OLD") != nullptr; // A/B: the first-generation kernel
+        if (first_gen)
+          hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+        else
+          {
+            const int ntx = (int)((OWX + R2N - 1) / R2N);
+            static const int zc_force = getenv("PFM_RES2_ZC") ? atoi(getenv("PFM_RES2_ZC")) : 0; // tuning only
+            const int zc = zc_force > 0 ? zc_force : choose_zchunk(ntx, (int)OWY, 4, 64, 8);
+            const unsigned nw = (unsigned)(ntx * ((OWY + zc - 1) / zc));
+            if (!S.monolithic && S.gamma_fac == 0.0)
+              hipLaunchKernelGGL(k_cart_residual2m<true>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+            else
+              hipLaunchKernelGGL(k_cart_residual2m<false>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+          }
+      }
     else
       {
         const int ntx = (int)((OWX + RNX - 1) / RNX), nty = (int)((OWY + RNY - 1) / RNY);
