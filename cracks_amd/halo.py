@@ -56,6 +56,7 @@ class HaloExchange:
                          and os.environ.get("PFM_HALO_TORCH") != "1")
         self._comm = None
         self._comm_lib = None
+        self._lib_checked = False
 
     @property
     def bytes_per_exchange(self) -> int:
@@ -134,8 +135,28 @@ class HaloExchange:
         if self._use_lib:
             self._ensure_comm(ctx)
         if self._use_lib:
-            ctx.halo_exchange(self._comm.value, self.peers)
-            return
+            if self._lib_checked:
+                ctx.halo_exchange(self._comm.value, self.peers)
+                return
+            # first use of the in-library transport: every rank reports its outcome, and all ranks fall back to
+            # torch.distributed together if any of them failed (the enqueue of a failed rank never matches its peers')
+            from . import capi
+
+            try:
+                ctx.halo_exchange(self._comm.value, self.peers)
+                self.torch.cuda.current_stream().synchronize()
+                good = 1
+            except capi.PfmError:
+                good = 0
+            ok = self.torch.tensor([good], device=self.send_all.device)
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
+            self._lib_checked = True
+            if int(ok.item()) == 1:
+                return
+            import warnings
+
+            warnings.warn("pfm_halo_exchange failed on some rank: ghost exchange falls back to torch.distributed P2P")
+            self._use_lib = False
         if self.send_all.numel():
             ctx.halo_pack_all(self.send_all.data_ptr())  # one launch for all peers
         self._post()
