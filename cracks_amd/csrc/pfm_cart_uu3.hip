@@ -540,26 +540,30 @@ namespace pfm
       auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
         if (regular_tile)
           {
-            // 6 positions per thread (the last one for t < 32 only): both LDS reads of all of them in flight before the
-            // first store -- a loop pays two dependent LDS round trips (~130 cycles each) per iteration
-            constexpr int NIT = (NN3 * STG + NT3 - 1) / NT3;
-            long long rb[NIT];
-            double val[NIT];
-            int el[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i)
+            // thread <-> (node group g, element el) with el fixed: nodes g, g + 6, ..., g + 30 -- no division per
+            // position, one row-base read and one value read per node, all of them in flight before the first store (a
+            // loop pays two dependent LDS round trips of ~130 cycles per iteration); threads 486..511 idle
+            constexpr int NG = 6, NIT = (NN3 + NG - 1) / NG;
+            int tq = t;
+            asm volatile("" : "+v"(tq)); // (g, el) are recomputed per component, not kept live across the node phases
+            const int g = tq / STG, el = tq - g * STG;
+            if (g < NG)
               {
-                const int f = min(t + NT3 * i, NN3 * STG - 1);
-                const int nl = f / STG;
-                el[i] = f - nl * STG;
-                rb[i] = s_rowbase[nl];
-                val[i] = stage[f];
-              }
-            __builtin_amdgcn_sched_barrier(0);
+                long long rb[NIT];
+                double val[NIT];
 #pragma unroll
-            for (int i = 0; i < NIT; ++i)
-              if (t + NT3 * i < NN3 * STG)
-                vals[rb[i] + c * STG + el[i]] = val[i];
+                for (int i = 0; i < NIT; ++i)
+                  {
+                    const int nl = min(g + NG * i, NN3 - 1);
+                    rb[i] = s_rowbase[nl];
+                    val[i] = stage[nl * STG + el];
+                  }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NIT; ++i)
+                  if (g + NG * i < NN3)
+                    vals[rb[i] + (c * STG + el)] = val[i];
+              }
           }
         else
           {
