@@ -210,6 +210,31 @@ def sneddon_2d_prerefined_mesh() -> Mesh:
     return refine_cells(m, inside.any(axis=1))
 
 
+def initial_values_multiple_het(mesh: Mesh, min_cell_diameter: float) -> np.ndarray:
+    """Nodal phase field of ``InitialValuesMultipleHet`` (cracks.cc:586-640): 0 inside the initial cracks, else 1.
+    3-D: two bars of cross-section ``width = min_cell_diameter`` (cracks.cc:601-612); 2-D: "example 3" (617-624)."""
+    p = mesh.coords
+    w = 0.5 * min_cell_diameter
+    if mesh.dim == 3:
+        a = ((p[:, 0] >= 2.6 - w) & (p[:, 0] <= 2.6 + w) & (p[:, 1] >= 3.8 - w) & (p[:, 1] <= 5.5 + w) &
+             (p[:, 2] >= 4.0 - w) & (p[:, 2] <= 4.0 + w))
+        b = ((p[:, 0] >= 5.5 - w) & (p[:, 0] <= 7.0 + w) & (p[:, 1] >= 4.0 - w) & (p[:, 1] <= 4.0 + w) &
+             (p[:, 2] >= 6.0 - w) & (p[:, 2] <= 6.0 + w))
+    else:
+        a = (p[:, 0] >= 2.5 - w) & (p[:, 0] <= 2.5 + w) & (p[:, 1] >= 0.8) & (p[:, 1] <= 1.5)
+        b = (p[:, 0] >= 0.5) & (p[:, 0] <= 1.5) & (p[:, 1] >= 3.0 - w) & (p[:, 1] <= 3.0 + w)
+    return np.where(a | b, 0.0, 1.0)
+
+
+def hetero_3d_prerefined_mesh() -> Mesh:
+    """Mesh of tests/hetero_3d_1.prm: ``meshes/unit_cube_10.inp`` ([0,10]^3) refined 3 times globally (512 cells), then one
+    'phase field' prerefinement step (cracks.cc:3971-3995: cells with a vertex where phi < 0.4, phi interpolated with the
+    coarse h, cracks.cc:4134-4160) => 932 cells, 1322 nodes (tests/hetero_3d_1.mpirun-4.output:3-8, :30)."""
+    m = box_mesh(3, 8, 0.0, 10.0)
+    phi = initial_values_multiple_het(m, m.min_cell_diameter())
+    return refine_cells(m, (phi[m.cells] < 0.4).any(axis=1))
+
+
 def slit_mesh(n_refine: int = 3) -> Mesh:
     """Unit square with a slit from (0.5,0.5) to (1,0.5): the coarse 2x2 mesh of the
     reference's ``meshes/unit_slit.inp`` (duplicated nodes along the slit, boundary ids

@@ -117,7 +117,35 @@ def kat_miehe_tension() -> Case:
                   k_factor=0.0)
 
 
-ALL_KATS = [kat_sneddon_3d, kat_sneddon_2d, kat_miehe_shear_1, kat_miehe_shear_2, kat_miehe_tension]
+def kat_hetero_3d() -> Case:
+    """tests/hetero_3d_1.prm -> tests/hetero_3d_1.mpirun-4.output:31 (2.772590e+01): heterogeneous material
+    (cracks.cc:2207-2216, E modulus per cell from the reference's bitmap ``test.pgm`` through ``BitmapFunction``,
+    cracks.cc:118-241), 3-D hanging nodes, pressure ``1e3 * time``.  The per-cell values of ``func_emodulus`` are the
+    fixture ``golden/hetero_3d_emod.json`` (made by ``golden/make_hetero_emod.py`` from the bitmap)."""
+    mesh = M.hetero_3d_prerefined_mesh()
+    h = mesh.min_cell_diameter()
+    lay = M.DofLayout(mesh.n_nodes, 3, blocked=True)  # Use Direct Inner Solver = false
+    E, nu, dt = 1.0e4, 0.2, 0.01
+    lam, mu = lame_from_E_nu(E, nu)
+    prm = make_params(**{"lambda": lam}, mu=mu, G_c=1.0, alpha_eps=1.5, constant_k=0.0,
+                      pressure=1.0e3 * dt, timestep=dt, time=dt, old_timestep=dt,
+                      old_old_timestep=dt, timestep_number=0)
+    phi = M.initial_values_multiple_het(mesh, h)
+    ch = M.hanging_constraints(mesh, lay)
+    cu = M.update_constraints(mesh, lay, M.sneddon_dirichlet_dofs(mesh, lay))  # u = 0 on all six faces, cracks.cc:2688-2696
+    sol = ch.distribute(lay.pack(np.zeros((mesh.n_nodes, 3)), phi))
+    with open(os.path.join(HERE, "golden", "hetero_3d_emod.json")) as f:
+        fx = json.load(f)
+    table = {tuple(np.round(np.asarray(c[:3]) * 64).astype(int)): c[3] for c in fx["cells"]}
+    centres = mesh.coords[mesh.cells].mean(axis=1)
+    emod = np.array([table[tuple(np.round(c * 64).astype(int))] for c in centres]) + 1.0  # cracks.cc:2209-2210
+    cell_mu = emod / (2.0 * (1 + nu))
+    cell_lambda = (2 * nu * cell_mu) / (1.0 - 2 * nu)
+    g = golden()["hetero_3d_1.mpirun-4"]["timesteps"][0]["residual0"]
+    return Case("hetero_3d", mesh, lay, prm, sol, sol.copy(), sol.copy(), cu, ch, g, cell_lambda, cell_mu)
+
+
+ALL_KATS = [kat_sneddon_3d, kat_sneddon_2d, kat_miehe_shear_1, kat_miehe_shear_2, kat_miehe_tension, kat_hetero_3d]
 
 
 def perturbed(case: Case, seed: int = 1234, u_amp: float = 1e-3, phi_amp: float = 0.2) -> Case:

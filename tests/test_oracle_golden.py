@@ -11,7 +11,8 @@ import oracle_api as O
 @pytest.mark.parametrize("make", cases.ALL_KATS, ids=lambda f: f.__name__)
 def test_step0_residual_matches_reference_golden(make):
     c = make()
-    r = O.assemble(c.mesh, c.layout, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, residual_only=True)
+    r = O.assemble(c.mesh, c.layout, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, residual_only=True,
+                   cell_lambda=c.cell_lambda, cell_mu=c.cell_mu)
     assert r.err == 0
     res = c.cu.set_zero(r.residual_pde)  # cracks.cc:2793
     norm = np.linalg.norm(res)
@@ -27,6 +28,11 @@ def test_kat_mesh_sizes_match_goldens():
     assert c.mesh.hn_nodes.size == 12
     c = cases.kat_sneddon_3d()
     assert c.layout.n_dofs == g["sneddon_3d_1.mpirun=4"]["timesteps"][0]["dofs"] == 5324
+    c = cases.kat_hetero_3d()
+    gh = g["hetero_3d_1.mpirun-4"]
+    assert c.mesh.n_cells == gh["timesteps"][0]["cells"] == 932
+    assert c.layout.n_dofs == gh["timesteps"][0]["dofs"] == 5288
+    assert c.mesh.min_cell_diameter() == pytest.approx(gh["params"]["h (min)"], rel=1e-5)
     c = cases.kat_miehe_shear_1()
     assert c.mesh.n_cells == 256 and c.layout.n_dofs == 891
     assert c.params.alpha_eps == pytest.approx(g["miehe_shear_1"]["params"]["eps"], rel=1e-5)
