@@ -145,7 +145,41 @@ def kat_hetero_3d() -> Case:
     return Case("hetero_3d", mesh, lay, prm, sol, sol.copy(), sol.copy(), cu, ch, g, cell_lambda, cell_mu)
 
 
-ALL_KATS = [kat_sneddon_3d, kat_sneddon_2d, kat_miehe_shear_1, kat_miehe_shear_2, kat_miehe_tension, kat_hetero_3d]
+def kat_threepoint() -> Case:
+    """tests/threepoint_1.prm -> tests/threepoint_1.mpirun=2.output (1.210342e+02): the reference's unstructured gmsh
+    mesh (``meshes/threepoint.msh``, fixture ``golden/threepoint_mesh.json``) -- general quadrilaterals, i.e. MappingQ1
+    geometry per quadrature point; point constraints of cracks.cc:2626-2676."""
+    with open(os.path.join(HERE, "golden", "threepoint_mesh.json")) as f:
+        fx = json.load(f)
+    mesh = M.Mesh(dim=2, coords=np.asarray(fx["coords"], float), cells=np.asarray(fx["cells"], np.int32))
+    # determine_mesh_dependent_parameters, cracks.cc:3839-3854: largest coarse diameter * 2^-(global+cycles+local)
+    h = mesh.cell_diameters().max() * 2.0 ** (-(0 + 1 + 0))
+    lay = M.DofLayout(mesh.n_nodes, 2, blocked=True)  # Use Direct Inner Solver = false
+    dt = 5.0e-3
+    prm = make_params(**{"lambda": 12.0e3}, mu=8.0e3, G_c=0.25, alpha_eps=2.0 * h, constant_k=1.0e-10,
+                      pressure=0.0, timestep=dt, time=dt, old_timestep=dt, old_old_timestep=dt,
+                      timestep_number=0, decompose_stress_rhs=1.0, decompose_stress_matrix=1.0)
+    x, y = mesh.coords[:, 0], mesh.coords[:, 1]
+    u = np.zeros((mesh.n_nodes, 2))
+    dd = []
+    for n in np.nonzero((np.abs(y) < 1e-10) & ((np.abs(x + 4.0) < 1e-10) | (np.abs(x - 4.0) < 1e-10)))[0]:
+        dd.append(lay.dof(n, 1))  # y displacement of both bottom corners
+        if abs(x[n] + 4.0) < 1e-10:
+            dd.append(lay.dof(n, 0))  # x displacement of the left one
+        dd.append(lay.dof(n, 2))  # phase field (inhomogeneity 1.0 = the initial value)
+    for n in np.nonzero((np.abs(x) < 1e-10) & (np.abs(y - 2.0) < 1e-10))[0]:
+        dd.append(lay.dof(n, 1))
+        u[n, 1] = -1.0 * dt  # constraints.set_inhomogeneity(idx, -1.0*time), cracks.cc:2668-2669
+    dd = np.asarray(sorted(int(d) for d in dd), np.int64)
+    sol = lay.pack(u, np.ones(mesh.n_nodes))  # InitialValuesNoCrack + set_initial_bc
+    ic = lay.pack(np.zeros_like(u), np.ones(mesh.n_nodes))
+    ch = M.hanging_constraints(mesh, lay)
+    cu = M.update_constraints(mesh, lay, dd)
+    g = golden()["threepoint_1.mpirun=2"]["timesteps"][0]["residual0"]
+    return Case("threepoint", mesh, lay, prm, sol, ic, ic.copy(), cu, ch, g)
+
+
+ALL_KATS = [kat_threepoint, kat_sneddon_3d, kat_sneddon_2d, kat_miehe_shear_1, kat_miehe_shear_2, kat_miehe_tension, kat_hetero_3d]
 
 
 def perturbed(case: Case, seed: int = 1234, u_amp: float = 1e-3, phi_amp: float = 0.2) -> Case:
