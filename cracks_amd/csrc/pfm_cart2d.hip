@@ -125,7 +125,34 @@ namespace pfm
               spE += sp[i][j] * E[i][j];
 
           // ---- Jacobian rows of vertex A, cracks.cc:2308-2389
-          if constexpr (FULL)
+          if constexpr (FULL && !SPLIT)
+            {
+              // unsplit law with the tensors written out (see k_assemble_general): the linearised stress of trial dof
+              // (b, d) against the test gradient is  lambda gN_b[d] gN_a[c] + mu (gN_b[c] gN_a[d] + delta_cd gN_b.gN_a),
+              // and sigma+_LinU : E = sigma+ : E_LinU = sum_k sigma+[d][k] gN_b[k]
+              const double gw = g * JxW;
+              const double LA[2] = {C.lam * gw * gNa[0], C.lam * gw * gNa[1]}, MA[2] = {C.mu * gw * gNa[0], C.mu * gw * gNa[1]};
+              const double mgw = C.mu * gw;
+              const double cpu = 2.0 * (1 - P.kappa) * pf * Na * JxW, cdiv = 2.0 * P.aB1 * P.p * pf * Na * JxW;
+              const double cpp = ((1 - P.kappa) * spE + P.Gc / P.eps) * Na * JxW, cgg = P.Gc * P.eps * JxW;
+              const double cdu = 2.0 * P.aB1 * P.p * divu * Na * JxW, cpen = P.penal_fac * Na * JxW;
+              const bool pen_on = !((pf - pfo) < 0.0); // shadowed variable, cracks.cc:2311-2315
+              static_for<4>([&](auto Bb) __attribute__((always_inline)) {
+                constexpr int b = decltype(Bb)::value;
+                const double t = gN[b][0] * gNa[0] + gN[b][1] * gNa[1];
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                  {
+                    const double sv = sp[d][0] * gN[b][0] + sp[d][1] * gN[b][1];
+                    out.pu(std::integral_constant<int, b>{}, d, cpu * sv - cdiv * gN[b][d]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                      out.uu(std::integral_constant<int, b>{}, c, d, LA[c] * gN[b][d] + MA[d] * gN[b][c] + (c == d ? mgw * t : 0.0));
+                  }
+                out.pp(std::integral_constant<int, b>{}, cpen * (pen_on ? N[b] : 0.0) + ((cpp - cdu) * N[b] + cgg * t));
+              });
+            }
+          if constexpr (FULL && SPLIT)
             {
               static_for<4>([&](auto Bb) __attribute__((always_inline)) {
                 constexpr int b = decltype(Bb)::value;
