@@ -123,12 +123,15 @@ namespace
               (void)hipEventDestroy(ev[i]);
           }
       }
-    } st;
+    } stages[16]; // one per device: the events belong to the device that was current when they were made
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Stage &st = stages[dev & 15];
     if (!st.tried)
       {
         st.tried = true;
-        st.ok = hipHostMalloc(&st.buf[0], CHUNK, hipHostMallocDefault) == hipSuccess &&
-                hipHostMalloc(&st.buf[1], CHUNK, hipHostMallocDefault) == hipSuccess &&
+        st.ok = hipHostMalloc(&st.buf[0], CHUNK, hipHostMallocPortable) == hipSuccess &&
+                hipHostMalloc(&st.buf[1], CHUNK, hipHostMallocPortable) == hipSuccess &&
                 hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming) == hipSuccess;
       }
