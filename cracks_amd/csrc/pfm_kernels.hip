@@ -193,12 +193,19 @@ namespace pfm
     }
 
     // ------------------------------------------------------------ the cell kernel
-    template <int dim, bool FULL, bool SPLIT, bool ATOMIC>
-    __global__ __launch_bounds__(256) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
+    // BH: the trial vertices b this launch integrates: -1 all of them; 0 / 1 the lower / upper half (3-D Jacobian: the 108
+    // row accumulators of a hex vertex need 374 registers -- one wave per SIMD plus accumulation-register moves; two
+    // launches with 54 accumulators each run at two waves per SIMD).  The residual and the constrained diagonals are
+    // written by the launch with BH < 0 or BH == 1 (the upper half has the registers to spare).
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1>
+    __global__ __launch_bounds__(256, (dim == 3 && FULL) ? 2 : 1) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
                                                               double *res_pde, double *res_tot,
                                                               int residual_only, long long class_begin, long long class_size)
     {
       constexpr int nv = 1 << dim, nc = dim + 1, nq = (dim == 2 ? 9 : 27), dpc = nv * nc;
+      constexpr int B0 = BH < 0 ? 0 : BH * (nv / 2), NBL = BH < 0 ? nv : nv / 2; // trial vertices [B0, B0 + NBL)
+      static_assert(BH < 0 || (FULL && !SPLIT), "the split of the trial vertices exists for the unsplit Jacobian only");
+      constexpr bool RESID = BH != 0; // this launch also integrates the residual and the own diagonal
       constexpr int CPB = 256 / nv; // cells per workgroup
       __shared__ double s_x[dim][nv][CPB];
       __shared__ double s_u[dim][nv][CPB];
@@ -263,16 +270,20 @@ namespace pfm
 
       // accumulators: rows j = (a, c)
       double R[nc];
-      double Kuu[FULL ? nv : 1][dim][dim]; // [b][c][d]   trial (b,d) -> row (a,c)
-      double Kpu[FULL ? nv : 1][dim];      // [b][d]      trial (b,d) -> row (a,phi)
-      double Kpp[FULL ? nv : 1];           // [b]         trial (b,phi) -> row (a,phi)
+      double Kuu[FULL ? NBL : 1][dim][dim]; // [b - B0][c][d]   trial (b,d) -> row (a,c)
+      double Kpu[FULL ? NBL : 1][dim];      // [b - B0][d]      trial (b,d) -> row (a,phi)
+      double Kpp[FULL ? NBL : 1];           // [b - B0]         trial (b,phi) -> row (a,phi)
+      double Kd[nc];                        // own diagonal K[(a,c),(a,c)] (needed by every launch for the mean |diagonal|)
+#pragma unroll
+      for (int c = 0; c < nc; ++c)
+        Kd[c] = 0.0;
 #pragma unroll
       for (int c = 0; c < nc; ++c)
         R[c] = 0.0;
       if constexpr (FULL)
         {
 #pragma unroll
-          for (int b = 0; b < nv; ++b)
+          for (int b = 0; b < NBL; ++b)
             {
               Kpp[b] = 0.0;
 #pragma unroll
@@ -490,8 +501,9 @@ namespace pfm
               const bool pen_on = !((pf - pfo) < 0.0); // shadowed variable, cracks.cc:2311-2315
               const double cpen = penal_fac * Na * JxW;
 #pragma unroll
-              for (int b = 0; b < nv; ++b)
+              for (int bb = 0; bb < NBL; ++bb)
                 {
+                  const int b = B0 + bb;
                   const double Nb = refN<dim>(q, b);
                   double t = 0.0;
 #pragma unroll
@@ -504,13 +516,26 @@ namespace pfm
 #pragma unroll
                       for (int k = 0; k < dim; ++k)
                         sv += sp[d][k] * gN[b][k];
-                      Kpu[b][d] += cpu * sv - cdiv * gN[b][d];
+                      Kpu[bb][d] += cpu * sv - cdiv * gN[b][d];
 #pragma unroll
                       for (int c = 0; c < dim; ++c)
-                        Kuu[b][c][d] += LA[c] * gN[b][d] + MA[d] * gN[b][c] + (c == d ? mgw * t : 0.0);
+                        Kuu[bb][c][d] += LA[c] * gN[b][d] + MA[d] * gN[b][c] + (c == d ? mgw * t : 0.0);
                     }
-                  Kpp[b] += cpen * (pen_on ? Nb : 0.0);
-                  Kpp[b] += (cpp - cdu) * Nb + cgg * t;
+                  Kpp[bb] += cpen * (pen_on ? Nb : 0.0);
+                  Kpp[bb] += (cpp - cdu) * Nb + cgg * t;
+                }
+              if constexpr (BH == 1)
+                {
+                  // the lane's own diagonal entries (trial vertex a, which half of the launches does not integrate)
+                  double taa = 0.0;
+#pragma unroll
+                  for (int k = 0; k < dim; ++k)
+                    taa += gNa[k] * gNa[k];
+#pragma unroll
+                  for (int c = 0; c < dim; ++c)
+                    Kd[c] += LA[c] * gNa[c] + MA[c] * gNa[c] + mgw * taa;
+                  Kd[dim] += cpen * (pen_on ? Na : 0.0);
+                  Kd[dim] += (cpp - cdu) * Na + cgg * taa;
                 }
             }
           if constexpr (FULL && SPLIT)
@@ -600,6 +625,8 @@ namespace pfm
                 }
             }
 
+          if constexpr (RESID)
+            {
           // ---- residual rows of vertex a, cracks.cc:2393-2432
 #pragma unroll
           for (int c = 0; c < dim; ++c)
@@ -623,6 +650,7 @@ namespace pfm
                        2.0 * aB1 * p * pf * divu * Na) *
                       JxW;
           }
+            }
         } // q
 
       if (!ortho_ok)
@@ -637,7 +665,7 @@ namespace pfm
           const bool owned = A < v.n_owned; // rows of ghost nodes belong to another rank
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           const unsigned fA = v.node_flags[A];
-          if (owned)
+          if (owned && RESID)
             {
             double *pr[nc], *pt[nc], o_r[nc], o_t[nc];
 #pragma unroll
@@ -675,18 +703,25 @@ namespace pfm
                 return d < dim ? vals.b[2] + (dim * off + (long long)s_ * dim + d) : vals.b[3] + (off + s_);
               };
               double diag[nc];
-#pragma unroll
-              for (int b = 0; b < nv; ++b)
+              if constexpr (BH >= 0)
                 {
+#pragma unroll
+                  for (int c = 0; c < nc; ++c)
+                    diag[c] = fabs(Kd[c]); // BH == 0: zero, unused
+                }
+#pragma unroll
+              for (int bb = 0; bb < NBL; ++bb)
+                {
+                  const int b = B0 + bb;
                   const int B = v.conn[(long long)b * v.n_cells + cell];
                   const unsigned fQ = v.node_flags[B];
                   const int slot = (int)cs[a * nv + b];
-                  if (b == a)
+                  if (BH < 0 && b == a)
                     {
 #pragma unroll
                       for (int c = 0; c < dim; ++c)
-                        diag[c] = fabs(Kuu[b][c][c]);
-                      diag[dim] = fabs(Kpp[b]);
+                        diag[c] = fabs(Kuu[bb][c][c]);
+                      diag[dim] = fabs(Kpp[bb]);
                     }
                   if (!owned)
                     continue;
@@ -699,18 +734,18 @@ namespace pfm
                     for (int d = 0; d < dim; ++d)
                       {
                         pe[c * dim + d] = entry(c, slot, d);
-                        ke[c * dim + d] = Kuu[b][c][d];
+                        ke[c * dim + d] = Kuu[bb][c][d];
                         on[c * dim + d] = !((fA >> c) & 1u) && !((fQ >> d) & 1u);
                       }
 #pragma unroll
                   for (int d = 0; d < dim; ++d)
                     {
                       pe[dim * dim + d] = entry(dim, slot, d);
-                      ke[dim * dim + d] = Kpu[b][d];
+                      ke[dim * dim + d] = Kpu[bb][d];
                       on[dim * dim + d] = !((fA >> dim) & 1u) && !((fQ >> d) & 1u);
                     }
                   pe[NE - 1] = entry(dim, slot, dim);
-                  ke[NE - 1] = Kpp[b];
+                  ke[NE - 1] = Kpp[bb];
                   on[NE - 1] = !((fA >> dim) & 1u) && !((fQ >> dim) & 1u);
 #pragma unroll
                   for (int e = 0; e < NE; ++e)
@@ -730,7 +765,7 @@ namespace pfm
               for (int m = 1; m < nv; m <<= 1)
                 dsum += __shfl_xor(dsum, m, nv);
               const double avg = dsum / (double)dpc;
-              if (fA && owned)
+              if (fA && owned && RESID)
                 {
                   const int slot = (int)cs[a * nv + a];
 #pragma unroll
@@ -751,7 +786,7 @@ namespace pfm
 
       // residual
       const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
-      for (long long r = rb; r < re; ++r)
+      for (long long r = rb; r < (RESID ? re : rb); ++r)
         {
           const int P = kA < 0 ? A : v.hn_parents[r];
           const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
@@ -774,17 +809,24 @@ namespace pfm
         {
           const unsigned fA = v.node_flags[A];
           double diag[nc];
+          if constexpr (BH >= 0)
+            {
+#pragma unroll
+              for (int c = 0; c < nc; ++c)
+                diag[c] = fabs(Kd[c]);
+            }
           // matrix rows of vertex a
 #pragma unroll
-          for (int b = 0; b < nv; ++b)
+          for (int bb = 0; bb < NBL; ++bb)
             {
+              const int b = B0 + bb;
               const int B = v.conn[(long long)b * v.n_cells + cell];
-              if (b == a)
+              if (BH < 0 && b == a)
                 {
 #pragma unroll
                   for (int c = 0; c < dim; ++c)
-                    diag[c] = fabs(Kuu[b][c][c]);
-                  diag[dim] = fabs(Kpp[b]);
+                    diag[c] = fabs(Kuu[bb][c][c]);
+                  diag[dim] = fabs(Kpp[bb]);
                 }
               const int kB = v.hn_index ? v.hn_index[B] : -1;
               const long long cb = kB < 0 ? 0 : v.hn_ptr[kB];
@@ -810,16 +852,16 @@ namespace pfm
 #pragma unroll
                           for (int d = 0; d < dim; ++d)
                             if (!((fQ >> d) & 1u))
-                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, c, slot, d), w * Kuu[b][c][d]);
+                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, c, slot, d), w * Kuu[bb][c][d]);
                         }
                       if (!((fP >> dim) & 1u))
                         {
 #pragma unroll
                           for (int d = 0; d < dim; ++d)
                             if (!((fQ >> d) & 1u))
-                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, d), w * Kpu[b][d]);
+                              add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, d), w * Kpu[bb][d]);
                           if (!((fQ >> dim) & 1u))
-                            add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, dim), w * Kpp[b]);
+                            add_to<ATOMIC>(val_ptr<dim>(v, vals, P, dim, slot, dim), w * Kpp[bb]);
                         }
                     }
                 }
@@ -834,7 +876,7 @@ namespace pfm
           for (int m = 1; m < nv; m <<= 1)
             dsum += __shfl_xor(dsum, m, nv);
           const double avg = dsum / (double)dpc;
-          if (A < v.n_owned && (kA >= 0 || fA))
+          if (RESID && A < v.n_owned && (kA >= 0 || fA))
             {
               const int slot = (int)cs[a * nv + a];
 #pragma unroll
@@ -1174,7 +1216,23 @@ namespace pfm
             if (residual_only)
               PFM_LAUNCH(3, false, false);
             else
-              PFM_LAUNCH(3, true, false);
+              {
+                // two launches per class, each with half of the trial vertices (see the kernel's BH parameter)
+                if (atomic)
+                  {
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 0>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 1>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                  }
+                else
+                  {
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 0>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 1>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                  }
+              }
           }
 #undef PFM_LAUNCH
       }
