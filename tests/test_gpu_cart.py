@@ -277,23 +277,30 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
         f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
         "import test_gpu_cart as T\n"
         "from gpu_util import make_context\n"
-        "out = []\n"
+        "out, rhs = [], []\n"
         "for blocked in (True, False):\n"
         "    for n in ((19, 9, 40), (6, 6, 6)):\n"
         "        c = T.box_case(3, n, -10.0, 10.0, blocked)\n"
         "        ctx = make_context(c)\n"
         "        values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)\n"
         "        out.append(values[0])\n"
-        "np.save(sys.argv[1], np.concatenate(out))\n")
-    res = {}
-    for tag, env in (("uu3", {}), ("uu4", {"PFM_UU4": "1"})):
-        f = tmp_path / f"{tag}.npy"
-        e = dict(os.environ, **env)
-        e.pop("PFM_UU4", None) if not env else None
-        subprocess.run([sys.executable, str(script), str(f)], check=True, env=e, timeout=600)
-        res[tag] = np.load(f)
-    assert res["uu3"].shape == res["uu4"].shape
-    assert np.array_equal(res["uu3"], res["uu4"])
+        "        rhs.append(res)\n"
+        "np.save(sys.argv[1], np.concatenate(out))\n"
+        "np.save(sys.argv[2], np.concatenate(rhs))\n")
+    # default: k_cart_uu3 / k_cart_phi4 also write the residual (from their matrix rows); PFM_RES_KERNEL=1: the quadrature
+    # residual kernel; PFM_UU4=1 (+ PFM_RES_KERNEL=1, the z-marching kernel has no residual variant): k_cart_uu4
+    val, rhs = {}, {}
+    for tag, env in (("rows", {}), ("uu3", {"PFM_RES_KERNEL": "1"}), ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"})):
+        f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
+        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_RES_KERNEL")}
+        e.update(env)
+        subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
+        val[tag], rhs[tag] = np.load(f), np.load(g)
+    assert val["uu3"].shape == val["uu4"].shape == val["rows"].shape
+    assert np.array_equal(val["uu3"], val["uu4"]) and np.array_equal(rhs["uu3"], rhs["uu4"])
+    # the residual variant of the (u,u) kernel writes the same matrix bits; its residual equals the quadrature one to round-off
+    assert np.array_equal(val["rows"], val["uu3"])
+    assert rhs["rows"].shape == rhs["uu3"].shape and linf_scaled(rhs["rows"], rhs["uu3"]) < TOL
 
 
 # ---- 2-D row-owner Jacobian (pfm_cart2d.hip): BASELINE config 2 with the matrix, tests/sneddon_2d_1.prm on a uniform mesh
