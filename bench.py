@@ -215,6 +215,19 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
                       f"insertion overhead the real reference pays"}
 
 
+def self_launch_command(n_gpus: int, argv):
+    """argv of `python -m torch.distributed.run ... bench.py <argv>` for a single-node run with one rank per GPU."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    # torch.distributed.run's own parser trips over the abbreviation --n: pass the long form on
+    fwd = ["--cells" if a == "--n" else ("--cells=" + a[4:] if a.startswith("--n=") else a) for a in argv]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + fwd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,9 +254,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: become the launcher of N ranks of this very script (one process per GPU,
+        # rendezvous on 127.0.0.1 at a free port); rank 0 of the children prints the JSON line
+        os.execv(sys.executable, self_launch_command(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     # PFM_BENCH_SMOKE_GLOO=1: all ranks on cuda:0, ghost import staged through the host over gloo -- exercises the
     # multi-process flow on a single-GPU box; never a measurement
     smoke_gloo = os.environ.get("PFM_BENCH_SMOKE_GLOO") == "1"

@@ -14,7 +14,8 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h> // types and constants only: the entry points are bound with dlopen (rccl() below)
+#include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -1259,6 +1260,8 @@ extern "C"
           (void)hipFree(*q);
           *q = nullptr;
         }
+    c->device_bytes -= c->halo_buf_bytes;
+    c->halo_buf_bytes = 0;
     c->n_send_all = n_peers ? send_ptr[n_peers] - send_ptr[0] : 0;
     c->n_recv_all = n_peers ? recv_ptr[n_peers] - recv_ptr[0] : 0;
     if (n_peers > 0)
@@ -1326,12 +1329,96 @@ extern "C"
   // ---- ghost import over RCCL inside the library (include/pfm_assemble.h)
   static_assert(sizeof(ncclUniqueId) == PFM_COMM_ID_BYTES, "PFM_COMM_ID_BYTES must match ncclUniqueId");
 
+  // RCCL is bound at run time: the library loads (and single-rank runs work) on hosts without librccl, and in a
+  // process that already carries a copy (torch bundles one under the same SONAME) the calls go to THAT copy instead of
+  // a second one with its own state.  The run-time version is checked against the header this file was compiled with
+  // (same major: ncclUniqueId / ncclComm_t / the send-receive signatures are stable within a major).
+  extern "C++"
+  {
+  namespace
+  {
+    struct RcclApi
+    {
+      ncclResult_t (*GetVersion)(int *) = nullptr;
+      ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+      ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+      ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+      ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+      ncclResult_t (*GroupStart)() = nullptr;
+      ncclResult_t (*GroupEnd)() = nullptr;
+      ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+      ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+      const char *(*GetErrorString)(ncclResult_t) = nullptr;
+      bool ok = false;
+      std::string why;
+    };
+
+    const RcclApi &rccl()
+    {
+      static const RcclApi api = [] {
+        RcclApi a;
+        void *h = nullptr;
+        // already in the process (torch's bundled copy, or the host application's)?
+        for (const char *name : {"librccl.so.1", "librccl.so"})
+          if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL)))
+            break;
+        if (!h)
+          {
+            const char *rocm = getenv("ROCM_PATH");
+            const std::string cand[] = {"librccl.so.1", "librccl.so", std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so.1",
+                                        std::string(rocm ? rocm : "/opt/rocm") + "/lib/librccl.so"};
+            for (const std::string &name : cand)
+              if ((h = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL)))
+                break;
+          }
+        if (!h)
+          {
+            a.why = "librccl.so not found (dlopen)";
+            return a;
+          }
+        bool all = true;
+        auto sym = [&](auto &fp, const char *name) {
+          fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(h, name));
+          all = all && fp != nullptr;
+        };
+        sym(a.GetVersion, "ncclGetVersion");
+        sym(a.GetUniqueId, "ncclGetUniqueId");
+        sym(a.CommInitRank, "ncclCommInitRank");
+        sym(a.CommDestroy, "ncclCommDestroy");
+        sym(a.CommAbort, "ncclCommAbort");
+        sym(a.GroupStart, "ncclGroupStart");
+        sym(a.GroupEnd, "ncclGroupEnd");
+        sym(a.Send, "ncclSend");
+        sym(a.Recv, "ncclRecv");
+        sym(a.GetErrorString, "ncclGetErrorString");
+        if (!all)
+          {
+            a.why = "librccl.so lacks a required symbol";
+            return a;
+          }
+        int ver = 0;
+        if (a.GetVersion(&ver) != ncclSuccess || ver / 10000 != NCCL_MAJOR)
+          {
+            a.why = "RCCL run-time version " + std::to_string(ver) + " does not match the compiled-in major " + std::to_string(NCCL_MAJOR);
+            return a;
+          }
+        a.ok = true;
+        return a;
+      }();
+      return api;
+    }
+  } // namespace
+  } // extern "C++"
+
   int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES])
   {
     if (!id)
       return PFM_ERR_BAD_ARG;
+    const RcclApi &R = rccl();
+    if (!R.ok)
+      return PFM_ERR_COMM;
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess)
+    if (R.GetUniqueId(&u) != ncclSuccess)
       return PFM_ERR_COMM;
     memcpy(id, &u, sizeof(u));
     return PFM_OK;
@@ -1341,12 +1428,15 @@ extern "C"
   {
     if (!comm || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks)
       return PFM_ERR_BAD_ARG;
+    const RcclApi &R = rccl();
+    if (!R.ok)
+      return PFM_ERR_COMM;
     if (hipSetDevice(device) != hipSuccess)
       return PFM_ERR_HIP;
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclComm_t cm = nullptr;
-    if (ncclCommInitRank(&cm, n_ranks, u, rank) != ncclSuccess)
+    if (R.CommInitRank(&cm, n_ranks, u, rank) != ncclSuccess)
       return PFM_ERR_COMM;
     *comm = cm;
     return PFM_OK;
@@ -1356,7 +1446,80 @@ extern "C"
   {
     if (!comm)
       return PFM_OK;
-    return ncclCommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? PFM_OK : PFM_ERR_COMM;
+    const RcclApi &R = rccl();
+    if (!R.ok)
+      return PFM_ERR_COMM;
+    return R.CommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? PFM_OK : PFM_ERR_COMM;
+  }
+
+  // both staging buffers or none: a half-allocated pair must not survive a failed call
+  static int ensure_halo_buffers(pfm_ctx *c)
+  {
+    if (c->d_halo_send && c->d_halo_recv)
+      return PFM_OK;
+    const int rec = PFM_HALO_DOUBLES_PER_NODE(c->v.dim);
+    if (c->d_halo_send)
+      (void)hipFree(c->d_halo_send);
+    if (c->d_halo_recv)
+      (void)hipFree(c->d_halo_recv);
+    c->d_halo_send = c->d_halo_recv = nullptr;
+    double *snd = nullptr, *rcv = nullptr;
+    hipError_t e = hipMalloc((void **)&snd, std::max<size_t>(8, sizeof(double) * rec * c->n_send_all));
+    if (e == hipSuccess)
+      e = hipMalloc((void **)&rcv, std::max<size_t>(8, sizeof(double) * rec * c->n_recv_all));
+    if (e != hipSuccess)
+      {
+        if (snd)
+          (void)hipFree(snd);
+        return hipfail(c, e, "hipMalloc halo buffers");
+      }
+    c->d_halo_send = snd;
+    c->d_halo_recv = rcv;
+    c->halo_buf_bytes = (int64_t)sizeof(double) * rec * (c->n_send_all + c->n_recv_all);
+    c->device_bytes += c->halo_buf_bytes;
+    return PFM_OK;
+  }
+
+  // pack -> grouped send/receive -> unpack, on `st` (the context's stream, or its side stream for the overlapped form)
+  static int halo_exchange_on(pfm_ctx *c, void *comm, const int *peer_ranks, hipStream_t st)
+  {
+    const RcclApi &R = rccl();
+    if (!R.ok)
+      return fail(c, PFM_ERR_COMM, "RCCL unavailable: " + R.why);
+    int rc = ensure_halo_buffers(c);
+    if (rc)
+      return rc;
+    const int rec = PFM_HALO_DOUBLES_PER_NODE(c->v.dim);
+    rc = launch_halo_all(c->v, c->d_send_all, c->d_send_ptr, (int)c->peers.size(), c->n_send_all, c->d_halo_send, 0, st);
+    if (rc)
+      return fail(c, rc, "halo pack launch failed");
+    ncclComm_t cm = static_cast<ncclComm_t>(comm);
+    ncclResult_t r = R.GroupStart();
+    int64_t so = 0, ro = 0;
+    for (size_t k = 0; k < c->peers.size() && r == ncclSuccess; ++k)
+      {
+        const HaloPeer &p = c->peers[k];
+        if (p.n_recv)
+          r = R.Recv(c->d_halo_recv + rec * ro, (size_t)(rec * p.n_recv), ncclDouble, peer_ranks[k], cm, st);
+        if (p.n_send && r == ncclSuccess)
+          r = R.Send(c->d_halo_send + rec * so, (size_t)(rec * p.n_send), ncclDouble, peer_ranks[k], cm, st);
+        so += p.n_send;
+        ro += p.n_recv;
+      }
+    const ncclResult_t r2 = R.GroupEnd();
+    if (r == ncclSuccess)
+      r = r2;
+    if (r != ncclSuccess)
+      {
+        // work may already be enqueued on the peers: there is no safe fall-back from here -- abort the
+        // communicator so that no rank waits for a message that will never come, and report
+        (void)R.CommAbort(cm);
+        return fail(c, PFM_ERR_COMM, std::string("RCCL (communicator aborted): ") + R.GetErrorString(r));
+      }
+    rc = launch_halo_all(c->v, c->d_recv_all, c->d_recv_ptr, (int)c->peers.size(), c->n_recv_all, c->d_halo_recv, 1, st);
+    if (rc)
+      return fail(c, rc, "halo unpack launch failed");
+    return PFM_OK;
   }
 
   int pfm_halo_exchange(pfm_ctx *c, void *comm, const int *peer_ranks)
@@ -1366,41 +1529,7 @@ extern "C"
     if (c->peers.empty())
       return PFM_OK;
     (void)hipSetDevice(c->device);
-    const int rec = PFM_HALO_DOUBLES_PER_NODE(c->v.dim);
-    if (!c->d_halo_send)
-      {
-        hipError_t e = hipMalloc((void **)&c->d_halo_send, std::max<size_t>(8, sizeof(double) * rec * c->n_send_all));
-        if (e == hipSuccess)
-          e = hipMalloc((void **)&c->d_halo_recv, std::max<size_t>(8, sizeof(double) * rec * c->n_recv_all));
-        if (e != hipSuccess)
-          return hipfail(c, e, "hipMalloc halo buffers");
-        c->device_bytes += (int64_t)sizeof(double) * rec * (c->n_send_all + c->n_recv_all);
-      }
-    int rc = pfm_halo_pack_all(c, c->d_halo_send);
-    if (rc)
-      return fail(c, rc, "halo pack launch failed");
-    ncclComm_t cm = static_cast<ncclComm_t>(comm);
-    ncclResult_t r = ncclGroupStart();
-    int64_t so = 0, ro = 0;
-    for (size_t k = 0; k < c->peers.size() && r == ncclSuccess; ++k)
-      {
-        const HaloPeer &p = c->peers[k];
-        if (p.n_recv)
-          r = ncclRecv(c->d_halo_recv + rec * ro, (size_t)(rec * p.n_recv), ncclDouble, peer_ranks[k], cm, c->stream);
-        if (p.n_send && r == ncclSuccess)
-          r = ncclSend(c->d_halo_send + rec * so, (size_t)(rec * p.n_send), ncclDouble, peer_ranks[k], cm, c->stream);
-        so += p.n_send;
-        ro += p.n_recv;
-      }
-    const ncclResult_t r2 = ncclGroupEnd();
-    if (r == ncclSuccess)
-      r = r2;
-    if (r != ncclSuccess)
-      return fail(c, PFM_ERR_COMM, std::string("RCCL: ") + ncclGetErrorString(r));
-    rc = pfm_halo_unpack_all(c, c->d_halo_recv);
-    if (rc)
-      return fail(c, rc, "halo unpack launch failed");
-    return PFM_OK;
+    return halo_exchange_on(c, comm, peer_ranks, c->stream);
   }
 
   int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values,

@@ -157,6 +157,7 @@ struct pfm_ctx
   long long *d_send_ptr = nullptr, *d_recv_ptr = nullptr;
   int64_t n_send_all = 0, n_recv_all = 0;
   double *d_halo_send = nullptr, *d_halo_recv = nullptr; // message buffers of pfm_halo_exchange
+  int64_t halo_buf_bytes = 0;                            // their share of device_bytes
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
   uint8_t *d_row_perm = nullptr; // CartView::row_perm storage (in allocs)
   pfm::LatticeHost lat;          // host lattice tables (cartesian path only)

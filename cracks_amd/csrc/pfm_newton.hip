@@ -477,6 +477,7 @@ extern "C"
             if (hipMalloc((void **)&c->d_func_mat, 2 * sizeof(double) * (size_t)c->v.n_cells) != hipSuccess)
               return fail(c, PFM_ERR_NOMEM, "hipMalloc material override");
             c->allocs.push_back(c->d_func_mat);
+            c->device_bytes += (int64_t)(2 * sizeof(double) * (size_t)c->v.n_cells);
           }
         d_lam = c->d_func_mat;
         d_mu = c->d_func_mat + c->v.n_cells;

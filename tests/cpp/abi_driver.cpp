@@ -7,6 +7,12 @@
 // plane x = 0 (a self-exchange: the only peer is this rank).  Context B = the same mesh with every node owned and the
 // same values written directly.  The owned rows of A (residual + every matrix block) must equal those of B.
 //
+// With `--ranks R` (R > 1, one GPU per rank; tests/test_cpp_driver.py runs R = 2 wherever the box has two GPUs) the
+// process forks R ranks BEFORE any HIP call; rank 0 makes the RCCL id and hands it to the others through pipes (the
+// stand-in for the host application's MPI_Bcast).  Every rank holds the same kind of box with its own field values, the
+// ghost plane of rank r receives the plane x = 0 of rank (r + 1) % R: a ring of real ncclSend / ncclRecv pairs over
+// xGMI.  The reference values of the neighbour are a closed-form function of (rank, node), so each rank checks locally.
+//
 // Build (tests/test_cpp_driver.py does it): hipcc -std=c++17 abi_driver.cpp -I../../include -L<libdir> -lpfm_hip
 #include <hip/hip_runtime_api.h>
 
@@ -15,7 +21,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "pfm_assemble.h"
 
@@ -48,9 +58,8 @@ static double noise(uint64_t i, uint64_t salt)
   return (double)(x >> 11) / (double)(1ull << 53);
 }
 
-int main(int argc, char **argv)
+static int run_rank(int nx, int ny, int nz, int rank, int n_ranks, int id_rd, const std::vector<int> &id_wr)
 {
-  const int nx = argc > 1 ? atoi(argv[1]) : 17, ny = argc > 2 ? atoi(argv[2]) : 9, nz = argc > 3 ? atoi(argv[3]) : 11;
   const int dim = 3, NX = nx + 1, NY = ny + 1, NZ = nz + 1;
   const int N = NX * NY * NZ, NO = (NX - 1) * NY * NZ, NG = N - NO;
   // local numbering: owned nodes (i < NX-1) lexicographic first, then the ghost plane i = NX-1
@@ -87,8 +96,9 @@ int main(int argc, char **argv)
     for (int j = 0; j < NY; ++j)
       for (int i = 0; i < NX; ++i)
         {
-          const int src = (i == NX - 1) ? 0 : i; // periodic image
-          const uint64_t g = src + (uint64_t)NX * (j + (uint64_t)NY * k);
+          const int src = (i == NX - 1) ? 0 : i; // image of the plane x = 0 of rank (rank + 1) % n_ranks
+          const uint64_t g = src + (uint64_t)NX * (j + (uint64_t)NY * k) +
+                             (uint64_t)1000003 * (uint64_t)((i == NX - 1) ? (rank + 1) % n_ranks : rank);
           const int n = id_of[i + NX * (j + NY * k)];
           const bool bnd = j == 0 || j == NY - 1 || k == 0 || k == NZ - 1;
           for (int d = 0; d < 3; ++d)
@@ -131,14 +141,18 @@ int main(int argc, char **argv)
   md.box_cells[1] = ny;
   md.box_cells[2] = nz;
 
-  REQUIRE(hipSetDevice(0) == hipSuccess, "no HIP device");
+  int n_dev = 0;
+  REQUIRE(hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0, "no HIP device");
+  const int device = rank % n_dev;
+  REQUIRE(n_ranks == 1 || n_dev >= n_ranks, "%d ranks need %d GPUs, %d visible", n_ranks, n_ranks, n_dev);
+  REQUIRE(hipSetDevice(device) == hipSuccess, "hipSetDevice(%d)", device);
   hipStream_t stream;
   REQUIRE(hipStreamCreate(&stream) == hipSuccess, "stream");
 
   // ---------------- context A: owned + ghost plane, ghost values over RCCL
   pfm_ctx *A = nullptr;
   md.n_owned_nodes = NO;
-  PFM(pfm_ctx_create(&A, &md, 0), A);
+  PFM(pfm_ctx_create(&A, &md, device), A);
   PFM(pfm_ctx_set_stream(A, stream), A);
   PFM(pfm_set_params(A, &prm), A);
   PFM(pfm_set_constraints(A, flags.data()), A);
@@ -158,7 +172,8 @@ int main(int argc, char **argv)
         REQUIRE(std::is_sorted(ci.begin() + rpA[b][r], ci.begin() + rpA[b][r + 1]), "block %d row %lld: columns not ascending", b, (long long)r);
       PFM(pfm_pattern_bind_i32(A, b, rp32.data(), ci.data()), A);
     }
-  // halo lists: one peer (this rank): send = owned plane i = 0, recv = ghost plane
+  // halo lists: the owned plane i = 0 goes to rank - 1, the ghost plane comes from rank + 1 (the same rank for
+  // n_ranks <= 2: one peer with both lists; otherwise a send-only and a receive-only peer)
   std::vector<int32_t> send_nodes, recv_nodes;
   for (int k = 0; k < NZ; ++k)
     for (int j = 0; j < NY; ++j)
@@ -166,14 +181,29 @@ int main(int argc, char **argv)
         send_nodes.push_back(id_of[0 + NX * (j + NY * k)]);
         recv_nodes.push_back(id_of[(NX - 1) + NX * (j + NY * k)]);
       }
-  const int64_t sp[2] = {0, (int64_t)send_nodes.size()}, rp[2] = {0, (int64_t)recv_nodes.size()};
   REQUIRE((int)recv_nodes.size() == NG, "ghost count");
-  PFM(pfm_halo_register(A, 1, sp, send_nodes.data(), rp, recv_nodes.data()), A);
+  const int to = (rank + n_ranks - 1) % n_ranks, from = (rank + 1) % n_ranks;
+  const int64_t ns = (int64_t)send_nodes.size(), nr = (int64_t)recv_nodes.size();
+  int n_peers = 1;
+  int peer_ranks[2] = {to, from};
+  int64_t sp[3] = {0, ns, ns}, rp[3] = {0, nr, nr};
+  if (to != from)
+    {
+      n_peers = 2;
+      rp[1] = 0; // peer 0 = `to`: send only; peer 1 = `from`: receive only
+    }
+  PFM(pfm_halo_register(A, n_peers, sp, send_nodes.data(), rp, recv_nodes.data()), A);
   uint8_t uid[PFM_COMM_ID_BYTES];
-  PFM(pfm_comm_unique_id(uid), A);
+  if (rank == 0)
+    {
+      PFM(pfm_comm_unique_id(uid), A);
+      for (int fd : id_wr)
+        REQUIRE(write(fd, uid, sizeof(uid)) == (ssize_t)sizeof(uid), "id pipe (write)");
+    }
+  else
+    REQUIRE(read(id_rd, uid, sizeof(uid)) == (ssize_t)sizeof(uid), "id pipe (read)");
   void *comm = nullptr;
-  PFM(pfm_comm_create(&comm, uid, 1, 0, 0), A);
-  const int peer_ranks[1] = {0};
+  PFM(pfm_comm_create(&comm, uid, n_ranks, rank, device), A);
 
   const std::vector<double> solA = pack(NO, PHI, true), oldA = pack(NO, PO, false), ooA = pack(NO, POO, false);
   double *d_res = nullptr, *d_tot = nullptr, *d_val[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -206,7 +236,7 @@ int main(int argc, char **argv)
   // ---------------- context B: every node owned, values given directly; synchronous host-pointer call
   pfm_ctx *B = nullptr;
   md.n_owned_nodes = N;
-  PFM(pfm_ctx_create(&B, &md, 0), B);
+  PFM(pfm_ctx_create(&B, &md, device), B);
   PFM(pfm_set_params(B, &prm), B);
   PFM(pfm_set_constraints(B, flags.data()), B);
   const std::vector<double> solB = pack(N, PHI, true), oldB = pack(N, PO, false), ooB = pack(N, POO, false);
@@ -248,9 +278,10 @@ int main(int argc, char **argv)
         cmp(valA[b][e], valB[b][e]);
     }
   const double rel = err / scale;
-  printf("abi_driver: box %dx%dx%d, %d owned + %d ghost nodes, kernel path %d, 1-rank RCCL self-exchange of %zu bytes: "
+  printf("abi_driver: rank %d of %d on GPU %d, box %dx%dx%d, %d owned + %d ghost nodes, kernel path %d, RCCL %s of %zu bytes: "
          "max |A - B| / max(1,|B|) = %.3e\n",
-         nx, ny, nz, NO, NG, path, send_nodes.size() * PFM_HALO_DOUBLES_PER_NODE(3) * sizeof(double), rel);
+         rank, n_ranks, device, nx, ny, nz, NO, NG, path, n_ranks == 1 ? "self-exchange" : "ring exchange",
+         send_nodes.size() * PFM_HALO_DOUBLES_PER_NODE(3) * sizeof(double), rel);
   REQUIRE(rel < 1e-12, "owned rows differ between the RCCL-fed and the directly fed context");
   double nrm = 0;
   for (double x : resA)
@@ -259,6 +290,60 @@ int main(int argc, char **argv)
   PFM(pfm_comm_destroy(comm), A);
   PFM(pfm_ctx_destroy(A), (pfm_ctx *)nullptr);
   PFM(pfm_ctx_destroy(B), (pfm_ctx *)nullptr);
-  printf("abi_driver: OK\n");
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  int dims[3] = {17, 9, 11}, nd = 0, n_ranks = 1;
+  for (int a = 1; a < argc; ++a)
+    {
+      if (!strcmp(argv[a], "--ranks") && a + 1 < argc)
+        n_ranks = atoi(argv[++a]);
+      else if (nd < 3)
+        dims[nd++] = atoi(argv[a]);
+    }
+  if (n_ranks < 1 || n_ranks > 64)
+    return 2;
+  if (n_ranks == 1)
+    {
+      const int rc = run_rank(dims[0], dims[1], dims[2], 0, 1, -1, {});
+      if (rc == 0)
+        printf("abi_driver: OK\n");
+      return rc;
+    }
+  // one process per rank, forked before the first HIP call of this process; the RCCL id travels through pipes
+  std::vector<int> rd(n_ranks, -1), wr;
+  for (int r = 1; r < n_ranks; ++r)
+    {
+      int fd[2];
+      if (pipe(fd) != 0)
+        return 2;
+      rd[r] = fd[0];
+      wr.push_back(fd[1]);
+    }
+  std::vector<pid_t> kids;
+  for (int r = 0; r < n_ranks; ++r)
+    {
+      const pid_t pid = fork();
+      if (pid < 0)
+        return 2;
+      if (pid == 0)
+        _exit(run_rank(dims[0], dims[1], dims[2], r, n_ranks, rd[r], r == 0 ? wr : std::vector<int>{}));
+      kids.push_back(pid);
+    }
+  int bad = 0;
+  for (pid_t pid : kids)
+    {
+      int st = 0;
+      if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+        ++bad;
+    }
+  if (bad)
+    {
+      fprintf(stderr, "abi_driver: %d of %d ranks failed\n", bad, n_ranks);
+      return 1;
+    }
+  printf("abi_driver: OK (%d ranks)\n", n_ranks);
   return 0;
 }

@@ -82,3 +82,19 @@ def test_no_oracle_in_product_package():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "oracle_api" not in text and "oracle/" not in text.replace(
                     "oracle/)", ""), f
+
+
+def test_bench_self_launch_command_line():
+    """`python bench.py --gpus N` re-executes itself under torch.distributed.run (bench.py: self_launch_command);
+    the multi-process run itself is a GPU test (tests/test_gpu_multirank.py)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    cmd = bench.self_launch_command(8, ["--gpus", "8", "--n", "216", "--steps", "5"])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    script = cmd.index(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--cells", "216", "--steps", "5"]

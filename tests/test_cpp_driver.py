@@ -43,3 +43,20 @@ def test_cpp_host_create_halo_assemble(shape):
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_driver: OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_host_two_ranks_over_rccl():
+    """Two forked ranks, one GPU each, RCCL id over a pipe, ring exchange of the ghost planes through
+    pfm_comm_create / pfm_halo_exchange: the first box with >= 2 GPUs that runs `pytest -m gpu` exercises the in-library
+    transport with more than one rank.  Skipped on single-GPU boxes."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the 1-rank self-exchange above covers the call sequence)")
+    exe = build_driver()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "13", "9", "10", "--ranks", "2"], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_driver: OK (2 ranks)" in r.stdout

@@ -267,3 +267,52 @@ def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra
     assert a.shape == b.shape and np.abs(a).max() > 0
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)  # each pair is (sum, sum of absolute values)
     assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
+
+
+def _bench_json(cmd, env, timeout=900):
+    import json
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_gpus_n_as_typed_self_launches():
+    """`python bench.py --gpus 2` exactly as typed (no torch.distributed.run in front): the script re-executes itself
+    under the launcher and rank 0 prints the line.  All ranks on this GPU, ghost import over gloo (smoke switch)."""
+    import os
+    import sys
+
+    env = dict(os.environ, PFM_BENCH_SMOKE_GLOO="1")
+    env.pop("WORLD_SIZE", None)
+    common = ["--n", "24", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    one = _bench_json([sys.executable, "bench.py", "--gpus", "1"] + common, env)
+    two = _bench_json([sys.executable, "bench.py", "--gpus", "2"] + common, env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    a, b = np.array(one["checksum"]), np.array(two["checksum"])
+    scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
+    assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
+
+
+def test_bench_two_gpus_over_rccl():
+    """The same over real RCCL, one GPU per rank: runs wherever `pytest -m gpu` finds two GPUs."""
+    import os
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("PFM_BENCH_SMOKE_GLOO", None)
+    common = ["--n", "40", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    one = _bench_json([sys.executable, "bench.py", "--gpus", "1"] + common, env)
+    two = _bench_json([sys.executable, "bench.py", "--gpus", "2"] + common, env)
+    assert two["n_gpus"] == 2
+    a, b = np.array(one["checksum"]), np.array(two["checksum"])
+    scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
+    assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
