@@ -1042,9 +1042,16 @@ namespace pfm
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    static const bool use_uu3 = getenv("PFM_UU4") == nullptr; // PFM_UU4=1: the z-marching variant (pfm_cart_uu4.hip), measured equal
-    int rc = (use_uu3 || cv.cell_lam || res_pde) ? launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde)
-                                                 : launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
+    // (u,u) kernel: k_cart_uu3 (tile per plane); PFM_UU5=1: the z-march of round 3 (pfm_cart_uu5.hip); PFM_UU4=1: the
+    // z-march of round 2 (no residual rows, no heterogeneous material)
+    static const int uu_sel = getenv("PFM_UU5") ? 5 : (getenv("PFM_UU4") ? 4 : 3);
+    int rc;
+    if (uu_sel == 5 && !cv.cell_lam)
+      rc = launch_cart_uu5(v, cv, p, d_values[0], s, d_scal, res_pde);
+    else if (uu_sel == 4 && !cv.cell_lam && !res_pde)
+      rc = launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
+    else
+      rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde);
     if (rc)
       return rc;
     return launch_cart_phi4(v, cv, p, d_values, s, d_scal, res_pde);

@@ -402,107 +402,115 @@ namespace pfm
       __syncthreads();
       stamp(1);
 
-      // ---- cell phase b: moment tables, thread <-> (cell, task), 9 tasks per cell: A^x, A^y, A^z and the two halves
-      // (al = 0, 1) of T^xy, T^xz, T^yz -- 810 tasks of ~65 flops in two passes (the 540 (cell, family) tasks of round 1
-      // needed a second pass for 28 of them, at twice the work per task).  All 27 w*g values of a task are read before
-      // the first use: every s_waitcnt on the LDS is a ~130-cycle round trip.
-      // The upper layer (l = 1) is written z-mirrored so that both half-waves run the same node phase.
-      for (int tt = t; tt < 9 * CS3; tt += NT3)
-        {
-          const int cs = tt % CS3, task = tt / CS3;
-          const bool mir = cs >= CL3;
-          double *out = s_tab + cs;
-          const double *wq = s_stage + cs;
-          if (task < 3)
+      // ---- cell phase b: moment tables.  Round 3: wave <-> (family f, cell group) with the family WAVE-UNIFORM: waves
+      // 0..5 = families 0..2 x cell groups {cells 0..44 = layer 0, cells 45..89 = layer 1}, lane <-> cell.  A family is
+      // A^f plus both halves of the pair table that contracts direction f first (T^xy, T^xz for f = 0 ... see below), so
+      // that the 27 w*g values of a cell are read ONCE for 198 flops (round 2: thread <-> (cell, task), 9 tasks per cell
+      // with run-time strides: 27 reads per 65 flops, and 63 % of the VALU instructions of the phase were address
+      // arithmetic -- on this chip an integer VALU instruction costs the same 4-cycle issue slot as an FP64 FMA).
+      // Every stride, table number and the z-mirroring of layer 1 are compile-time constants per (family, layer).
+      // The arithmetic of each table entry is unchanged (bitwise identical tables).
+      // Families: f = 0: A^x, T^xy (lo = x);  f = 1: A^y, T^yz (lo = y);  f = 2: A^z, T^xz (lo = x, hi = z).
+      {
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int ln = t & 63;
+        auto family = [&](auto Ff, auto Ll) __attribute__((always_inline)) {
+          constexpr int f = decltype(Ff)::value, l = decltype(Ll)::value;
+          constexpr bool mir = l == 1;
+          if (ln < CL3)
             {
-              const int c = task;
-              const int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
-              const int si = (c == 0) ? 3 : 1;
-              const int sj = (c == 2) ? 3 : 9;
-              double r27[3][3][3];
+              const int cs = l * CL3 + ln;
+              const double *wq = s_stage + cs;
+              double *out = s_tab + cs;
+              double w27[27];
 #pragma unroll
-              for (int qj = 0; qj < 3; ++qj)
-#pragma unroll
-                for (int qi = 0; qi < 3; ++qi)
-                  {
-                    const int q0 = qi * si + qj * sj;
-                    r27[qj][qi][0] = wq[q0 * CS3];
-                    r27[qj][qi][1] = wq[(q0 + sc) * CS3];
-                    r27[qj][qi][2] = wq[(q0 + 2 * sc) * CS3];
-                  }
+              for (int q = 0; q < 27; ++q)
+                w27[q] = wq[q * CS3];
               __builtin_amdgcn_sched_barrier(0);
-              double s9[3][3]; // [qj][qi], (i,j) = other axes ascending
+              // ---- A^c, c = f: sum over q_c, then the two moment axes (i, j) = other axes ascending
+              {
+                constexpr int c = f;
+                constexpr int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
+                constexpr int si = (c == 0) ? 3 : 1;
+                constexpr int sj = (c == 2) ? 3 : 9;
+                double s9[3][3]; // [qj][qi]
 #pragma unroll
-              for (int qj = 0; qj < 3; ++qj)
+                for (int qj = 0; qj < 3; ++qj)
 #pragma unroll
-                for (int qi = 0; qi < 3; ++qi)
-                  s9[qj][qi] = (r27[qj][qi][0] + r27[qj][qi][1]) + r27[qj][qi][2];
-              const bool zj = (c != 2); // for c = x or y the second moment axis j is z
-              // mirrored: g_j -> 2 - g_j, i.e. index = base + gi*3 + (mir&&zj ? 2 - gj : gj): stride and start per lane
-              const int gj0 = (mir && zj) ? 2 : 0, gjs = (mir && zj) ? -1 : 1;
-#pragma unroll
-              for (int gi = 0; gi < 3; ++gi)
-                {
-                  double tq[3];
-#pragma unroll
-                  for (int qj = 0; qj < 3; ++qj)
-                    tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
-#pragma unroll
-                  for (int gj = 0; gj < 3; ++gj)
+                  for (int qi = 0; qi < 3; ++qi)
                     {
-                      const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
-                      out[(c * 9 + gi * 3 + gj0 + gjs * gj) * CS3] = val;
+                      const int q0 = qi * si + qj * sj;
+                      s9[qj][qi] = (w27[q0] + w27[q0 + sc]) + w27[q0 + 2 * sc];
                     }
-                }
-            }
-          else
-            {
-              const int p = (task - 3) >> 1, al = (task - 3) & 1; // pair (lo,hi): 0 = (x,y), 1 = (x,z), 2 = (y,z)
-              const int slo = (p == 2) ? 3 : 1;
-              const int shi = (p == 0) ? 3 : 9;
-              const int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
-              const double na0 = al ? c_g1.n[1][0] : c_g1.n[0][0], na1 = al ? c_g1.n[1][1] : c_g1.n[0][1],
-                           na2 = al ? c_g1.n[1][2] : c_g1.n[0][2];
-              double r27[3][3][3];
+                constexpr bool zj = (c != 2); // for c = x or y the second moment axis j is z
 #pragma unroll
-              for (int qe = 0; qe < 3; ++qe)
-#pragma unroll
-                for (int qh = 0; qh < 3; ++qh)
+                for (int gi = 0; gi < 3; ++gi)
                   {
-                    const int q0 = qh * shi + qe * se;
-                    r27[qe][qh][0] = wq[q0 * CS3];
-                    r27[qe][qh][1] = wq[(q0 + slo) * CS3];
-                    r27[qe][qh][2] = wq[(q0 + 2 * slo) * CS3];
+                    double tq[3];
+#pragma unroll
+                    for (int qj = 0; qj < 3; ++qj)
+                      tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
+#pragma unroll
+                    for (int gj = 0; gj < 3; ++gj)
+                      {
+                        const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
+                        const int gjm = (mir && zj) ? 2 - gj : gj; // layer 1 is stored z-mirrored
+                        out[(c * 9 + gi * 3 + gjm) * CS3] = val;
+                      }
                   }
-              __builtin_amdgcn_sched_barrier(0);
-              double t1[3][3]; // [q_e][q_hi]
+              }
+              // ---- T^p, both halves al = 0, 1: p = 0 (x,y) for f = 0, p = 2 (y,z) for f = 1, p = 1 (x,z) for f = 2
+              {
+                constexpr int p = (f == 0) ? 0 : (f == 1) ? 2 : 1;
+                constexpr int slo = (p == 2) ? 3 : 1;
+                constexpr int shi = (p == 0) ? 3 : 9;
+                constexpr int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
+                constexpr bool mz = mir && p == 0, mb = mir && p != 0;
 #pragma unroll
-              for (int qe = 0; qe < 3; ++qe)
+                for (int al = 0; al < 2; ++al)
+                  {
+                    const double na0 = c_g1.n[al][0], na1 = c_g1.n[al][1], na2 = c_g1.n[al][2];
+                    double t1[3][3]; // [q_e][q_hi]
 #pragma unroll
-                for (int qh = 0; qh < 3; ++qh)
-                  t1[qe][qh] = (r27[qe][qh][0] * na0 + r27[qe][qh][1] * na1) + r27[qe][qh][2] * na2;
-              // mirrored layer: p = 0 (e = z): g -> 2 - g; p = 1, 2 (hi = z carries n_be(q_z)): be -> 1 - be and one
-              // z-derivative => sign flip
-              const bool mz = mir && p == 0, mb = mir && p != 0;
-              const int g0 = mz ? 2 : 0, gs = mz ? -1 : 1;
-              const double sgn = mb ? -1.0 : 1.0;
+                    for (int qe = 0; qe < 3; ++qe)
 #pragma unroll
-              for (int be = 0; be < 2; ++be)
-                {
-                  double t2[3];
+                      for (int qh = 0; qh < 3; ++qh)
+                        {
+                          const int q0 = qh * shi + qe * se;
+                          t1[qe][qh] = (w27[q0] * na0 + w27[q0 + slo] * na1) + w27[q0 + 2 * slo] * na2;
+                        }
 #pragma unroll
-                  for (int qe = 0; qe < 3; ++qe)
-                    t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
-                  const int bes = mb ? 1 - be : be;
+                    for (int be = 0; be < 2; ++be)
+                      {
+                        double t2[3];
 #pragma unroll
-                  for (int g = 0; g < 3; ++g)
-                    {
-                      const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
-                      out[(27 + p * 12 + al * 6 + bes * 3 + g0 + gs * g) * CS3] = sgn * val;
-                    }
-                }
+                        for (int qe = 0; qe < 3; ++qe)
+                          t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
+                        const int bes = mb ? 1 - be : be;
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                          {
+                            const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
+                            const int gm = mz ? 2 - g : g;
+                            out[(27 + p * 12 + al * 6 + bes * 3 + gm) * CS3] = mb ? -val : val;
+                          }
+                      }
+                  }
+              }
             }
-        }
+        };
+        using std::integral_constant;
+        switch (wv)
+          {
+            case 0: family(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+            case 1: family(integral_constant<int, 0>{}, integral_constant<int, 1>{}); break;
+            case 2: family(integral_constant<int, 1>{}, integral_constant<int, 0>{}); break;
+            case 3: family(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+            case 4: family(integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
+            case 5: family(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+            default: break;
+          }
+      }
       __syncthreads();
       stamp(2);
 
@@ -775,7 +783,9 @@ namespace pfm
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)
   {
-    static const bool use_uu3 = getenv("PFM_UU4") == nullptr;
-    return (use_uu3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal, nullptr) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
+    static const int uu_sel = getenv("PFM_UU5") ? 5 : (getenv("PFM_UU4") ? 4 : 3);
+    if (uu_sel == 5 && !cv.cell_lam)
+      return launch_cart_uu5(v, cv, p, vals_uu, s, d_scal, nullptr);
+    return (uu_sel == 3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal, nullptr) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
   }
 } // namespace pfm

@@ -114,6 +114,9 @@ namespace pfm
   // selected by PFM_UU4=1 (A/B runs, tests/test_gpu_cart.py runs both)
   int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal);
+  // round 3: the z-march with LDS-DMA plane prefetch and the residual from the rows (pfm_cart_uu5.hip)
+  int launch_cart_uu5(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
+                      const void *d_scal, double *res_pde);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal);
   // color_ptr[n_classes + 1]: ranges of DevView::color_cells, one launch per class; the LAST class holds the cells with

@@ -56,7 +56,6 @@ class HaloExchange:
                          and os.environ.get("PFM_HALO_TORCH") != "1")
         self._comm = None
         self._comm_lib = None
-        self._lib_checked = False
 
     @property
     def bytes_per_exchange(self) -> int:
@@ -100,14 +99,21 @@ class HaloExchange:
         from . import capi
 
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
-        uid = np.zeros(capi.COMM_ID_BYTES, np.uint8)
+        uid = np.zeros(capi.COMM_ID_BYTES + 1, np.uint8)  # last byte: rank 0 obtained an id
         if rank == 0:
-            rc = ctx.lib.pfm_comm_unique_id(capi.np_ptr(uid, np.uint8))
-            if rc != capi.PFM_OK:
-                raise capi.PfmError(rc, "pfm_comm_unique_id")
+            rc0 = ctx.lib.pfm_comm_unique_id(capi.np_ptr(uid, np.uint8))
+            uid[-1] = 1 if rc0 == capi.PFM_OK else 0
+        # every rank takes part in the broadcast whatever rank 0's outcome was: nobody is left waiting in a collective
         t = torch.from_numpy(uid).to(self.send_all.device)
         dist.broadcast(t, 0, group=self.group)
         uid = np.ascontiguousarray(t.cpu().numpy())
+        if uid[-1] == 0:
+            import warnings
+
+            warnings.warn("pfm_comm_unique_id failed on rank 0 (RCCL unavailable?): ghost exchange uses torch.distributed P2P")
+            self._use_lib = False
+            return
+        uid = np.ascontiguousarray(uid[:-1])
         h = C.c_void_p()
         rc = ctx.lib.pfm_comm_create(C.byref(h), capi.np_ptr(uid, np.uint8), world, rank, self.send_all.device.index)
         # the choice of transport must be the same on every rank: agree on the outcome
@@ -135,28 +141,12 @@ class HaloExchange:
         if self._use_lib:
             self._ensure_comm(ctx)
         if self._use_lib:
-            if self._lib_checked:
-                ctx.halo_exchange(self._comm.value, self.peers)
-                return
-            # first use of the in-library transport: every rank reports its outcome, and all ranks fall back to
-            # torch.distributed together if any of them failed (the enqueue of a failed rank never matches its peers')
-            from . import capi
-
-            try:
-                ctx.halo_exchange(self._comm.value, self.peers)
-                self.torch.cuda.current_stream().synchronize()
-                good = 1
-            except capi.PfmError:
-                good = 0
-            ok = self.torch.tensor([good], device=self.send_all.device)
-            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN, group=self.group)
-            self._lib_checked = True
-            if int(ok.item()) == 1:
-                return
-            import warnings
-
-            warnings.warn("pfm_halo_exchange failed on some rank: ghost exchange falls back to torch.distributed P2P")
-            self._use_lib = False
+            # Every local, non-blocking precondition (library loaded, communicator made, lists registered) was agreed on
+            # by all ranks in _ensure_comm BEFORE any RCCL work was enqueued.  From here on a failure is fatal: peers may
+            # already have enqueued the matching send/receive, so there is no fall-back -- the library aborts the
+            # communicator (pfm_halo_exchange) and the error propagates.
+            ctx.halo_exchange(self._comm.value, self.peers)
+            return
         if self.send_all.numel():
             ctx.halo_pack_all(self.send_all.data_ptr())  # one launch for all peers
         self._post()

@@ -290,9 +290,10 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
     # default: k_cart_uu3 / k_cart_phi4 also write the residual (from their matrix rows); PFM_RES_KERNEL=1: the quadrature
     # residual kernel; PFM_UU4=1 (+ PFM_RES_KERNEL=1, the z-marching kernel has no residual variant): k_cart_uu4
     val, rhs = {}, {}
-    for tag, env in (("rows", {}), ("uu3", {"PFM_RES_KERNEL": "1"}), ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"})):
+    for tag, env in (("rows", {}), ("uu3", {"PFM_RES_KERNEL": "1"}), ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"}),
+                     ("uu5", {"PFM_UU5": "1", "PFM_RES_KERNEL": "1"}), ("uu5rows", {"PFM_UU5": "1"})):
         f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
-        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_RES_KERNEL")}
+        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_UU5", "PFM_RES_KERNEL")}
         e.update(env)
         subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
         val[tag], rhs[tag] = np.load(f), np.load(g)
@@ -301,6 +302,9 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
     # the residual variant of the (u,u) kernel writes the same matrix bits; its residual equals the quadrature one to round-off
     assert np.array_equal(val["rows"], val["uu3"])
     assert rhs["rows"].shape == rhs["uu3"].shape and linf_scaled(rhs["rows"], rhs["uu3"]) < TOL
+    # round 3: the z-march with LDS-DMA plane prefetch (pfm_cart_uu5.hip), without and with the residual from the rows
+    assert np.array_equal(val["uu3"], val["uu5"]) and np.array_equal(rhs["uu3"], rhs["uu5"])
+    assert np.array_equal(val["uu3"], val["uu5rows"]) and linf_scaled(rhs["uu5rows"], rhs["uu3"]) < TOL
 
 
 # ---- 2-D row-owner Jacobian (pfm_cart2d.hip): BASELINE config 2 with the matrix, tests/sneddon_2d_1.prm on a uniform mesh
