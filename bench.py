@@ -34,20 +34,52 @@ N_SIMD = 1024  # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4  # max clock (the chip sustains ~1.6-2.1 GHz under FP64 load: profiles/r02/microbench_mfma_f64_lds.txt)
 
 
-def measured_valu_instructions(dim: int, n: int, residual_only: bool):
-    """Second bound, from counters instead of a flop estimate: VALU wave-instructions per assembly (SQ_INSTS_VALU of a
-    separate rocprofv3 PMC pass of this very command, summary committed under profiles/).  An FP64 VALU instruction
-    occupies its SIMD for 4 cycles (16 lanes per clock), so N / (4 SIMDs x CUs) x 4 cycles is the time the kernels would
-    need if they issued nothing else and every instruction were FP64 -- an upper estimate of the issue floor (integer
-    and move instructions take 2 cycles).  None if this workload was not profiled."""
+def kernel_source_hash() -> str:
+    """sha1 over the kernel sources: profiles/ summaries carry the hash they were measured with, and bench.py refuses to
+    quote counters of other kernels (a stale profile goes into the JSON as null, with a warning on stderr)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "cracks_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _profile_record(key: str):
     import glob
 
-    key = f"valu_instructions_{dim}d_{n}{'_residual' if residual_only else ''}.json"
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key)))
     if not found:
         return None, None
     rec = json.load(open(found[-1]))
-    return float(sum(rec["per_launch"].values())), os.path.relpath(found[-1], ROOT)
+    src = os.path.relpath(found[-1], ROOT)
+    want = rec.get("kernel_source_hash")
+    if want is not None and want != kernel_source_hash():
+        print(f"bench.py: WARNING {src} was measured with other kernel sources (hash {want}): not quoted; "
+              f"re-run tools/profile_round.sh", file=sys.stderr)
+        return None, src + " (STALE: kernels changed since)"
+    return rec, src
+
+
+def measured_valu_instructions(dim: int, n: int, residual_only: bool):
+    """Second bound, from counters instead of a flop estimate: VALU wave-instructions per assembly and how many of them
+    are FP64 arithmetic (SQ_INSTS_VALU, SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of a separate rocprofv3 PMC pass of this very
+    command, tools/profile_round.sh; summary committed under profiles/).  On gfx950 EVERY VALU instruction occupies its
+    SIMD for a 4-cycle issue slot (measured: an integer or move instruction costs what an FP64 FMA costs), so
+    N_valu x 4 cycles / (4 SIMDs x CUs) is the issue floor of the instruction stream as it is, and N_fp64 x 4 cycles
+    the floor of its arithmetic alone.  None if this workload was not profiled with the current kernels."""
+    rec, src = _profile_record(f"instruction_mix_{dim}d_{n}{'_residual' if residual_only else ''}.json")
+    if rec is None:
+        return None, src
+    tot = fp64 = 0.0
+    for name, d in rec["per_launch"].items():
+        if name in ("k_aos_to_soa",):
+            continue
+        tot += d.get("SQ_INSTS_VALU", 0.0)
+        fp64 += d.get("SQ_INSTS_VALU_ADD_F64", 0.0) + d.get("SQ_INSTS_VALU_MUL_F64", 0.0) + d.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+    return {"valu": tot, "fp64": fp64}, src
 
 
 def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
@@ -60,20 +92,17 @@ def algorithmic_bytes_per_cell(dim: int, residual_only: bool) -> float:
 
 def measured_hbm_traffic(dim: int, n: int, residual_only: bool):
     """HBM bytes per assembly from the PMC counters (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes of this very
-    command, tools/hbm_traffic.sh; summaries committed under profiles/).  None if this workload was not profiled."""
-    import glob
-
-    key = f"hbm_traffic_{dim}d_{n}{'_residual' if residual_only else ''}.json"
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key)))
-    if not found:
-        return None, None
-    rec = json.load(open(found[-1]))
+    command, tools/profile_round.sh; summaries committed under profiles/).  None if this workload was not profiled with
+    the current kernels."""
+    rec, src = _profile_record(f"hbm_traffic_{dim}d_{n}{'_residual' if residual_only else ''}.json")
+    if rec is None:
+        return None, src
     total = 0.0
     for name, d in rec["per_launch"].items():
         if residual_only and name not in ("k_cart_residual3", "k_cart_residual", "k_state_set"):
             continue
         total += d.get("write_bytes", 0.0) + d.get("fetch_bytes", 0.0)
-    return total, os.path.relpath(found[-1], ROOT)
+    return total, src
 
 
 def sneddon_params(h: float, dim: int):
@@ -215,6 +244,98 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
                       f"insertion overhead the real reference pays"}
 
 
+def time_mode(asm, dev, residual_only: bool, steps: int, warmup: int):
+    """ms per call (wall, barrier-free single rank) and mean kernel-group ms (HIP events) of one assembly mode."""
+    import torch
+
+    first = [True]
+
+    def call():
+        asm.assemble_system(residual_only, solution_only=residual_only and not first[0])
+        first[0] = False
+
+    for _ in range(warmup):
+        call()
+    asm.synchronize()
+    asm.ctx.timing_enable(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    torch.cuda.synchronize(dev)
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    asm.synchronize()
+    k_ms, _ = asm.ctx.kernel_time_ms()
+    asm.ctx.timing_enable(False)
+    return wall, k_ms
+
+
+def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
+    """The other lines of SURVEY.md 8(d) in the same run (a few seconds): residual-only at the headline size (the
+    line-search call of cracks.cc:2942-2957), BASELINE config 2 (2-D 1000^2 residual-only) and the 2-D Jacobian, each
+    with its fraction of the HBM roofline and, where the kernels were profiled, the counted FP64 bound."""
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler
+
+    out = {}
+
+    def record(key, dim, n, residual_only, wall, k_ms, n_cells, n_dofs):
+        ab = algorithmic_bytes_per_cell(dim, residual_only) * n_cells
+        rec = {"ms_per_call": wall, "kernel_ms": k_ms, "DoFs_per_s": n_dofs / (wall * 1e-3),
+               "hbm_frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+               "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)}
+        vi, src = measured_valu_instructions(dim, n, residual_only)
+        if vi is not None:
+            to_ms = 4.0 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            rec["fp64_bound"] = {"fp64_wave_instructions": vi["fp64"], "valu_wave_instructions": vi["valu"],
+                                 "fp64_share": vi["fp64"] / vi["valu"] if vi["valu"] else None,
+                                 "fp64_floor_ms_at_max_clock": vi["fp64"] * to_ms,
+                                 "issue_floor_ms_at_max_clock": vi["valu"] * to_ms, "source": src}
+        out[key] = rec
+
+    n_nodes3 = (n3 + 1) ** 3
+    wall, k_ms = time_mode(asm3, dev, True, steps, 2)
+    record("residual_only_3d", 3, n3, True, wall, k_ms, n3 ** 3, 4 * n_nodes3)
+    n2 = 1000
+    lp = P.build_local_problem(2, (n2, n2), P.factor_ranks(1, 2), 0)
+    h = (20.0 / n2) * np.sqrt(2)
+    u, phi, po, poo, flags = synthetic_state(lp.mesh, lp.global_ids, h, 2)
+    a2 = Assembler(lp.mesh, blocked=True, device=local_rank, n_owned_nodes=lp.n_owned)
+    a2.set_params(sneddon_params(h, 2))
+    a2.set_constraints(flags)
+    no = lp.n_owned
+
+    def pack(uu, pp):
+        v = np.empty(no * 3)
+        v[:no * 2] = uu[:no].reshape(-1)
+        v[no * 2:] = pp[:no]
+        return v
+
+    a2.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
+    wall, k_ms = time_mode(a2, dev, True, 4 * steps, 3)
+    record("config2_residual_only_2d", 2, n2, True, wall, k_ms, n2 * n2, 3 * (n2 + 1) ** 2)
+    wall, k_ms = time_mode(a2, dev, False, steps, 2)
+    record("jacobian_2d", 2, n2, False, wall, k_ms, n2 * n2, 3 * (n2 + 1) ** 2)
+    a2.ctx.close()
+    return out
+
+
+def d2h_bandwidth(dev, gib: float = 2.0):
+    """Device -> pinned host copy rate (GB/s) on a sample: what the synchronous host-pointer call shape of the reference
+    (pfm_assemble: values complete in host memory on return) pays per byte of matrix values."""
+    import torch
+
+    n = int(gib * (1 << 30) / 8)
+    src = torch.empty(n, dtype=torch.float64, device=dev)
+    dst = torch.empty(n, dtype=torch.float64, pin_memory=True)
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    return n * 8 / (time.perf_counter() - t0) / 1e9
+
+
 def self_launch_command(n_gpus: int, argv):
     """argv of `python -m torch.distributed.run ... bench.py <argv>` for a single-node run with one rank per GPU."""
     import socket
@@ -239,6 +360,7 @@ def main():
     ap.add_argument("--residual-only", action="store_true")
     ap.add_argument("--path", choices=["auto", "general", "cart", "overlay"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra lines (residual-only, 2-D configurations, PCIe-inclusive value)")
     ap.add_argument("--checksum", action="store_true",
                     help="add partition-independent sums of the assembled values (outside the timed region): the "
                          "N-rank run must reproduce the 1-rank numbers up to round-off")
@@ -313,8 +435,13 @@ def main():
         del again
     residual_only = args.residual_only
 
+    # residual-only runs measure the line search (cracks.cc:2942-2957): between two assemble_nl_residual() calls only
+    # `solution` has changed, so only it is scattered again (pfm_state_set_solution); the first call scatters all three
+    first_call = [True]
+
     def step():
-        asm.assemble_system(residual_only)
+        asm.assemble_system(residual_only, solution_only=residual_only and not first_call[0])
+        first_call[0] = False
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -367,9 +494,13 @@ def main():
         vi, vi_src = measured_valu_instructions(dim, n, residual_only) if world == 1 else (None, None)
         valu = None
         if vi is not None:
-            floor_ms = vi * 4.0 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
-            valu = {"wave_instructions_per_launch": vi, "issue_floor_ms_if_all_fp64_at_max_clock": floor_ms,
-                    "frac_of_kernel_time": floor_ms / k_ms if k_ms > 0 else None, "source": vi_src}
+            to_ms = 4.0 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
+            valu = {"wave_instructions_per_launch": vi["valu"], "fp64_wave_instructions_per_launch": vi["fp64"],
+                    "fp64_share": vi["fp64"] / vi["valu"] if vi["valu"] else None,
+                    "issue_floor_ms_at_max_clock": vi["valu"] * to_ms, "fp64_floor_ms_at_max_clock": vi["fp64"] * to_ms,
+                    "issue_floor_frac_of_kernel_time": vi["valu"] * to_ms / k_ms if k_ms > 0 else None, "source": vi_src}
+        elif vi_src:
+            valu = {"source": vi_src}
         out = {
             "metric": "assembled DoFs/sec (residual+Jacobian) on 3D Sneddon" if (dim == 3 and not residual_only)
             else f"assembled DoFs/sec ({'residual-only' if residual_only else 'residual+Jacobian'}) on {dim}D Sneddon",
@@ -381,6 +512,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
+            "parity": "GPU vs CPU oracle: |x - x_ref|_inf < 1e-12 * max(1, |x_ref|_inf), every matrix entry and residual (tests/, 216^3 sample in tests/test_gpu_fullsize.py)",
             "data": "synthetic (uniform hex mesh on [-10,10]^d, interpolated Sneddon crack + seeded perturbation)" +
                     (" -- SMOKE RUN: all ranks on one GPU, gloo, not a measurement" if smoke_gloo else ""),
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
@@ -399,6 +531,18 @@ def main():
         }
         if checksum is not None:
             out["checksum"] = checksum
+        if world == 1 and not smoke_gloo and not args.no_extras and dim == 3 and not residual_only and args.path == "auto":
+            try:
+                out["extra"] = extra_lines(asm, dev, local_rank, n, max(5, args.steps // 2))
+                # PCIe-inclusive figure of SURVEY 8(d): the values a host-side Trilinos solve needs in host memory
+                bw = d2h_bandwidth(dev)
+                nbytes = 8.0 * (sum(int(m.numel()) for m in asm.system_pde_matrix) + n_dofs)
+                t_incl = elapsed / args.steps + nbytes / (bw * 1e9)
+                out["value_incl_d2h"] = n_dofs / t_incl
+                out["d2h"] = {"GBps_pinned": bw, "bytes_per_assembly": nbytes, "seconds_per_assembly_incl_d2h": t_incl,
+                              "note": "rate measured on a 2 GiB pinned copy, applied to the bytes of all matrix blocks + residual; never the headline value"}
+            except Exception as e:  # the headline line must not depend on the extras
+                out["extra_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, residual_only)
         print(json.dumps(out), flush=True)

@@ -152,6 +152,10 @@ class Context:
         self._check(self.lib.pfm_state_set(self._h, C.c_void_p(sol_ptr), C.c_void_p(old_ptr),
                                            C.c_void_p(oldold_ptr), 1), "pfm_state_set")
 
+    def state_set_solution_device(self, sol_ptr: int):
+        """``pfm_state_set_solution``: old / old_old keep the values of the last full scatter (line search)."""
+        self._check(self.lib.pfm_state_set_solution(self._h, C.c_void_p(sol_ptr), 1), "pfm_state_set_solution")
+
     def state_set_host(self, sol: np.ndarray, old: np.ndarray, oldold: np.ndarray):
         a = [np.ascontiguousarray(x, np.float64) for x in (sol, old, oldold)]
         self._check(self.lib.pfm_state_set(self._h, capi.np_ptr(a[0], np.float64), capi.np_ptr(a[1], np.float64),
@@ -314,11 +318,16 @@ class Assembler:
         self.old_solution.copy_(t.from_numpy(np.ascontiguousarray(old)))
         self.old_old_solution.copy_(t.from_numpy(np.ascontiguousarray(oldold)))
 
-    def assemble_system(self, residual_only: bool = False):
-        """cracks.cc:2129-2475 (without the AMG set-up that follows it)."""
+    def assemble_system(self, residual_only: bool = False, solution_only: bool = False):
+        """cracks.cc:2129-2475 (without the AMG set-up that follows it).  ``solution_only``: only ``solution`` changed
+        since the last call (the line search of cracks.cc:2942-2957 and the Newton iterations within a time step):
+        old_solution / old_old_solution are not scattered again."""
         self.ctx.set_stream(self.torch.cuda.current_stream(self.dev).cuda_stream)
-        self.ctx.state_set_device(self.solution.data_ptr(), self.old_solution.data_ptr(),
-                                  self.old_old_solution.data_ptr())
+        if solution_only:
+            self.ctx.state_set_solution_device(self.solution.data_ptr())
+        else:
+            self.ctx.state_set_device(self.solution.data_ptr(), self.old_solution.data_ptr(),
+                                      self.old_old_solution.data_ptr())
         if self.halo is not None:
             self.halo.exchange(self.ctx)
         if not residual_only:
@@ -326,9 +335,9 @@ class Assembler:
         self.ctx.assemble_device(residual_only, [m.data_ptr() for m in self.system_pde_matrix] if not residual_only else [],
                                  self.system_pde_residual.data_ptr(), self.system_total_residual.data_ptr())
 
-    def assemble_nl_residual(self):
+    def assemble_nl_residual(self, solution_only: bool = False):
         """cracks.cc:2507-2512."""
-        self.assemble_system(True)
+        self.assemble_system(True, solution_only)
 
     def synchronize(self):
         """Wait for the stream and raise what the reference would have thrown/aborted on."""

@@ -23,7 +23,7 @@ LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 EXPORTS = [
     "pfm_ctx_create", "pfm_ctx_destroy", "pfm_last_error", "pfm_ctx_set_stream", "pfm_set_params",
     "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_pattern_bind", "pfm_pattern_bind_i32",
-    "pfm_state_set", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_destroy", "pfm_halo_exchange",
+    "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_destroy", "pfm_halo_exchange",
     "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
     "pfm_assemble_device",
@@ -107,6 +107,7 @@ def load():
     lib.pfm_check_finite.argtypes = [vp, vp, i64]
     lib.pfm_functionals_material.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
     lib.pfm_state_set.argtypes = [vp, vp, vp, vp, i32]
+    lib.pfm_state_set_solution.argtypes = [vp, vp, i32]
     lib.pfm_halo_register.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pfm_halo_pack.argtypes = [vp, i32, vp]
     lib.pfm_halo_unpack.argtypes = [vp, i32, vp]

@@ -1171,22 +1171,24 @@ extern "C"
     return pattern_bind_impl(c, block, nullptr, rowptr, colind);
   }
 
-  int pfm_state_set(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
-                    int on_device)
+  // sol / old / oldold -> node state; old == oldold == nullptr: solution only (pfm_state_set_solution)
+  static int state_set_impl(pfm_ctx *c, const double *sol, const double *old, const double *oldold, int on_device)
   {
     if (!c)
       return PFM_ERR_BAD_ARG;
     if (c->n_owned_dofs() == 0)
       return PFM_OK; // a rank that owns nothing: its node state comes from the ghost import alone
-    if (!sol || !old || !oldold)
+    const bool sol_only = !old && !oldold;
+    if (!sol || (!sol_only && (!old || !oldold)))
       return PFM_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
+    const int nvec = sol_only ? 1 : 3;
     const double *src[3] = {sol, old, oldold};
     const double *d[3] = {sol, old, oldold};
     if (!on_device)
       {
         const size_t bytes = sizeof(double) * (size_t)c->n_owned_dofs();
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < nvec; ++k)
           {
             if (!c->d_stage_vec[k])
               {
@@ -1212,6 +1214,15 @@ extern "C"
       }
     return PFM_OK;
   }
+
+  int pfm_state_set(pfm_ctx *c, const double *sol, const double *old, const double *oldold, int on_device)
+  {
+    if (!c || (c->n_owned_dofs() != 0 && (!old || !oldold)))
+      return PFM_ERR_BAD_ARG;
+    return state_set_impl(c, sol, old, oldold, on_device);
+  }
+
+  int pfm_state_set_solution(pfm_ctx *c, const double *sol, int on_device) { return state_set_impl(c, sol, nullptr, nullptr, on_device); }
 
   int pfm_halo_register(pfm_ctx *c, int n_peers, const int64_t *send_ptr, const int32_t *send_nodes,
                         const int64_t *recv_ptr, const int32_t *recv_nodes)

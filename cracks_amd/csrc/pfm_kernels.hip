@@ -900,8 +900,11 @@ namespace pfm
         v.u[d][n] = sol[dof_index<dim>(v, n, d)];
       const long long dp = dof_index<dim>(v, n, dim);
       v.phi[n] = sol[dp];
-      v.phi_old[n] = old[dp];
-      v.phi_oldold[n] = oldold[dp];
+      if (old) // nullptr: pfm_state_set_solution, the old fields keep their values (kernel argument: uniform branch)
+        {
+          v.phi_old[n] = old[dp];
+          v.phi_oldold[n] = oldold[dp];
+        }
     }
 
     template <int dim>

@@ -132,6 +132,12 @@ int pfm_pattern_bind_i32(pfm_ctx *ctx, int block, const int32_t *rowptr, const i
  * (cracks.cc:2229, 2232). */
 int pfm_state_set(pfm_ctx *ctx, const double *sol, const double *old, const double *oldold,
                   int on_device);
+/* The same for `solution` alone: old / old_old keep the values of the last pfm_state_set.  This is the call of the
+ * line search (cracks.cc:2942-2957: solution += delta; assemble_nl_residual(), up to max_no_line_search_steps times per
+ * Newton step while old_solution / old_old_solution do not change) and of every Newton iteration after the first of a
+ * time step: a third of the scatter traffic of pfm_state_set.  Ghost values of solution still come from
+ * pfm_halo_exchange. */
+int pfm_state_set_solution(pfm_ctx *ctx, const double *sol, int on_device);
 /* Ghost import (cracks.cc:2147-2154) as pack -> RCCL send/recv -> unpack; the exchange itself is
  * done by the host side between the two calls.  Registration copies the lists.
  * send_nodes: owned nodes whose values a peer needs; recv_nodes: ghost nodes a peer owns.

@@ -411,3 +411,30 @@ def test_cart_heterogeneous_material_mean_diagonal_and_constraints():
     phi_dofs = np.nonzero(is_phi)[0]
     c.cu = M.update_constraints(c.mesh, c.layout, M.sneddon_dirichlet_dofs(c.mesh, c.layout), phi_dofs[::5])
     _full(heterogeneous(c, free_ratio=True), path=1)
+
+
+def test_state_set_solution_only_keeps_the_old_fields():
+    """pfm_state_set_solution (the line search of cracks.cc:2942-2957: only `solution` changes between two
+    assemble_nl_residual calls): the residual after a solution-only scatter equals the one of a context that was given
+    all three vectors, bit for bit, and differs from the residual of the previous solution."""
+    from cracks_amd import capi
+
+    c = box_case(3, (11, 9, 20), -10.0, 10.0, True)
+    ctx = make_context(c)
+    _, r0, t0 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    rng = np.random.default_rng(3)
+    sol2 = c.sol + 1e-3 * rng.standard_normal(c.sol.shape)
+    a = np.ascontiguousarray(sol2, dtype=np.float64)
+    rc = ctx.lib.pfm_state_set_solution(ctx._h, capi.np_ptr(a, np.float64), 0)
+    assert rc == capi.PFM_OK
+    import torch
+
+    n = c.layout.n_dofs
+    bufs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(2)]
+    ctx.assemble_device(True, [], bufs[0].data_ptr(), bufs[1].data_ptr())
+    ctx.sync_status()
+    r1, t1 = bufs[0].cpu().numpy(), bufs[1].cpu().numpy()
+    ref = make_context(c)
+    _, r2, t2 = ref.assemble_host(sol2, c.old, c.oldold, True)
+    assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
+    assert not np.array_equal(r1, r0)

@@ -6,14 +6,15 @@ tag=${1:-rXX}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
+HASH=$(python -c "import bench; print(bench.kernel_source_hash())")
 python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err
-python bench.py --residual-only --no-cpu-baseline > $O/bench_216cube_residual_only.json 2>/dev/null
-python bench.py --dim 2 --residual-only --no-cpu-baseline > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
-python bench.py --dim 2 --no-cpu-baseline > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
-PFM_UU4=1 PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline > $O/bench_216cube_uu4.json 2>/dev/null
-PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline > $O/bench_216cube_residual_kernel.json 2>/dev/null
-python bench.py --n 100 --path general --no-cpu-baseline --steps 5 > $O/bench_100cube_general.json 2>/dev/null
-python bench.py --dim 2 --path general --no-cpu-baseline > $O/bench_2d_1000sq_general.json 2>/dev/null
+python bench.py --residual-only --no-cpu-baseline --no-extras > $O/bench_216cube_residual_only.json 2>/dev/null
+python bench.py --dim 2 --residual-only --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
+python bench.py --dim 2 --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
+PFM_UU4=1 PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_216cube_uu4.json 2>/dev/null
+PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_216cube_residual_kernel.json 2>/dev/null
+python bench.py --n 100 --path general --no-cpu-baseline --no-extras --steps 5 > $O/bench_100cube_general.json 2>/dev/null
+python bench.py --dim 2 --path general --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_general.json 2>/dev/null
 python tools/bench_extra.py config5 --levels 8 --meshes 5 --world 1 --out $O/config5_miehe_amr.json > /dev/null 2>&1
 (cd tools/microbench && [ -x ./lat ] && timeout 120 ./lat > $O/microbench_load_latency.txt 2>&1)
 cd /tmp && export TMPDIR=/tmp
@@ -22,22 +23,34 @@ run_prof () { # name, extra rocprof args..., -- bench args
   rm -rf $O/$name
   timeout 600 rocprofv3 --kernel-trace "$@" > $O/$name.log 2>&1
 }
-run_prof stats --stats --output-format csv -d $O/stats -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+run_prof stats --stats --output-format csv -d $O/stats -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras
 cp $O/stats/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube.csv 2>/dev/null
-run_prof stats_res --stats --output-format csv -d $O/stats_res -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --residual-only
+run_prof stats_res --stats --output-format csv -d $O/stats_res -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --residual-only
 cp $O/stats_res/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube_residual_only.csv 2>/dev/null
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
-run_prof pmc_sq --pmc $SQ --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+run_prof pmc_sq --pmc $SQ --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
 cp $O/pmc_sq/p_counter_collection.csv $O/rocprofv3_pmc_SQ_216cube.csv 2>/dev/null
-run_prof pmc_lds --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/pmc_lds -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+run_prof pmc_lds --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/pmc_lds -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
 cp $O/pmc_lds/p_counter_collection.csv $O/rocprofv3_pmc_LDS_216cube.csv 2>/dev/null
 for ctr in WRITE_SIZE FETCH_SIZE; do
-  run_prof pmc_$ctr --pmc $ctr --output-format csv -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  run_prof pmc_$ctr --pmc $ctr --output-format csv -d $O/pmc_$ctr -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
   cp $O/pmc_$ctr/p_counter_collection.csv $O/rocprofv3_pmc_${ctr}_216cube.csv 2>/dev/null
 done
+MIX="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS"
+mix () { # tag, bench args...
+  tag=$1; shift
+  run_prof pmc_mix_$tag --pmc $MIX --output-format csv -d $O/pmc_mix_$tag -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@"
+  cp $O/pmc_mix_$tag/p_counter_collection.csv $O/rocprofv3_pmc_MIX_$tag.csv 2>/dev/null
+  rm -rf $O/pmc_mix_$tag
+}
+mix 3d_216
+mix 3d_216_residual --residual-only
+mix 2d_1000 --dim 2
+mix 2d_1000_residual --dim 2 --residual-only
 python - <<PY
 import csv, collections, json, re
 O = "$O"
+HASH = "$HASH"
 def per_kernel(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
@@ -50,9 +63,20 @@ res = collections.defaultdict(dict)
 for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
     for k, d in per_kernel(f"{O}/rocprofv3_pmc_{ctr}_216cube.csv").items():
         res[k][ctr.lower().replace("_size", "_bytes")] = d[ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
-keep = ("k_cart_residual3", "k_cart_uu3", "k_cart_uu4", "k_cart_phi4", "k_state_set")
-json.dump({"args": "--steps 3 --warmup 1 --no-cpu-baseline", "per_launch": {k: v for k, v in res.items() if k in keep}},
+keep = ("k_cart_residual3", "k_cart_uu3", "k_cart_uu4", "k_cart_uu5", "k_cart_phi4", "k_state_set")
+json.dump({"args": "--steps 3 --warmup 1 --no-cpu-baseline --no-extras", "kernel_source_hash": HASH, "per_launch": {k: v for k, v in res.items() if k in keep}},
           open(f"{O}/hbm_traffic_3d_216.json", "w"), indent=1)
+for tag in ("3d_216", "3d_216_residual", "2d_1000", "2d_1000_residual"):
+    try:
+        mixd = per_kernel(f"{O}/rocprofv3_pmc_MIX_{tag}.csv")
+    except OSError:
+        continue
+    for k, d in mixd.items():
+        f64 = d.get("SQ_INSTS_VALU_ADD_F64", 0) + d.get("SQ_INSTS_VALU_MUL_F64", 0) + d.get("SQ_INSTS_VALU_FMA_F64", 0)
+        d["fp64_share_of_valu"] = f64 / max(d.get("SQ_INSTS_VALU", 1), 1)
+        print("mix", tag, k, "VALU %.3e FP64 %.3e share %.3f" % (d.get("SQ_INSTS_VALU", 0), f64, d["fp64_share_of_valu"]))
+    json.dump({"counters": "$MIX (wave-instructions per launch, mean over the launches of the run)", "kernel_source_hash": HASH,
+               "per_launch": {k: v for k, v in mixd.items() if k != "k_aos_to_soa"}}, open(f"{O}/instruction_mix_{tag}.json", "w"), indent=1)
 sq = per_kernel(f"{O}/rocprofv3_pmc_SQ_216cube.csv")
 json.dump({"counter": "SQ_INSTS_VALU (wave-instructions per launch)", "per_launch": {k: v["SQ_INSTS_VALU"] for k, v in sq.items() if k in keep and k != "k_state_set"}},
           open(f"{O}/valu_instructions_3d_216.json", "w"), indent=1)
