@@ -1,0 +1,528 @@
+// glue/cracks_gpu_assemble.cc — the deal.II / Trilinos side of the drop-in: what a maintainer of tjhei/cracks adds to
+// cracks.cc so that assemble_system() / assemble_nl_residual() run through include/pfm_assemble.h.
+//
+//   STATUS: UNTESTED AND NEVER COMPILED.  deal.II, Trilinos and p4est do not exist in the image this repository is
+//   built in (cracks.cc needs deal.II >= 9.5 with Trilinos + p4est, CMakeLists.txt:14-36), so this file is compiled
+//   only when PFM_WITH_DEALII is defined and nothing in tests/ builds it.  Everything it CALLS is compiled and tested:
+//   tests/cpp/abi_driver.cpp drives the same sequence (create -> bind -> comm -> state -> halo -> assemble) from C++
+//   on the GPU, with 1 rank everywhere and with 2 forked ranks wherever two GPUs are visible.  Statements about
+//   deal.II / Epetra behaviour that could not be checked here are marked "deal.II-knowledge".
+//
+// How to use: add  #include "glue/cracks_gpu_assemble.cc"  behind the class definition in cracks.cc, add the members of
+// PfmGlue<dim> (one object `pfm_glue`) to FracturePhaseFieldProblem<dim>, call pfm_glue.rebuild(*this) at the end of
+// setup_system() (cracks.cc:1579-1680; called from run() 4174 and refine_mesh() 4148) and replace the body of
+// assemble_system(bool) (cracks.cc:2129-2475; the AMG set-up 2477-2497 stays) by pfm_glue.assemble(*this, residual_only).
+// The glue is a friend-less template over the problem class: it touches only the members named in SURVEY.md 8(a).
+//
+// Design notes
+//   * Node numbering handed to the library: the phase-field dof of a vertex is the key of a node.  Owned nodes first,
+//     in ascending global phase-field index (= the order of the Epetra row map of the phi block and, divided by dim, of
+//     the u block: DoFRenumbering::component_wise keeps the relative order of the dofs of a block; deal.II-knowledge),
+//     ghost nodes behind them in ascending global index.
+//   * Cells handed over: locally owned + ghost cells (owner computes: every owned row is complete locally, no
+//     compress(add)).  Caveat, stated not solved: a cell that touches this rank only through a HANGING vertex whose
+//     parent is owned here is not guaranteed to be in deal.II's ghost layer; its contribution to that parent's row
+//     would be missing.  check_hanging_closure() below detects the situation from the constraint lines (a parent of a
+//     locally relevant hanging dof that is owned here while no local cell carries the hanging dof) and throws, so that
+//     such a mesh fails loudly instead of assembling a wrong row.
+//   * 32-bit limit: Epetra's local CSR has int offsets, pfm_pattern_bind_i32 takes them as they are; a block with more
+//     than 2^31-1 entries per rank cannot exist in Epetra either (the 216^3 single-rank (u,u) block has 2.48e9: such a
+//     run needs >= 2 ranks, or the library's own 64-bit pattern through pfm_pattern_get).
+#ifdef PFM_WITH_DEALII
+
+#include <deal.II/base/index_set.h>
+#include <deal.II/base/mpi.h>
+#include <deal.II/dofs/dof_handler.h>
+#include <deal.II/dofs/dof_tools.h>
+#include <deal.II/lac/affine_constraints.h>
+#include <deal.II/lac/trilinos_block_sparse_matrix.h>
+#include <deal.II/lac/trilinos_parallel_block_vector.h>
+
+#include <Epetra_CrsMatrix.h>
+#include <Epetra_Map.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <map>
+#include <set>
+#include <vector>
+
+extern "C"
+{
+#include "pfm_assemble.h"
+}
+
+namespace pfm_glue_detail
+{
+  using namespace dealii;
+  using gidx = types::global_dof_index;
+
+#define PFM_CALL(ctx, call)                                                                                     \
+  do                                                                                                            \
+    {                                                                                                           \
+      const int pfm_rc_ = (call);                                                                               \
+      AssertThrow(pfm_rc_ == PFM_OK, ExcMessage(std::string(#call) + ": " + ((ctx) ? pfm_last_error(ctx) : "no context")));   \
+    }                                                                                                           \
+  while (0)
+
+  template <int dim>
+  struct PfmGlue
+  {
+    pfm_ctx *ctx = nullptr;
+    void *comm = nullptr; // ncclComm_t, made once per program (collective)
+    int device = 0;
+    bool blocked = true; // PFM_LAYOUT_BLOCKED (iterative solver) / INTERLEAVED (direct solver), cracks.cc:1587-1590
+
+    // rank-local node numbering
+    std::map<gidx, int32_t> node_of_phi_dof; // global phase-field dof -> local node (owned first)
+    std::vector<gidx> phi_dof_of_node;       // inverse
+    int32_t n_owned = 0, n_nodes = 0;
+    // ghost import lists (node level), grouped by peer rank
+    std::vector<int> peer_ranks;
+    std::vector<int64_t> send_ptr, recv_ptr;
+    std::vector<int32_t> send_nodes, recv_nodes;
+    // device mirrors of the owned vectors and of the outputs
+    double *d_vec[3] = {nullptr, nullptr, nullptr}, *d_res[2] = {nullptr, nullptr}, *d_val[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t nnz[4] = {0, 0, 0, 0};
+    std::vector<double> h_vec[3], h_res[2];
+    std::vector<uint8_t> flags;
+
+    ~PfmGlue()
+    {
+      release();
+      if (comm)
+        pfm_comm_destroy(comm);
+    }
+
+    void release()
+    {
+      if (ctx)
+        pfm_ctx_destroy(ctx);
+      ctx = nullptr;
+      for (double *&p : d_vec)
+        {
+          if (p)
+            (void)hipFree(p);
+          p = nullptr;
+        }
+      for (double *&p : d_res)
+        {
+          if (p)
+            (void)hipFree(p);
+          p = nullptr;
+        }
+      for (double *&p : d_val)
+        {
+          if (p)
+            (void)hipFree(p);
+          p = nullptr;
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // setup_system() epilogue: mesh tables, hanging-node table, pattern bind, halo lists, communicator
+    template <class Problem>
+    void rebuild(Problem &P)
+    {
+      release();
+      const auto &dh = P.dof_handler;
+      const auto &fe = dh.get_fe();
+      const MPI_Comm mpi = P.mpi_com;
+      const unsigned int me = Utilities::MPI::this_mpi_process(mpi), n_ranks = Utilities::MPI::n_mpi_processes(mpi);
+      blocked = !P.direct_solver;
+      const unsigned int phi_comp = dim; // components 0..dim-1 = u, dim = phi (cracks.cc:980-996)
+      AssertThrow(fe.degree == 1 && fe.n_components() == dim + 1, ExcMessage("the GPU assembly is written for Q1/Q1 (FE degree 1)"));
+      const IndexSet &owned = dh.locally_owned_dofs();
+
+      // ---- 1. nodes: every vertex of a locally owned or ghost cell, keyed by its phase-field dof
+      std::set<gidx> owned_phi, ghost_phi;
+      for (const auto &cell : dh.active_cell_iterators())
+        if (cell->is_locally_owned() || cell->is_ghost())
+          for (unsigned int v = 0; v < GeometryInfo<dim>::vertices_per_cell; ++v)
+            {
+              const gidx g = cell->vertex_dof_index(v, phi_comp); // FESystem(FE_Q(1)^(dim+1)): vertex dof i = component i
+              (owned.is_element(g) ? owned_phi : ghost_phi).insert(g);
+            }
+      node_of_phi_dof.clear();
+      phi_dof_of_node.clear();
+      for (const gidx g : owned_phi)
+        {
+          node_of_phi_dof[g] = (int32_t)phi_dof_of_node.size();
+          phi_dof_of_node.push_back(g);
+        }
+      n_owned = (int32_t)phi_dof_of_node.size();
+      for (const gidx g : ghost_phi)
+        {
+          node_of_phi_dof[g] = (int32_t)phi_dof_of_node.size();
+          phi_dof_of_node.push_back(g);
+        }
+      n_nodes = (int32_t)phi_dof_of_node.size();
+
+      // ---- 2. cells and coordinates (deal.II vertex order = the order pfm_mesh_desc expects)
+      constexpr unsigned int nv = GeometryInfo<dim>::vertices_per_cell;
+      std::vector<int32_t> cell_nodes;
+      std::vector<double> coords((size_t)n_nodes * dim, 0.0);
+      std::vector<double> cell_lambda, cell_mu;
+      const bool het = P.test_case == Problem::TestCase::multiple_het;
+      for (const auto &cell : dh.active_cell_iterators())
+        if (cell->is_locally_owned() || cell->is_ghost())
+          {
+            for (unsigned int v = 0; v < nv; ++v)
+              {
+                const int32_t n = node_of_phi_dof.at(cell->vertex_dof_index(v, phi_comp));
+                cell_nodes.push_back(n);
+                for (unsigned int d = 0; d < dim; ++d)
+                  coords[(size_t)n * dim + d] = cell->vertex(v)[d];
+              }
+            if (het)
+              {
+                // cracks.cc:2207-2216: E from the bitmap at the cell centre, +1.0, nu = poisson_ratio_nu
+                const double E = P.func_emodulus->value(cell->center(), 0) + 1.0;
+                const double mu = E / (2.0 * (1.0 + P.poisson_ratio_nu));
+                cell_mu.push_back(mu);
+                cell_lambda.push_back(2.0 * P.poisson_ratio_nu * mu / (1.0 - 2.0 * P.poisson_ratio_nu));
+              }
+          }
+
+      // ---- 3. hanging nodes: constraints_hanging_nodes (cracks.cc:1630-1635) at node level; the lines of all
+      // components of a vertex are the same, the phase-field line is taken
+      std::vector<int32_t> hn_nodes, hn_parents;
+      std::vector<int64_t> hn_ptr(1, 0);
+      std::vector<double> hn_w;
+      for (int32_t n = 0; n < n_nodes; ++n)
+        {
+          const gidx g = phi_dof_of_node[n];
+          if (!P.constraints_hanging_nodes.is_constrained(g))
+            continue;
+          const auto *line = P.constraints_hanging_nodes.get_constraint_entries(g);
+          AssertThrow(line != nullptr && !line->empty(), ExcMessage("hanging-node line without entries"));
+          hn_nodes.push_back(n);
+          for (const auto &e : *line)
+            {
+              const auto it = node_of_phi_dof.find(e.first);
+              AssertThrow(it != node_of_phi_dof.end(), ExcMessage("parent of a hanging node is not a local node"));
+              hn_parents.push_back(it->second);
+              hn_w.push_back(e.second);
+            }
+          hn_ptr.push_back((int64_t)hn_parents.size());
+        }
+      check_hanging_closure(P, owned);
+
+      // ---- 4. context
+      pfm_mesh_desc m{};
+      m.dim = dim;
+      m.layout = blocked ? PFM_LAYOUT_BLOCKED : PFM_LAYOUT_INTERLEAVED;
+      m.n_nodes = n_nodes;
+      m.n_owned_nodes = n_owned;
+      m.n_cells = (int64_t)(cell_nodes.size() / nv);
+      m.cell_nodes = cell_nodes.data();
+      m.coords = coords.data();
+      m.cell_lambda = het ? cell_lambda.data() : nullptr;
+      m.cell_mu = het ? cell_mu.data() : nullptr;
+      m.n_hanging = (int32_t)hn_nodes.size();
+      m.hn_nodes = hn_nodes.data();
+      m.hn_ptr = hn_ptr.data();
+      m.hn_parents = hn_parents.data();
+      m.hn_weights = hn_w.data();
+      // box_cells stays 0: the library recognises a uniform box from the coordinates by itself
+      int n_dev = 0;
+      AssertThrow(hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0, ExcMessage("no HIP device"));
+      device = (int)(me % (unsigned int)n_dev);
+      PFM_CALL(ctx, pfm_ctx_create(&ctx, &m, device));
+
+      // ---- 5. the library adopts Trilinos' local CSR (cracks.cc:1644-1654): values[] is then written in Epetra's order
+      const unsigned int nb1 = blocked ? 2 : 1;
+      for (unsigned int r = 0; r < nb1; ++r)
+        for (unsigned int c = 0; c < nb1; ++c)
+          {
+            const Epetra_CrsMatrix &A = P.system_pde_matrix.block(r, c).trilinos_matrix();
+            int *rowptr = nullptr, *colind = nullptr;
+            double *values = nullptr;
+            AssertThrow(A.ExtractCrsDataPointers(rowptr, colind, values) == 0, ExcMessage("matrix storage is not optimised (FillComplete?)"));
+            const int n_rows = A.NumMyRows();
+            const int64_t n_entries = rowptr[n_rows];
+            // Epetra's local column id = position in ITS column map; translate once to the library's local numbering:
+            //   blocked: u column = node * dim + comp, phi column = node;   interleaved: node * (dim + 1) + comp
+            std::vector<int32_t> col_lib((size_t)n_entries);
+            const Epetra_BlockMap &cmap = A.ColMap();
+            std::vector<int32_t> lib_of_lid((size_t)cmap.NumMyElements());
+            for (int lid = 0; lid < cmap.NumMyElements(); ++lid)
+              lib_of_lid[lid] = local_column_of_global_dof(P, r, c, (gidx)cmap.GID64(lid));
+            for (int64_t e = 0; e < n_entries; ++e)
+              col_lib[e] = lib_of_lid[colind[e]];
+            const int block = blocked ? (int)(2 * r + c) : 0;
+            PFM_CALL(ctx, pfm_pattern_bind_i32(ctx, block, rowptr, col_lib.data()));
+            PFM_CALL(ctx, pfm_pattern_size(ctx, block, nullptr, &nnz[block]));
+            AssertThrow(nnz[block] == n_entries, ExcMessage("pattern size mismatch"));
+            AssertThrow(hipMalloc((void **)&d_val[block], sizeof(double) * (size_t)std::max<int64_t>(nnz[block], 1)) == hipSuccess,
+                        ExcMessage("hipMalloc (matrix values)"));
+          }
+
+      // ---- 6. ghost import lists (cracks.cc:2147-2154 at node level): who owns my ghost nodes, who needs my owned ones
+      // owner of a ghost dof: the locally owned ranges of all ranks (deal.II-knowledge: Utilities::MPI::all_gather of
+      // the IndexSets, or dh.compute_locally_owned_dofs_per_processor() in older versions)
+      const std::vector<IndexSet> owned_per_rank = Utilities::MPI::all_gather(mpi, owned);
+      std::map<int, std::vector<gidx>> want_from; // rank -> ghost phi dofs I need (ascending)
+      for (int32_t n = n_owned; n < n_nodes; ++n)
+        {
+          const gidx g = phi_dof_of_node[n];
+          int owner = -1;
+          for (unsigned int p = 0; p < n_ranks; ++p)
+            if (owned_per_rank[p].is_element(g))
+              {
+                owner = (int)p;
+                break;
+              }
+          AssertThrow(owner >= 0 && owner != (int)me, ExcMessage("ghost node without an owner"));
+          want_from[owner].push_back(g);
+        }
+      // tell every owner which of its nodes I need: some_to_some exchange of index lists
+      std::map<unsigned int, std::vector<gidx>> requests;
+      for (const auto &kv : want_from)
+        requests[(unsigned int)kv.first] = kv.second;
+      const std::map<unsigned int, std::vector<gidx>> asked = Utilities::MPI::some_to_some(mpi, requests);
+      std::set<int> peers;
+      for (const auto &kv : want_from)
+        peers.insert(kv.first);
+      for (const auto &kv : asked)
+        peers.insert((int)kv.first);
+      peer_ranks.assign(peers.begin(), peers.end());
+      send_ptr.assign(1, 0);
+      recv_ptr.assign(1, 0);
+      send_nodes.clear();
+      recv_nodes.clear();
+      for (const int p : peer_ranks)
+        {
+          const auto a = asked.find((unsigned int)p);
+          if (a != asked.end())
+            for (const gidx g : a->second) // the order the receiver listed them in = the order of its recv list
+              send_nodes.push_back(node_of_phi_dof.at(g));
+          send_ptr.push_back((int64_t)send_nodes.size());
+          const auto w = want_from.find(p);
+          if (w != want_from.end())
+            for (const gidx g : w->second)
+              recv_nodes.push_back(node_of_phi_dof.at(g));
+          recv_ptr.push_back((int64_t)recv_nodes.size());
+        }
+      PFM_CALL(ctx, pfm_halo_register(ctx, (int)peer_ranks.size(), send_ptr.data(), send_nodes.data(), recv_ptr.data(), recv_nodes.data()));
+
+      // ---- 7. one RCCL communicator for the life of the program (collective); the id travels over MPI
+      if (!comm && n_ranks > 1)
+        {
+          uint8_t id[PFM_COMM_ID_BYTES] = {0};
+          int ok = 1;
+          if (me == 0)
+            ok = pfm_comm_unique_id(id) == PFM_OK;
+          MPI_Bcast(&ok, 1, MPI_INT, 0, mpi);
+          AssertThrow(ok, ExcMessage("pfm_comm_unique_id failed on rank 0 (RCCL unavailable?)"));
+          MPI_Bcast(id, PFM_COMM_ID_BYTES, MPI_BYTE, 0, mpi);
+          PFM_CALL(ctx, pfm_comm_create(&comm, id, (int)n_ranks, (int)me, device));
+        }
+
+      // ---- 8. device mirrors of the owned vectors / outputs
+      const size_t nd = (size_t)n_owned * (dim + 1);
+      for (double *&p : d_vec)
+        AssertThrow(hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(nd, 1)) == hipSuccess, ExcMessage("hipMalloc (vectors)"));
+      for (double *&p : d_res)
+        AssertThrow(hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(nd, 1)) == hipSuccess, ExcMessage("hipMalloc (residuals)"));
+      for (auto &h : h_vec)
+        h.assign(nd, 0.0);
+      for (auto &h : h_res)
+        h.assign(nd, 0.0);
+      flags.assign((size_t)n_nodes, 0);
+    }
+
+    // library column id (within block (r, c)'s column space) of a global dof
+    template <class Problem>
+    int32_t local_column_of_global_dof(const Problem &P, unsigned int /*r*/, unsigned int c, gidx g_in_block) const
+    {
+      // global numbering: blocked = component_wise with blocks {u..u, phi} (cracks.cc:1587-1590): block 0 holds the
+      // u dofs node-interleaved (dim per node), block 1 the phi dofs; Epetra's block matrices index each block from 0.
+      // The node of a u dof (block 0): its phi dof is found through the vertex -> via the map below.
+      if (!blocked)
+        {
+          // interleaved: dof = (dim + 1) * vertex-rank + comp in the UNrenumbered enumeration; the phi dof of the same
+          // vertex is g - comp + dim
+          const unsigned int comp = (unsigned int)(g_in_block % (dim + 1));
+          const auto it = node_of_phi_dof.find(g_in_block - comp + dim);
+          AssertThrow(it != node_of_phi_dof.end(), ExcMessage("matrix column outside the local nodes"));
+          return it->second * (dim + 1) + (int32_t)comp;
+        }
+      if (c == 1) // phi column: block-local index -> global index = offset of block 1 + index
+        {
+          const auto it = node_of_phi_dof.find(P.n_u_dofs_global() + g_in_block);
+          AssertThrow(it != node_of_phi_dof.end(), ExcMessage("matrix column outside the local nodes"));
+          return it->second;
+        }
+      // u column: block-local index = dim * (global vertex rank) + comp; the same vertex rank indexes block 1
+      const unsigned int comp = (unsigned int)(g_in_block % dim);
+      const auto it = node_of_phi_dof.find(P.n_u_dofs_global() + g_in_block / dim);
+      AssertThrow(it != node_of_phi_dof.end(), ExcMessage("matrix column outside the local nodes"));
+      return it->second * dim + (int32_t)comp;
+    }
+
+    // see the caveat in the file header
+    template <class Problem>
+    void check_hanging_closure(const Problem &P, const IndexSet &owned) const
+    {
+      const IndexSet relevant = DoFTools::extract_locally_relevant_dofs(P.dof_handler);
+      for (const gidx g : relevant)
+        {
+          if (!P.constraints_hanging_nodes.is_constrained(g))
+            continue;
+          const auto *line = P.constraints_hanging_nodes.get_constraint_entries(g);
+          if (line == nullptr)
+            continue;
+          bool parent_owned = false;
+          for (const auto &e : *line)
+            parent_owned = parent_owned || owned.is_element(e.first);
+          // a hanging dof with an owned parent must sit on a local cell: its node is then in the map (phi dofs), or
+          // its vertex is (other components share the vertex)
+          if (parent_owned && P.is_phase_field_dof(g))
+            AssertThrow(node_of_phi_dof.count(g) == 1,
+                        ExcMessage("a hanging node with a locally owned parent lies on no local cell: owner-computes "
+                                   "would miss its contributions (glue/cracks_gpu_assemble.cc, header)"));
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // body of assemble_system(bool residual_only), cracks.cc:2129-2475
+    template <class Problem>
+    void assemble(Problem &P, const bool residual_only)
+    {
+      // scalars
+      pfm_params p{};
+      p.lambda = P.lame_coefficient_lambda;
+      p.mu = P.lame_coefficient_mu;
+      p.G_c = P.G_c;
+      p.alpha_eps = P.alpha_eps;
+      p.constant_k = P.constant_k;
+      p.pressure = P.func_pressure.value(Point<1>(P.time), 0); // cracks.cc:2145
+      p.alpha_biot = P.alpha_biot;
+      if (P.outer_solver == Problem::OuterSolverType::simple_monolithic && P.timestep_number < 1)
+        P.gamma_penal = 0.0; // the member side effect of cracks.cc:2141-2144
+      p.gamma_penal = P.gamma_penal;
+      p.timestep = P.timestep;
+      p.time = P.time;
+      p.old_timestep = P.old_timestep;
+      p.old_old_timestep = P.old_old_timestep;
+      p.decompose_stress_rhs = P.decompose_stress_rhs;
+      p.decompose_stress_matrix = P.decompose_stress_matrix;
+      p.timestep_number = (int32_t)P.timestep_number;
+      p.outer_solver = P.outer_solver == Problem::OuterSolverType::active_set ? PFM_SOLVER_ACTIVE_SET : PFM_SOLVER_SIMPLE_MONOLITHIC;
+      p.use_old_timestep_pf = P.use_old_timestep_pf ? 1 : 0;
+      PFM_CALL(ctx, pfm_set_params(ctx, &p));
+
+      // constraints_update minus the hanging-node lines: one flag byte per local node (cracks.cc:2442-2463)
+      std::fill(flags.begin(), flags.end(), (uint8_t)0);
+      for (int32_t n = 0; n < n_nodes; ++n)
+        for (unsigned int comp = 0; comp <= (unsigned int)dim; ++comp)
+          {
+            const gidx g = global_dof_of(P, n, comp);
+            if (P.constraints_update.is_constrained(g) && !P.constraints_hanging_nodes.is_constrained(g))
+              flags[(size_t)n] |= (uint8_t)(1u << comp);
+          }
+      PFM_CALL(ctx, pfm_set_constraints(ctx, flags.data()));
+
+      // owned values of the three vectors in the context's layout (the Epetra storage of a block is contiguous and in
+      // row-map order = ascending global index = the library's owned order; deal.II-knowledge)
+      const TrilinosWrappers::MPI::BlockVector *vec[3] = {&P.solution, &P.old_solution, &P.old_old_solution};
+      const size_t nd = (size_t)n_owned * (dim + 1);
+      for (int k = 0; k < 3; ++k)
+        {
+          gather_owned(*vec[k], h_vec[k]);
+          AssertThrow(hipMemcpy(d_vec[k], h_vec[k].data(), sizeof(double) * nd, hipMemcpyHostToDevice) == hipSuccess, ExcMessage("H2D"));
+        }
+      // ghost import (cracks.cc:2147-2154) + cell work; every rank calls the exchange (it is collective among peers)
+      PFM_CALL(ctx, pfm_state_set(ctx, d_vec[0], d_vec[1], d_vec[2], /*on_device=*/1));
+      if (comm)
+        PFM_CALL(ctx, pfm_halo_exchange(ctx, comm, peer_ranks.data()));
+      PFM_CALL(ctx, pfm_assemble_device(ctx, residual_only ? 1 : 0, d_val, d_res[0], d_res[1]));
+      const int rc = pfm_sync_status(ctx);
+      if (rc == PFM_ERR_NOT_ORTHOGONAL)
+        {
+          std::cout << "Seems not to be orthogonal" << std::endl; // cracks.cc:1734-1735
+          abort();
+        }
+      AssertThrow(rc == PFM_OK, ExcMessage(pfm_last_error(ctx)));
+
+      // results into the Trilinos objects (owned rows are complete: no compress(add), cracks.cc:2470-2475)
+      AssertThrow(hipMemcpy(h_res[0].data(), d_res[0], sizeof(double) * nd, hipMemcpyDeviceToHost) == hipSuccess, ExcMessage("D2H"));
+      scatter_owned(h_res[0], P.system_pde_residual);
+      if (residual_only)
+        {
+          AssertThrow(hipMemcpy(h_res[1].data(), d_res[1], sizeof(double) * nd, hipMemcpyDeviceToHost) == hipSuccess, ExcMessage("D2H"));
+          scatter_owned(h_res[1], P.system_total_residual);
+        }
+      else
+        {
+          const unsigned int nb1 = blocked ? 2 : 1;
+          for (unsigned int r = 0; r < nb1; ++r)
+            for (unsigned int c = 0; c < nb1; ++c)
+              {
+                const int block = blocked ? (int)(2 * r + c) : 0;
+                int *rowptr = nullptr, *colind = nullptr;
+                double *values = nullptr;
+                P.system_pde_matrix.block(r, c).trilinos_matrix().ExtractCrsDataPointers(rowptr, colind, values);
+                AssertThrow(hipMemcpy(values, d_val[block], sizeof(double) * (size_t)nnz[block], hipMemcpyDeviceToHost) == hipSuccess,
+                            ExcMessage("D2H (matrix values)"));
+              }
+        }
+      // the AMG set-up of cracks.cc:2477-2497 follows in the caller, unchanged
+    }
+
+    // global dof of (local node, component)
+    template <class Problem>
+    gidx global_dof_of(const Problem &P, int32_t n, unsigned int comp) const
+    {
+      const gidx gphi = phi_dof_of_node[(size_t)n];
+      if (!blocked)
+        return gphi - dim + comp; // interleaved: the dim + 1 dofs of a vertex are consecutive, phi last
+      if (comp == (unsigned int)dim)
+        return gphi;
+      return (gphi - P.n_u_dofs_global()) * dim + comp; // block 0: dim * vertex rank + comp
+    }
+
+    // owned dofs of a block vector -> the context's layout
+    void gather_owned(const TrilinosWrappers::MPI::BlockVector &v, std::vector<double> &out) const
+    {
+      if (blocked)
+        {
+          const auto &u = v.block(0), &phi = v.block(1);
+          AssertThrow((int64_t)u.locally_owned_size() == (int64_t)n_owned * dim && (int64_t)phi.locally_owned_size() == n_owned,
+                      ExcMessage("owned sizes do not match the node count"));
+          std::copy(u.begin(), u.end(), out.begin());                                // dim * node + comp
+          std::copy(phi.begin(), phi.end(), out.begin() + (size_t)n_owned * dim);  // n_owned * dim + node
+        }
+      else
+        {
+          const auto &b = v.block(0);
+          AssertThrow((int64_t)b.locally_owned_size() == (int64_t)n_owned * (dim + 1), ExcMessage("owned size does not match the node count"));
+          std::copy(b.begin(), b.end(), out.begin()); // (dim + 1) * node + comp
+        }
+    }
+    void scatter_owned(const std::vector<double> &in, TrilinosWrappers::MPI::BlockVector &v) const
+    {
+      if (blocked)
+        {
+          std::copy(in.begin(), in.begin() + (size_t)n_owned * dim, v.block(0).begin());
+          std::copy(in.begin() + (size_t)n_owned * dim, in.end(), v.block(1).begin());
+        }
+      else
+        std::copy(in.begin(), in.end(), v.block(0).begin());
+    }
+  };
+#undef PFM_CALL
+} // namespace pfm_glue_detail
+
+// Two one-line helpers the glue asks of the problem class (add to FracturePhaseFieldProblem<dim>):
+//   types::global_dof_index n_u_dofs_global() const { return dof_handler.n_dofs() / (dim + 1) * dim; }   // = n_solid of cracks.cc:1606 (Q1/Q1: dim + 1 dofs per vertex)
+//   bool is_phase_field_dof(types::global_dof_index g) const
+//   { return direct_solver ? (g % (dim + 1) == dim) : (g >= n_u_dofs_global()); }
+//
+// and the two call sites:
+//   setup_system():            ... diag mass (cracks.cc:1675);  pfm_glue.rebuild(*this);
+//   assemble_system(bool ro):  pfm_glue.assemble(*this, ro);  if (!direct_solver && !ro) { AMG set-up, cracks.cc:2477-2497 }
+
+#endif // PFM_WITH_DEALII
