@@ -1,7 +1,8 @@
 // pfm_cart2d.hip — 2-D row-owner kernel for uniform Cartesian boxes: Jacobian + residual (cracks.cc:2200-2464) of the
 // 2-D Sneddon configurations (tests/sneddon_2d_1.prm on a uniform mesh, BASELINE config 2 with the matrix).  Runs with
-// the stress split of cracks.cc:2294 active stay on the general family (the routine below is written for both, but the
-// split variant of the kernel needs > 512 registers).
+// the stress split of cracks.cc:2294 active stay on the general family: a row owner would evaluate the linearised split
+// of every trial dof 12 times (4 cells around the node x 3 row components to fit the registers) where the general
+// family's quad evaluates it once (pfm_kernels.hip); the launcher refuses them and the host routes them there.
 //
 // Work is assigned by output row: thread <-> owned node.  The thread visits the (up to) 4 cells around its node and
 // integrates, per cell, only the 3 rows of its own vertex -- the loop body of cracks.cc:2308-2432 for j = (a, c) -- into
@@ -10,12 +11,10 @@
 // Every q-point state is evaluated by the 4 threads around the cell (4x redundant; in 2-D the state is ~60 flops, the
 // entries ~400 per q-point) -- the price for not staging anything: the kernel has no LDS and no barrier.
 //
-// The 3-D family (pfm_cart_uu3/phi4) sum-factorises the element matrix; here, with the split active, the entries are NOT
-// polynomial moments of g(q) (sigma+-(u) and its linearisation are piecewise in the eigenvalues), so the kernel integrates
-// the reference's formulas directly.
+// The 3-D family (pfm_cart_uu3/phi4) sum-factorises the element matrix; this kernel integrates the reference's formulas
+// directly (9 q-points, the unsplit law written out).
 #include "pfm_internal.h"
 #include "pfm_cart_common.h"
-#include "pfm_split.h"
 
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -37,16 +36,15 @@ namespace pfm
 
     struct Prm2 // resolved scalars
     {
-      double lam, mu, kappa, eps, Gc, p, aB1, penal_fac, tfac, d_rhs, d_mat, ihx, ihy, vol;
+      double lam, mu, kappa, eps, Gc, p, aB1, penal_fac, tfac, ihx, ihy, vol;
       int monolithic, use_old;
     };
 
     // Rows of vertex A of one cell: the general kernel's loop body (pfm_kernels.hip: k_assemble_general) for constant
     // geometry J = diag(h).  Sink receives uu(b, c, d, x), pu(b, d, x), pp(b, x), r(c, x).
-    template <int A, bool FULL, bool SPLIT, class Sink>
-    __device__ __forceinline__ bool cell_rows2d(const Cell2 &C, const Prm2 &P, Sink &out)
+    template <int A, bool FULL, class Sink>
+    __device__ __forceinline__ void cell_rows2d(const Cell2 &C, const Prm2 &P, Sink &out)
     {
-      bool ortho_ok = true;
 #pragma unroll 1
       for (int q = 0; q < 9; ++q)
         {
@@ -103,20 +101,12 @@ namespace pfm
                 E[i][j] = 0.5 * (gu[i][j] + gu[j][i]);
               trE += E[i][i];
             }
-          double sp[2][2], sm[2][2];
-          if constexpr (SPLIT)
-            ortho_ok &= split_stress(E, trE, C.lam, C.mu, sp, sm);
-          else
-            {
+          double sp[2][2]; // sigma+ = lambda tr(E) I + 2 mu E, sigma- = 0 (no split: cracks.cc:2299-2305)
 #pragma unroll
-              for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                  {
-                    sp[i][j] = C.lam * trE * (i == j ? 1.0 : 0.0) + 2 * C.mu * E[i][j];
-                    sm[i][j] = 0.0;
-                  }
-            }
+            for (int j = 0; j < 2; ++j)
+              sp[i][j] = C.lam * trE * (i == j ? 1.0 : 0.0) + 2 * C.mu * E[i][j];
           double spE = 0.0;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -125,7 +115,7 @@ namespace pfm
               spE += sp[i][j] * E[i][j];
 
           // ---- Jacobian rows of vertex A, cracks.cc:2308-2389
-          if constexpr (FULL && !SPLIT)
+          if constexpr (FULL)
             {
               // unsplit law with the tensors written out (see k_assemble_general): the linearised stress of trial dof
               // (b, d) against the test gradient is  lambda gN_b[d] gN_a[c] + mu (gN_b[c] gN_a[d] + delta_cd gN_b.gN_a),
@@ -152,82 +142,15 @@ namespace pfm
                 out.pp(std::integral_constant<int, b>{}, cpen * (pen_on ? N[b] : 0.0) + ((cpp - cdu) * N[b] + cgg * t));
               });
             }
-          if constexpr (FULL && SPLIT)
-            {
-              static_for<4>([&](auto Bb) __attribute__((always_inline)) {
-                constexpr int b = decltype(Bb)::value;
-                const double Nb = N[b];
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-                  {
-                    double EL[2][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                      for (int j = 0; j < 2; ++j)
-                        EL[i][j] = 0.5 * ((i == d ? gN[b][j] : 0.0) + (j == d ? gN[b][i] : 0.0));
-                    const double trEL = gN[b][d];
-                    double spL[2][2], smL[2][2];
-                    if constexpr (SPLIT)
-                      ortho_ok &= split_stress_lin(E, trE, EL, trEL, C.lam, C.mu, spL, smL);
-                    else
-                      {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                          for (int j = 0; j < 2; ++j)
-                            {
-                              spL[i][j] = C.lam * trEL * (i == j ? 1.0 : 0.0) + 2 * C.mu * EL[i][j];
-                              smL[i][j] = 0.0;
-                            }
-                      }
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                      {
-                        double t = 0.0, tm = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 2; ++k)
-                          {
-                            t += g * spL[c][k] * gNa[k];
-                            tm += smL[c][k] * gNa[k];
-                          }
-                        out.uu(std::integral_constant<int, b>{}, c, d, (t + P.d_mat * tm) * JxW);
-                      }
-                    double spLE = 0.0, spEL = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                      for (int j = 0; j < 2; ++j)
-                        {
-                          spLE += spL[i][j] * E[i][j];
-                          spEL += sp[i][j] * EL[i][j];
-                        }
-                    out.pu(std::integral_constant<int, b>{}, d,
-                           ((1 - P.kappa) * (spLE + spEL) * pf * Na - 2.0 * P.aB1 * P.p * (pf * trEL) * Na) * JxW);
-                  }
-                {
-                  const double pen_i = ((pf - pfo) < 0.0) ? 0.0 : Nb; // shadowed variable, cracks.cc:2311-2315
-                  const double gg = gN[b][0] * gNa[0] + gN[b][1] * gNa[1];
-                  double x = P.penal_fac * pen_i * Na * JxW;
-                  x += ((1 - P.kappa) * spE * Nb * Na + P.Gc / P.eps * Nb * Na + P.Gc * P.eps * gg -
-                        2.0 * P.aB1 * P.p * (Nb * divu) * Na) *
-                       JxW;
-                  out.pp(std::integral_constant<int, b>{}, x);
-                }
-              });
-            }
           // ---- residual rows of vertex A, cracks.cc:2393-2432
 #pragma unroll
           for (int c = 0; c < 2; ++c)
             {
-              double t = 0.0, tm = 0.0;
+              double t = 0.0;
 #pragma unroll
               for (int k = 0; k < 2; ++k)
-                {
-                  t += g * sp[c][k] * gNa[k];
-                  tm += sm[c][k] * gNa[k];
-                }
-              out.r(c, -(t + P.d_rhs * tm - P.aB1 * P.p * pfx * pfx * gNa[c]) * JxW);
+                t += g * sp[c][k] * gNa[k];
+              out.r(c, -(t - P.aB1 * P.p * pfx * pfx * gNa[c]) * JxW);
             }
           {
             const double gg = gpf[0] * gNa[0] + gpf[1] * gNa[1];
@@ -238,7 +161,6 @@ namespace pfm
             out.r(2, x);
           }
         }
-      return ortho_ok;
     }
 
     // sum of |diagonal| of the rows of vertex A (mean |diagonal| of the element matrix: deal.II's placeholder when a
@@ -265,14 +187,13 @@ namespace pfm
       __device__ void r(int, double) {}
     };
 
-    template <bool SPLIT>
     __device__ __forceinline__ double element_mean_abs_diag(const Cell2 &C, const Prm2 &P)
     {
       double s = 0.0;
       static_for<4>([&](auto Aa) __attribute__((always_inline)) {
         DiagSink2 ds;
         ds.a = decltype(Aa)::value;
-        (void)cell_rows2d<decltype(Aa)::value, true, SPLIT>(C, P, ds);
+        cell_rows2d<decltype(Aa)::value, true>(C, P, ds);
         s += fabs(ds.d[0]) + fabs(ds.d[1]) + fabs(ds.d[2]);
       });
       return s / 12.0;
@@ -312,7 +233,7 @@ namespace pfm
       __device__ __forceinline__ void r(int c, double x) { R[c] += x; }
     };
 
-    template <bool FULL, bool SPLIT>
+    template <bool FULL>
     __global__ __launch_bounds__(128) void k_cart2d_rows(DevView v, CartView cv, Prm2 P, Vals2 vals, double *__restrict__ res_pde,
                                                          double *__restrict__ res_tot, int write_total, int total_via_update)
     {
@@ -334,8 +255,6 @@ namespace pfm
             for (int c = 0; c < 3; ++c)
               acc[o][c][0] = acc[o][c][1] = acc[o][c][2] = 0.0;
         }
-      bool ortho_ok = true;
-
       // the 4 cells around the node, in the order of a lexicographic cell loop: the node is vertex A = 3, 2, 1, 0 of them
       static_for<4>([&](auto Ee) __attribute__((always_inline)) {
         constexpr int A = 3 - decltype(Ee)::value, ax = A & 1, ay = A >> 1;
@@ -363,7 +282,7 @@ namespace pfm
         RowSink2<A> sink;
         sink.acc = acc;
         sink.R = R;
-        ortho_ok &= cell_rows2d<A, FULL, SPLIT>(C, P, sink);
+        cell_rows2d<A, FULL>(C, P, sink);
         if constexpr (FULL)
           {
             if (fP & 7u) // a constrained row needs its placeholder: sum_e (|K_e,aa| != 0 ? |K_e,aa| : mean |diag K_e|)
@@ -371,16 +290,13 @@ namespace pfm
                 const double k0 = fabs(sink.kd[0]), k1 = fabs(sink.kd[1]), k2 = fabs(sink.kd[2]);
                 double avg = 0.0;
                 if (((fP & 1u) && k0 == 0.0) || ((fP & 2u) && k1 == 0.0) || ((fP & 4u) && k2 == 0.0))
-                  avg = element_mean_abs_diag<SPLIT>(C, P);
+                  avg = element_mean_abs_diag(C, P);
                 dg[0] += k0 != 0.0 ? k0 : avg;
                 dg[1] += k1 != 0.0 ? k1 : avg;
                 dg[2] += k2 != 0.0 ? k2 : avg;
               }
           }
       });
-      if (!ortho_ok)
-        atomicMax(v.status, (int)PFM_ERR_NOT_ORTHOGONAL);
-
       // ---- constrained scatter as masks (cracks.cc:2439-2464)
       const bool blocked = v.layout == PFM_LAYOUT_BLOCKED;
 #pragma unroll
@@ -437,8 +353,8 @@ namespace pfm
     }
   } // namespace
 
-  // 2-D cartesian boxes: Jacobian + residual (or residual only when the split is active: the plain 2-D residual has its
-  // own kernel in pfm_cart.hip)
+  // 2-D cartesian boxes: Jacobian + residual without the stress split (the plain 2-D residual has its own kernel in
+  // pfm_cart.hip)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
                     double *res_pde, double *res_tot, hipStream_t s)
   {
@@ -459,8 +375,6 @@ namespace pfm
     P.penal_fac = gamma / p.timestep * 1.0 / (cv.h[0] * cv.h[0] + cv.h[1] * cv.h[1]); // cell->diameter()^2, cracks.cc:2370
     P.tfac = (p.time - (p.time - p.old_timestep - p.old_old_timestep)) /
              (p.time - p.old_timestep - (p.time - p.old_timestep - p.old_old_timestep));
-    P.d_rhs = p.decompose_stress_rhs;
-    P.d_mat = p.decompose_stress_matrix;
     P.ihx = 1.0 / cv.h[0];
     P.ihy = 1.0 / cv.h[1];
     P.vol = cv.h[0] * cv.h[1];
@@ -476,14 +390,13 @@ namespace pfm
     const unsigned nb = (unsigned)((n + 127) / 128);
     if (nb == 0)
       return PFM_OK;
-#define PFM_L2D(F, SP) hipLaunchKernelGGL((k_cart2d_rows<F, SP>), dim3(nb), dim3(128), 0, s, v, cv, P, vals, res_pde, res_tot, residual_only, total_via_update)
+#define PFM_L2D(F) hipLaunchKernelGGL((k_cart2d_rows<F>), dim3(nb), dim3(128), 0, s, v, cv, P, vals, res_pde, res_tot, residual_only, total_via_update)
     if (split)
-      return PFM_ERR_UNSUPPORTED; // with the split the 81 accumulators + the linearised split exceed the register file
-                                  // (416 spilled registers): those runs stay on the general family (pfm_host.cpp)
+      return PFM_ERR_UNSUPPORTED; // stress-split runs stay on the general family (header of this file, pfm_host.cpp)
     if (residual_only)
-      PFM_L2D(false, false);
+      PFM_L2D(false);
     else
-      PFM_L2D(true, false);
+      PFM_L2D(true);
 #undef PFM_L2D
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }

@@ -89,7 +89,7 @@ namespace pfm
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
                            hipStream_t s_residual, void *d_scal);
   bool cart_matrix_supported(int dim);
-  // 2-D boxes: row-owner Jacobian + residual, stress split included (pfm_cart2d.hip)
+  // 2-D boxes: row-owner Jacobian + residual of runs WITHOUT the stress split (pfm_cart2d.hip; PFM_ERR_UNSUPPORTED otherwise)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
                     double *res_pde, double *res_tot, hipStream_t s);
   // z-chunk length of a marching kernel: `tiles` columns, `planes` node planes, one redundant cell layer per chunk,

@@ -85,12 +85,6 @@ def test_both_layouts(dim, blocked):
     _full_parity(c2)
 
 
-def test_stress_split_active():
-    c = cases.perturbed(cases.kat_miehe_shear_1(), u_amp=2e-3)
-    c.params.timestep_number = 1  # cracks.cc:2294, 2338
-    _full_parity(c, tol=1e-11)
-
-
 def test_active_set_lines_and_monolithic_penalty():
     c = cases.perturbed(cases.kat_sneddon_2d())
     # put a few phase-field dofs into the active set (cracks.cc:2878-2879)
