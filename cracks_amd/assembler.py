@@ -12,6 +12,7 @@ reference throws / aborts).  All arithmetic happens in the HIP library behind th
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -188,6 +189,15 @@ class Context:
                                                  C.c_void_p(res_pde_ptr), C.c_void_p(res_tot_ptr)),
                     "pfm_assemble_device")
 
+    def assemble_overlapped(self, comm_handle: int, peer_ranks, residual_only: bool, value_ptrs: Sequence[int], res_pde_ptr: int,
+                            res_tot_ptr: int):
+        """``pfm_assemble_overlapped``: ghost import on the context's side stream next to the interior tiles."""
+        pr = np.ascontiguousarray(peer_ranks, np.int32)
+        arr = (C.c_void_p * 4)(*[C.c_void_p(p) for p in list(value_ptrs) + [0] * (4 - len(value_ptrs))])
+        self._check(self.lib.pfm_assemble_overlapped(self._h, C.c_void_p(comm_handle), capi.np_ptr(pr, np.int32) if pr.size else None,
+                                                     1 if residual_only else 0, arr, C.c_void_p(res_pde_ptr),
+                                                     C.c_void_p(res_tot_ptr)), "pfm_assemble_overlapped")
+
     def sync_status(self):
         self._check(self.lib.pfm_sync_status(self._h), "pfm_sync_status")
 
@@ -234,6 +244,10 @@ class Context:
 
     def force_path(self, path: int):
         self._check(self.lib.pfm_ctx_force_path(self._h, path), "pfm_ctx_force_path")
+
+    def force_phase(self, phase: int):
+        """measurement: 1 / 2 = only the first / second half of the overlapped assembly, 0 = all."""
+        self._check(self.lib.pfm_ctx_force_phase(self._h, phase), "pfm_ctx_force_phase")
 
     @property
     def device_bytes(self) -> int:
@@ -328,12 +342,21 @@ class Assembler:
         else:
             self.ctx.state_set_device(self.solution.data_ptr(), self.old_solution.data_ptr(),
                                       self.old_old_solution.data_ptr())
-        if self.halo is not None:
-            self.halo.exchange(self.ctx)
         if not residual_only:
             self.allocate_matrix()
-        self.ctx.assemble_device(residual_only, [m.data_ptr() for m in self.system_pde_matrix] if not residual_only else [],
-                                 self.system_pde_residual.data_ptr(), self.system_total_residual.data_ptr())
+        ptrs = [m.data_ptr() for m in self.system_pde_matrix] if not residual_only else []
+        # PFM_OVERLAP=1: the ghost import on the context's side stream next to the interior tiles.  Off by default: on one
+        # node the import is ~0.05 ms (pack + unpack 0.02 ms measured, ~7 messages of <= 0.6 MB over xGMI) while cutting
+        # the first kernel into an interior and a boundary launch costs 0.12 ms at 8 ranks (profiles/r03/rank_share_w8.json)
+        lib_comm = self.halo.library_comm(self.ctx) if (self.halo is not None and os.environ.get("PFM_OVERLAP") == "1") else None
+        if lib_comm is not None:
+            # one library call: exchange on the side stream || interior tiles, then the tiles that read ghost nodes
+            self.ctx.assemble_overlapped(lib_comm, self.halo.peers, residual_only, ptrs, self.system_pde_residual.data_ptr(),
+                                         self.system_total_residual.data_ptr())
+            return
+        if self.halo is not None:
+            self.halo.exchange(self.ctx)
+        self.ctx.assemble_device(residual_only, ptrs, self.system_pde_residual.data_ptr(), self.system_total_residual.data_ptr())
 
     def assemble_nl_residual(self, solution_only: bool = False):
         """cracks.cc:2507-2512."""

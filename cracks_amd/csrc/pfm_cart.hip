@@ -133,6 +133,12 @@ namespace pfm
       const int k = dim == 3 ? cv.o0[2] + (int)(rowid / OWY) : 0;
       const int xi = chunk * 63 + lane - 1; // lane 0 is the halo lane of the chunk
       const int i = cv.o0[0] + xi;
+      {
+        const int iA = cv.o0[0] + chunk * 63;
+        if (cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, iA - 1, iA + 63) || cart_range_has_ghost(cv, 1, j - 1, j + 1) ||
+                                      (dim == 3 && cart_range_has_ghost(cv, 2, k - 1, k + 1))))
+          return; // overlapped assembly: the other launch owns this wave's chunk
+      }
 
       const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = dim == 3 ? 1.0 / cv.h[2] : 0.0;
       const double vol = cv.h[0] * cv.h[1] * (dim == 3 ? cv.h[2] : 1.0);
@@ -363,6 +369,11 @@ namespace pfm
       const int i = cv.o0[0] + tix * R2N - 1 + lane; // this lane's node column = left vertex of its cell column
       const int jA = cv.o0[1] + chunk * zc;
       const int jB = min(jA + zc, cv.o1[1] + 1); // node rows [jA, jB)
+      {
+        const int iA = cv.o0[0] + tix * R2N;
+        if (cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, iA - 1, iA + R2N) || cart_range_has_ghost(cv, 1, jA - 1, jB)))
+          return; // overlapped assembly: the other launch owns this wave's chunk
+      }
       const bool node_in = i >= 0 && i < cv.NX;
       const bool col_ok = lane < 63 && i >= 0 && i < cv.NX - 1;
       const bool owner = lane >= 1 && lane <= R2N && i <= cv.o1[0];
@@ -571,13 +582,23 @@ namespace pfm
       const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + RNX - 1) / RNX, nty = (OWY + RNY - 1) / RNY;
-      const int bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); // XCD-aware launch, pfm_internal.h
+      int bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); // XCD-aware launch, pfm_internal.h
+      const bool listed = cv.tile_sel == 2 && cv.bnd_res3 != nullptr && cv.zc_res3 == zc; // compact launch over the boundary tiles
+      if (listed)
+        {
+          if (bid >= cv.n_bnd_res3)
+            return;
+          bid = cv.bnd_res3[bid];
+        }
       if (bid >= ntx * nty * ((cv.o1[2] - cv.o0[2] + zc) / zc))
         return;
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * RNX, j0 = cv.o0[1] + tiy * RNY;
       const int kA = cv.o0[2] + chunk * zc;
       const int kB = min(kA + zc, cv.o1[2] + 1); // node planes [kA, kB)
+      if (!listed && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i0 - 1, i0 + RNX) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + RNY) ||
+                                               cart_range_has_ghost(cv, 2, kA - 1, kB)))
+        return; // overlapped assembly: the other launch owns this tile column chunk
       const int ci = i0 - 1 + cx, cj = j0 - 1 + cy;
       const bool col_ok = ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1;
       const bool node_ok = cx < RNX && cy < RNY && (i0 + cx) <= cv.o1[0] && (j0 + cy) <= cv.o1[1];
@@ -843,7 +864,7 @@ namespace pfm
   } // namespace
 
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values,
-                         hipStream_t s, void *d_scal, double *res_pde);
+                         hipStream_t s, void *d_scal, double *res_pde, int phase);
 
   int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu)
   {
@@ -868,9 +889,11 @@ namespace pfm
     return best;
   }
 
-  int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
+  // phase: 0 = the whole assembly; 1 / 2 = the two halves of pfm_assemble_overlapped: 1 launches what reads no ghost
+  // node (the "interior" tiles of the first kernel of the sequence), 2 the rest -- the ghost import lands in between
+  int launch_assemble_cart(const DevView &v, const CartView &cv_in, const pfm_params &p, int residual_only,
                            double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
-                           hipStream_t s_residual, void *d_scal)
+                           hipStream_t s_residual, void *d_scal, int phase)
   {
     // the residual and the Jacobian only read the node state: on different streams they overlap
     // (s_residual == s: plain stream order)
@@ -882,6 +905,8 @@ namespace pfm
     const bool split = p.decompose_stress_matrix > 0 && p.timestep_number > 0; // cracks.cc:2294
     if (split)
       return PFM_ERR_UNSUPPORTED; // the host routes split runs to the general path
+    CartView cv = cv_in;
+    cv.tile_sel = phase; // 0: all tiles, 1: interior, 2: boundary -- of the FIRST kernel of the sequence only (below)
     if (v.dim == 2 && !residual_only)
       return launch_cart2d(v, cv, p, residual_only, d_values, res_pde, res_tot, s); // 2-D Jacobian + residual
     const Scal S = make_scal(p, cv, v.dim);
@@ -893,7 +918,7 @@ namespace pfm
     const bool rows_residual = v.dim == 3 && !residual_only && !S.monolithic && S.gamma_fac == 0.0 && S.kappa < 0.5 && !res_kernel_forced &&
                                !cv.cell_lam; // (the heterogeneous (u,u) variant has no registers left for it)
     if (rows_residual)
-      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, res_pde);
+      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, res_pde, phase);
     const int bs = 256;
     const long long OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = v.dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
     const long long n_waves = OWY * OWZ * ((OWX + 62) / 63);
@@ -922,17 +947,43 @@ namespace pfm
         static const int zc_force = getenv("PFM_RES_ZC") ? atoi(getenv("PFM_RES_ZC")) : 0; // tuning only
         const int zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, (int)OWZ, 4, 24, 2);
         const int nch = (int)((OWZ + zc - 1) / zc);
-        if (!S.monolithic && S.gamma_fac == 0.0)
-          hipLaunchKernelGGL(k_cart_residual3<true>, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S,
-                             res_pde, res_tot, residual_only, zc);
+        const bool listed = cv.tile_sel == 2 && cv.bnd_res3 != nullptr && cv.zc_res3 == zc;
+        const unsigned nt = listed ? (unsigned)cv.n_bnd_res3 : (unsigned)(ntx * nty * nch);
+        if (nt == 0)
+          ;
+        else if (!S.monolithic && S.gamma_fac == 0.0)
+          hipLaunchKernelGGL(k_cart_residual3<true>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
         else
-          hipLaunchKernelGGL(k_cart_residual3<false>, dim3(xcd_grid((unsigned)(ntx * nty * nch))), dim3(RTX * RTY), 0, s, v, cv, S,
-                             res_pde, res_tot, residual_only, zc);
+          hipLaunchKernelGGL(k_cart_residual3<false>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
       }
     if (hipGetLastError() != hipSuccess)
       return PFM_ERR_HIP;
-    if (!residual_only)
-      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, nullptr);
+    // the residual kernel was the first of the sequence (and the one split into interior / boundary tiles): the Jacobian
+    // kernels follow it completely, in the second phase of an overlapped assembly
+    if (!residual_only && phase != 1)
+      return launch_cart_matrix(v, cv_in, p, d_values, s_jac, d_scal, nullptr, 0);
     return PFM_OK;
+  }
+} // namespace pfm
+namespace pfm
+{
+  void cart_res3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out, int &zc)
+  {
+    out.clear();
+    const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+    const int ntx = (OWX + RNX - 1) / RNX, nty = (OWY + RNY - 1) / RNY;
+    static const int zc_force = getenv("PFM_RES_ZC") ? atoi(getenv("PFM_RES_ZC")) : 0; // as launch_assemble_cart
+    zc = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 4, 24, 2);
+    const int nch = (OWZ + zc - 1) / zc;
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tiy = 0; tiy < nty; ++tiy)
+        for (int tix = 0; tix < ntx; ++tix)
+          {
+            const int i0 = cv.o0[0] + tix * RNX, j0 = cv.o0[1] + tiy * RNY, kA = cv.o0[2] + ch * zc;
+            const int kB = std::min(kA + zc, cv.o1[2] + 1);
+            if (cart_range_has_ghost(cv, 0, i0 - 1, i0 + RNX) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + RNY) ||
+                cart_range_has_ghost(cv, 2, kA - 1, kB))
+              out.push_back(tix + ntx * (tiy + nty * ch));
+          }
   }
 } // namespace pfm

@@ -242,6 +242,8 @@ namespace pfm
       if (id >= (long long)OWX * OWY)
         return;
       const int i = cv.o0[0] + (int)(id % OWX), j = cv.o0[1] + (int)(id / OWX);
+      if (cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
+        return; // overlapped assembly: the other launch owns this node's rows
       const int row = cart_local_id(cv, i, j, 0);
       const unsigned fP = v.node_flags[row];
 

@@ -1037,22 +1037,34 @@ namespace pfm
 
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
   // (same stream) and clears the structurally zero (u,phi) block (cracks.cc:2333-2337) along with its (phi,u) stores
-  int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values, hipStream_t s,
-                         void *d_scal, double *res_pde)
+  int launch_cart_matrix(const DevView &v, const CartView &cv_in, const pfm_params &p, double *const *d_values, hipStream_t s,
+                         void *d_scal, double *res_pde, int phase)
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
     // (u,u) kernel: k_cart_uu3 (tile per plane); PFM_UU5=1: the z-march of round 3 (pfm_cart_uu5.hip); PFM_UU4=1: the
     // z-march of round 2 (no residual rows, no heterogeneous material)
     static const int uu_sel = getenv("PFM_UU5") ? 5 : (getenv("PFM_UU4") ? 4 : 3);
+    // phase 1 / 2 of an overlapped assembly: the (u,u) kernel is cut into interior and boundary tiles (CartView::tile_sel),
+    // the phase-field kernel follows completely in phase 2 -- it patches (u,u) diagonals of constrained rows and must see
+    // every (u,u) tile written, and the ghost import (~0.1 ms) is hidden behind the interior (u,u) tiles alone
+    CartView cv = cv_in;
+    cv.tile_sel = 0;
+    const bool cut = phase != 0 && (uu_sel == 3 || cv.cell_lam);
+    if (phase == 1 && !cut)
+      return PFM_OK; // the marching variants are not cut: everything in phase 2
     int rc;
     if (uu_sel == 5 && !cv.cell_lam)
       rc = launch_cart_uu5(v, cv, p, d_values[0], s, d_scal, res_pde);
     else if (uu_sel == 4 && !cv.cell_lam && !res_pde)
       rc = launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
     else
-      rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde);
-    if (rc)
+      {
+        cv.tile_sel = cut ? phase : 0;
+        rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde);
+        cv.tile_sel = 0;
+      }
+    if (rc || phase == 1)
       return rc;
     return launch_cart_phi4(v, cv, p, d_values, s, d_scal, res_pde);
   }

@@ -280,11 +280,21 @@ namespace pfm
       const int t = threadIdx.x;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
       const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
-      const int bid = xcd_tile_index();
+      int bid = xcd_tile_index();
+      const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr; // compact launch over the boundary tiles
+      if (listed)
+        {
+          if (bid >= cv.n_bnd_uu3)
+            return;
+          bid = cv.bnd_uu3[bid];
+        }
       if (bid >= ntx * nty * (cv.o1[2] - cv.o0[2] + 1))
         return; // padding of the XCD-aware grid
       const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
       const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
+      if (!listed && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i0 - 1, i0 + T3X) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + T3Y) ||
+                                               cart_range_has_ghost(cv, 2, k - 1, k + 1)))
+        return; // overlapped assembly: the other launch owns this tile
 
       // ---- phase 0: nodal halo + CSR row info (flags of the tile are collected per wave: no atomics, no init barrier)
       stamp(0);
@@ -729,7 +739,10 @@ namespace pfm
     const MatScal *S = static_cast<const MatScal *>(d_scal);
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
-    const unsigned nb = (unsigned)(ntx * nty * OWZ);
+    const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr;
+    const unsigned nb = listed ? (unsigned)cv.n_bnd_uu3 : (unsigned)(ntx * nty * OWZ);
+    if (nb == 0)
+      return PFM_OK;
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
 #define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, 0, s, v, cv, S, vals_uu, nullptr, res_pde)
@@ -779,6 +792,22 @@ namespace pfm
 #undef PFM_UU3
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
+  void cart_uu3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out)
+  {
+    out.clear();
+    const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+    const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
+    for (int tk = 0; tk < OWZ; ++tk)
+      for (int tiy = 0; tiy < nty; ++tiy)
+        for (int tix = 0; tix < ntx; ++tix)
+          {
+            const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
+            if (cart_range_has_ghost(cv, 0, i0 - 1, i0 + T3X) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + T3Y) ||
+                cart_range_has_ghost(cv, 2, k - 1, k + 1))
+              out.push_back(tix + ntx * (tiy + nty * tk));
+          }
+  }
+
   // entry point used by the debug overlay (pfm_ctx_force_path(ctx, 2)) and by launch_cart_matrix
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)

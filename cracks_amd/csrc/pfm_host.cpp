@@ -1543,8 +1543,39 @@ extern "C"
     return halo_exchange_on(c, comm, peer_ranks, c->stream);
   }
 
-  int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values,
-                          double *d_res_pde, double *d_res_tot)
+  // phase 2 of pfm_assemble_overlapped launches only the tiles that read ghost nodes: their indices, once per context
+  static int ensure_overlap_lists(pfm_ctx *c)
+  {
+    if (c->overlap_lists_ready || c->kernel_path != 1 || c->v.dim != 3)
+      return PFM_OK;
+    std::vector<int32_t> t_uu, t_res;
+    int zc = 0;
+    cart_uu3_boundary_tiles(c->cv, t_uu);
+    cart_res3_boundary_tiles(c->cv, t_res, zc);
+    const int n_uu = (int)t_uu.size(), n_res = (int)t_res.size();
+    if (t_uu.empty())
+      t_uu.push_back(0);
+    if (t_res.empty())
+      t_res.push_back(0);
+    try
+      {
+        c->cv.bnd_uu3 = dev_upload(c, t_uu.data(), t_uu.size());
+        c->cv.bnd_res3 = dev_upload(c, t_res.data(), t_res.size());
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
+      }
+    c->cv.n_bnd_uu3 = n_uu;
+    c->cv.n_bnd_res3 = n_res;
+    c->cv.zc_res3 = zc;
+    c->overlap_lists_ready = true;
+    return PFM_OK;
+  }
+
+  // phase 0: the whole assembly (pfm_assemble_device).  phases 1, 2: the two halves of pfm_assemble_overlapped -- 1 = what
+  // reads no ghost node, 2 = the rest; timing events bracket 1..2 together.
+  static int assemble_impl(pfm_ctx *c, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot, int phase)
   {
     // a rank may own nothing (empty partition piece): null buffers are fine where there is nothing to write
     const bool no_rows = c && c->n_owned_dofs() == 0;
@@ -1573,7 +1604,9 @@ extern "C"
       }
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (c->timing)
+    if (c->timing && phase == 2)
+      ev1 = c->ev_pool[c->ev_used - 1].second; // opened by phase 1
+    if (c->timing && phase != 2)
       {
         if (c->ev_used == c->ev_pool.size())
           {
@@ -1590,7 +1623,7 @@ extern "C"
     // Optional (PFM_SIDE_STREAM=1): residual kernel on a side stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
     // the kernels do not share CUs usefully; off by default.
     hipStream_t s_res = c->stream;
-    const bool fork = cart && !residual_only && getenv("PFM_SIDE_STREAM");
+    const bool fork = cart && !residual_only && phase == 0 && getenv("PFM_SIDE_STREAM");
     if (fork)
       {
         if (!c->side_stream)
@@ -1609,6 +1642,8 @@ extern "C"
       }
     // zero the outputs (cracks.cc:2133-2137); the row-owner kernels of the cartesian path
     // write every entry exactly once and need no zeroing pass
+    if (!cart && phase == 1)
+      return PFM_OK; // the general family is not cut into interior / boundary work: everything in phase 2
     if (!cart)
       e = hipMemsetAsync(d_res_pde, 0, sizeof(double) * (size_t)c->n_owned_dofs(), c->stream);
     if (!cart && e == hipSuccess && residual_only)
@@ -1635,7 +1670,7 @@ extern "C"
           return fail(c, rcs, "scalar tables");
         c->scal_dirty = false;
       }
-    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal)
+    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal, phase)
                   : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr);
     if (fork)
       {
@@ -1645,6 +1680,8 @@ extern "C"
         if (e != hipSuccess)
           return hipfail(c, e, "join");
       }
+    if (phase == 1)
+      return rc ? fail(c, rc, "assemble launch failed (interior tiles)") : PFM_OK;
     if (rc == PFM_OK && overlay_uu && c->scal_dirty)
       {
         rc = upload_mat_scal(c->prm, c->cv, c->d_scal, c->stream);
@@ -1657,6 +1694,87 @@ extern "C"
     if (rc)
       return fail(c, rc, "assemble launch failed");
     return PFM_OK;
+  }
+
+  int pfm_assemble_device(pfm_ctx *c, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot)
+  {
+    if (c && c->force_phase) // measurement: one half of the overlapped assembly alone, bracketed like a whole one
+      {
+        const bool timing = c->timing;
+        c->timing = false;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (timing)
+          {
+            if (c->ev_used == c->ev_pool.size())
+              {
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+                  return fail(c, PFM_ERR_HIP, "hipEventCreate");
+                c->ev_pool.emplace_back(a, b);
+              }
+            a = c->ev_pool[c->ev_used].first;
+            b = c->ev_pool[c->ev_used].second;
+            ++c->ev_used;
+            (void)hipEventRecord(a, c->stream);
+          }
+        const int rc = assemble_impl(c, residual_only, d_values, d_res_pde, d_res_tot, c->force_phase);
+        if (timing)
+          (void)hipEventRecord(b, c->stream);
+        c->timing = timing;
+        return rc;
+      }
+    return assemble_impl(c, residual_only, d_values, d_res_pde, d_res_tot, 0);
+  }
+
+  int pfm_ctx_force_phase(pfm_ctx *c, int phase)
+  {
+    if (!c || phase < 0 || phase > 2)
+      return PFM_ERR_BAD_ARG;
+    c->force_phase = phase;
+    return phase ? ensure_overlap_lists(c) : PFM_OK;
+  }
+
+  // Ghost import NEXT TO the cell work instead of in front of it (cracks.cc:2147-2154 against 2200-2437): after the
+  // caller's pfm_state_set, the exchange (pack -> RCCL -> unpack) runs on the context's side stream while the context's
+  // stream assembles the tiles that read no ghost node; the stream then waits for the import and assembles the rest.
+  int pfm_assemble_overlapped(pfm_ctx *c, void *comm, const int *peer_ranks, int residual_only, double *const *d_values,
+                              double *d_res_pde, double *d_res_tot)
+  {
+    if (!c || (!c->peers.empty() && (!comm || !peer_ranks)))
+      return PFM_ERR_BAD_ARG;
+    if (c->peers.empty())
+      return assemble_impl(c, residual_only, d_values, d_res_pde, d_res_tot, 0);
+    (void)hipSetDevice(c->device);
+    if (!c->side_stream)
+      {
+        if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+          return fail(c, PFM_ERR_HIP, "side stream");
+      }
+    {
+      const int rcl = ensure_overlap_lists(c);
+      if (rcl)
+        return rcl;
+    }
+    // fork behind the state scatter; the pack kernel of the exchange reads the owned node state
+    hipError_t e = hipEventRecord(c->ev_fork, c->stream);
+    if (e == hipSuccess)
+      e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+    if (e != hipSuccess)
+      return hipfail(c, e, "fork");
+    int rc = halo_exchange_on(c, comm, peer_ranks, c->side_stream);
+    if (rc)
+      return rc;
+    e = hipEventRecord(c->ev_join, c->side_stream);
+    if (e != hipSuccess)
+      return hipfail(c, e, "join event");
+    rc = assemble_impl(c, residual_only, d_values, d_res_pde, d_res_tot, 1); // interior: no ghost node is read
+    if (rc)
+      return rc;
+    e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e != hipSuccess)
+      return hipfail(c, e, "join");
+    return assemble_impl(c, residual_only, d_values, d_res_pde, d_res_tot, 2);
   }
 
   int pfm_sync_status(pfm_ctx *c)

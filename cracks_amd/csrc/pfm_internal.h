@@ -51,7 +51,27 @@ namespace pfm
                                  // row_perm[nadj_ptr[row] + r]; nullptr when no row needs it
     const double *cell_lam, *cell_mu; // per-cell Lame coefficients (cracks.cc:2207-2216) in lattice cell order
                                       // ci + (NX-1) (cj + (NY-1) ck); nullptr: the scalars of pfm_params
+    // pfm_assemble_overlapped, phase 2: compact launches over the tiles that read ghost nodes (lists built on first use:
+    // an early-exit launch over the full grid costs ~3 ns per skipped workgroup, 0.4 ms at 1.5e5 tiles)
+    const int32_t *bnd_uu3, *bnd_res3; // tile indices of k_cart_uu3 / k_cart_residual3 (the latter for its z-chunk length)
+    int n_bnd_uu3, n_bnd_res3, zc_res3;
+    int tile_sel;                     // 0: every tile; 1: only tiles that read no ghost node ("interior"); 2: only the
+                                      // others -- the two launches of pfm_assemble_overlapped, between which the ghost
+                                      // import lands (cracks.cc:2147-2154 next to the cell loop instead of in front of it)
   };
+
+  // does the node range [lo, hi] (tile + one-node halo, lattice indices along `axis`) contain a ghost node?  Ghost nodes
+  // are the lattice nodes outside the owned box [o0, o1].
+  __host__ __device__ inline bool cart_range_has_ghost(const CartView &cv, int axis, int lo, int hi)
+  {
+    const int n = axis == 0 ? cv.NX : (axis == 1 ? cv.NY : cv.NZ);
+    return (cv.o0[axis] > 0 && lo < cv.o0[axis]) || (cv.o1[axis] < n - 1 && hi > cv.o1[axis]);
+  }
+  // tile filter of the overlapped assembly: true = this launch skips the tile
+  __host__ __device__ inline bool cart_tile_skipped(const CartView &cv, bool touches_ghost)
+  {
+    return cv.tile_sel != 0 && touches_ghost != (cv.tile_sel == 2);
+  }
 
   // host copy of the lattice tables of a uniform box (kept for pfm_pattern_bind)
   struct LatticeHost
@@ -87,7 +107,7 @@ namespace pfm
   // compiler spills them into VGPR lanes (12 % of the instructions of the phase-field kernel were such moves).
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
-                           hipStream_t s_residual, void *d_scal);
+                           hipStream_t s_residual, void *d_scal, int phase = 0);
   bool cart_matrix_supported(int dim);
   // 2-D boxes: row-owner Jacobian + residual of runs WITHOUT the stress split (pfm_cart2d.hip; PFM_ERR_UNSUPPORTED otherwise)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
@@ -117,6 +137,9 @@ namespace pfm
   // round 3: the z-march with LDS-DMA plane prefetch and the residual from the rows (pfm_cart_uu5.hip)
   int launch_cart_uu5(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal, double *res_pde);
+  // host: indices of the tiles of k_cart_uu3 / k_cart_residual3 that read a ghost node (pfm_assemble_overlapped, phase 2)
+  void cart_uu3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out);
+  void cart_res3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out, int &zc);
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal);
   // color_ptr[n_classes + 1]: ranges of DevView::color_cells, one launch per class; the LAST class holds the cells with
@@ -137,6 +160,7 @@ struct pfm_ctx
   bool have_params = false;
   int n_blocks = 1;
   int kernel_path = 0;
+  int force_phase = 0; // pfm_ctx_force_phase (measurement)
   bool cart_ok = false;
   pfm::CartView cv{};
   // host copies needed for pattern queries
@@ -163,6 +187,7 @@ struct pfm_ctx
   int64_t halo_buf_bytes = 0;                            // their share of device_bytes
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
   uint8_t *d_row_perm = nullptr; // CartView::row_perm storage (in allocs)
+  bool overlap_lists_ready = false; // CartView::bnd_uu3 / bnd_res3 built
   pfm::LatticeHost lat;          // host lattice tables (cartesian path only)
   bool pattern_bound[4] = {false, false, false, false};
   bool scal_dirty = true; // d_scal does not hold the tables of the current parameters yet

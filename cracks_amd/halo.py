@@ -129,6 +129,16 @@ class HaloExchange:
             return
         self._comm, self._comm_lib = h, ctx.lib
 
+    def library_comm(self, ctx):
+        """The ncclComm_t handle of the in-library transport (made on first use), or None when the exchange goes through
+        torch.distributed (gloo smoke runs, PFM_HALO_TORCH=1, RCCL unavailable)."""
+        if not self._use_lib:
+            return None
+        if self._registered is not ctx:
+            self.register(ctx)
+        self._ensure_comm(ctx)
+        return self._comm.value if (self._use_lib and self._comm is not None) else None
+
     def close(self):
         if self._comm is not None:
             self._comm_lib.pfm_comm_destroy(self._comm)

@@ -167,6 +167,12 @@ int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES]);
 int pfm_comm_create(void **comm, const uint8_t id[PFM_COMM_ID_BYTES], int n_ranks, int rank, int device);
 int pfm_comm_destroy(void *comm);
 int pfm_halo_exchange(pfm_ctx *ctx, void *comm, const int *peer_ranks /* host, [n_peers] */);
+/* pfm_halo_exchange + pfm_assemble_device with the ghost import HIDDEN behind cell work: after pfm_state_set the exchange
+ * runs on a second stream of the context while the tiles that read no ghost node are assembled; the rest follows when the
+ * import has landed.  Same results as the two calls in sequence (bit for bit on uniform boxes); same collective rule as
+ * pfm_halo_exchange.  Declared here, next to the call it replaces; arguments as pfm_assemble_device. */
+int pfm_assemble_overlapped(pfm_ctx *ctx, void *comm, const int *peer_ranks, int residual_only, double *const *d_values,
+                            double *d_res_pde, double *d_res_tot);
 
 /* -- the hot path --------------------------------------------------------------------- */
 /* assemble_system(residual_only) on the current state.  Output pointers are DEVICE
@@ -214,6 +220,9 @@ int pfm_kernel_times_ms(pfm_ctx *ctx, double *ms, int capacity, int *n_launches)
 /* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian */
 int pfm_ctx_kernel_path(const pfm_ctx *ctx);
 int pfm_ctx_force_path(pfm_ctx *ctx, int path);
+/* measurement only: 1 / 2 make pfm_assemble_device run only the first / second half of pfm_assemble_overlapped (the work
+ * that reads no ghost node / the rest), 0 restores the whole assembly: how much work hides the ghost import */
+int pfm_ctx_force_phase(pfm_ctx *ctx, int phase);
 int64_t pfm_ctx_device_bytes(const pfm_ctx *ctx);
 
 #ifdef __cplusplus

@@ -323,8 +323,49 @@ def rank_share(args):
             asm.assemble_system(False)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t)
+        # the two halves of pfm_assemble_overlapped alone (pfm_ctx_force_phase): phase 1 = the tiles that read no ghost
+        # node = the work that runs NEXT TO the ghost import; phase 2 = the rest.  And what the import itself costs on
+        # this GPU without the wire: the pack + unpack launches of the registered lists.
+        phase_ms = {}
+        for ph in (1, 2):
+            asm.ctx.force_phase(ph)
+            for _ in range(2):
+                asm.assemble_system(False)
+            tp = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                asm.assemble_system(False)
+                torch.cuda.synchronize()
+                tp.append(time.perf_counter() - t)
+            phase_ms[ph] = 1e3 * float(np.median(tp))
+        asm.ctx.force_phase(0)
+        pack_ms = None
+        if world > 1 and lp.send_nodes.size:
+            asm.ctx.halo_register(lp.send_ptr, lp.send_nodes, lp.recv_ptr, lp.recv_nodes)
+            rec = 6
+            sbuf = torch.empty(rec * lp.send_nodes.size, dtype=torch.float64, device="cuda")
+            rbuf = torch.zeros(rec * lp.recv_nodes.size, dtype=torch.float64, device="cuda")
+            tp = []
+            for _ in range(12):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                asm.ctx.halo_pack_all(sbuf.data_ptr())
+                asm.ctx.halo_unpack_all(rbuf.data_ptr())
+                torch.cuda.synchronize()
+                tp.append(time.perf_counter() - t)
+            pack_ms = 1e3 * float(np.median(tp[2:]))
+        msg_bytes = 8 * 6 * int(lp.send_nodes.size)
         rows.append({"rank": rank, "of": world, "partition": "x".join(map(str, p)), "local_cells": int(lp.mesh.n_cells),
-                     "owned_nodes": int(no), "assemble_ms": round(1e3 * float(np.median(ts)), 4)})
+                     "owned_nodes": int(no), "assemble_ms": round(1e3 * float(np.median(ts)), 4),
+                     "interior_phase_ms": round(phase_ms[1], 4), "boundary_phase_ms": round(phase_ms[2], 4),
+                     "halo_pack_unpack_ms": None if pack_ms is None else round(pack_ms, 4),
+                     "halo_send_bytes": msg_bytes, "n_peers": int(len(lp.peers)),
+                     # exchange = pack + RCCL group (7 messages of <= 0.6 MB on 7 xGMI links: ~5 us of wire + ~25 us of
+                     # group latency) + unpack; hidden if it is shorter than the interior phase, which runs beside it
+                     "exchange_estimate_ms": None if pack_ms is None else round(pack_ms + 0.03, 4),
+                     "exposed_exchange_ms_sequential": None if pack_ms is None else round(pack_ms + 0.03, 4),
+                     "exposed_exchange_ms_overlapped": None if pack_ms is None else round(max(0.0, pack_ms + 0.03 - phase_ms[1]), 4)})
         print(rows[-1], flush=True)
         del asm
     if args.out:
