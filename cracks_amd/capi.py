@@ -87,7 +87,8 @@ def load():
         import torch  # noqa: F401
     except ImportError:  # pragma: no cover
         pass
-    lib = C.CDLL(LIB_PATH)
+    # PFM_LIB: another build of the library (A/B runs of kernel changes in one gpurun call; tools/ab.sh)
+    lib = C.CDLL(os.environ.get("PFM_LIB") or LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.pfm_ctx_create.argtypes = [C.POINTER(vp), C.POINTER(PfmMeshDesc), i32]
     lib.pfm_ctx_destroy.argtypes = [vp]

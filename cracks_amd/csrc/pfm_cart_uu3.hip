@@ -249,9 +249,13 @@ namespace pfm
               bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
               bool RES = false /* also writes the displacement rows of the residual (res_pde) */>
     __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
-                                                         unsigned long long *__restrict__ dbg, double *__restrict__ res_pde)
+                                                         unsigned long long *__restrict__ dbg, double *__restrict__ res_pde, int prio)
     {
       const MatScal &S = *Sp; // per-launch scalars in device memory (see pfm_internal.h)
+      // wave priorities per phase (prio != 0): the halo loads, w*g and the copy-out are short instruction sequences with
+      // long latencies -- issued ahead of the co-resident workgroup's arithmetic
+      if (prio & 1)
+        __builtin_amdgcn_s_setprio(3);
       long long tclk = 0;
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
@@ -368,6 +372,10 @@ namespace pfm
         }
       __syncthreads();
       stamp(0);
+      if (prio & 2)
+        __builtin_amdgcn_s_setprio(2);
+      else if (prio)
+        __builtin_amdgcn_s_setprio(0);
 
       // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
       if (t < 3 * CS3)
@@ -411,6 +419,8 @@ namespace pfm
         }
       __syncthreads();
       stamp(1);
+      if (prio)
+        __builtin_amdgcn_s_setprio(0);
 
       // ---- cell phase b: moment tables.  Round 3: wave <-> (family f, cell group) with the family WAVE-UNIFORM: waves
       // 0..5 = families 0..2 x cell groups {cells 0..44 = layer 0, cells 45..89 = layer 1}, lane <-> cell.  A family is
@@ -556,6 +566,8 @@ namespace pfm
         }
 
       auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
+        if (prio & 4)
+          __builtin_amdgcn_s_setprio(3);
         if (regular_tile)
           {
             // thread <-> (node group g, element el) with el fixed: nodes g, g + 6, ..., g + 30 -- no division per
@@ -605,6 +617,8 @@ namespace pfm
                 vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
               }
           }
+        if (prio & 4)
+          __builtin_amdgcn_s_setprio(0);
       };
 
       // RES: pressure part of the displacement residual, (alpha_B-1) p sum_q pfx^2 dN_a/dx_c JxW, from the A^c tables of
@@ -745,7 +759,8 @@ namespace pfm
       return PFM_OK;
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
-#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, 0, s, v, cv, S, vals_uu, nullptr, res_pde)
+    static const int prio = getenv("PFM_UU_PRIO") ? atoi(getenv("PFM_UU_PRIO")) : 0; // bit 0: halo loads, 1: w*g, 2: copy-out
+#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, 0, s, v, cv, S, vals_uu, nullptr, res_pde, prio)
     if (getenv("PFM_UU_CLK") && !il && !het && !res) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
@@ -753,7 +768,7 @@ namespace pfm
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr);
+        hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr, prio);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[8] = {};
