@@ -370,6 +370,7 @@ namespace pfm
           s_lam[HET ? cs : 0] = la;
           s_mu[HET ? cs : 0] = mu;
         }
+      stamp(5); // thread 0: its own halo loads have returned and are stored
       __syncthreads();
       stamp(0);
       if (prio & 2)
@@ -774,9 +775,10 @@ namespace pfm
         unsigned long long h[8] = {};
         for (size_t i = 0; i < nd; ++i)
           h[i % 8] += hall[i];
-        const char *names[5] = {"phase0", "w*g", "moments", "load+node c0,c2 (+copy c1)", "copy c0,c2 + node c1"};
+        const char *names[6] = {"phase0: wait at the barrier", "w*g", "moments", "load+node c0,c2 (+copy c1)", "copy c0,c2 + node c1",
+                                "phase0: own loads -> LDS"};
         fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per tile]");
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 6; ++i)
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
         fprintf(stderr, "\n");
       }
