@@ -1,0 +1,220 @@
+// pfm_graph.hip — node graph of a general (non-lattice) mesh on the device.
+//
+// The rows of the matrix pattern (cracks.cc:1644-1654: make_sparsity_pattern through the constraints) are, at node
+// level, "all nodes that share a constraint-resolved cell with the row's node": a hanging vertex stands for its parents.
+// pfm_ctx_create needs them after every refine_mesh (cracks.cc:4148); the host build (incidence lists + one sort per
+// node) was 12.6 of the 18 ms of a context rebuild on the 2.7e5-cell stand-in of BASELINE config 5 and 7.5 ms threaded.
+// Here: count the cells incident to every owned node (atomics), scan, fill the incidence lists, then one thread per owned
+// node merges the resolved vertices of its cells into a sorted duplicate-free list in private memory -- once for the row
+// length, once (after a scan of the lengths) to write the row.  The incidence lists are in arbitrary order (atomics); the
+// rows are sorted, so the result is deterministic: ascending local node id, ghost columns last, as the host build.
+#include "pfm_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+namespace pfm
+{
+  namespace
+  {
+    constexpr int MAX_ROW = 254; // the slot tables of the general family hold uint8 positions
+
+    struct GraphIn
+    {
+      const int32_t *cells; // [NC][nv], host order
+      long long NC;
+      int nv;
+      int32_t NO;
+      const int32_t *hn_index; // [N] or nullptr: index into the hanging table, -1 = not hanging
+      const long long *hn_ptr;
+      const int32_t *hn_parents;
+    };
+
+    template <class F>
+    __device__ __forceinline__ void for_each_resolved(const GraphIn &g, long long cell, F &&fn)
+    {
+      for (int a = 0; a < g.nv; ++a)
+        {
+          const int32_t n = g.cells[cell * g.nv + a];
+          fn(n);
+          const int32_t k = g.hn_index ? g.hn_index[n] : -1;
+          if (k >= 0)
+            for (long long j = g.hn_ptr[k]; j < g.hn_ptr[k + 1]; ++j)
+              fn(g.hn_parents[j]);
+        }
+    }
+
+    __global__ void k_graph_count(GraphIn g, int *__restrict__ cnt)
+    {
+      const long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (cell >= g.NC)
+        return;
+      for_each_resolved(g, cell, [&](int32_t n) {
+        if (n < g.NO)
+          atomicAdd(&cnt[n], 1);
+      });
+    }
+
+    __global__ void k_graph_fill(GraphIn g, const int *__restrict__ inc_ptr, int *__restrict__ fill, int *__restrict__ inc)
+    {
+      const long long cell = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (cell >= g.NC)
+        return;
+      for_each_resolved(g, cell, [&](int32_t n) {
+        if (n < g.NO)
+          inc[inc_ptr[n] + atomicAdd(&fill[n], 1)] = (int)cell;
+      });
+    }
+
+    // sorted duplicate-free neighbour list of node n in private memory; returns its length (MAX_ROW + 1: too long)
+    __device__ __forceinline__ int gather_row(const GraphIn &g, const int *__restrict__ inc_ptr, const int *__restrict__ inc, int32_t n,
+                                              int32_t (&row)[MAX_ROW + 1])
+    {
+      int len = 0;
+      bool over = false;
+      for (int k = inc_ptr[n]; k < inc_ptr[n + 1]; ++k)
+        for_each_resolved(g, inc[k], [&](int32_t q) {
+          // position of q in the sorted list (binary search), insert if absent
+          int lo = 0, hi = len;
+          while (lo < hi)
+            {
+              const int mid = (lo + hi) >> 1;
+              if (row[mid] < q)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+          if (lo < len && row[lo] == q)
+            return;
+          if (len > MAX_ROW)
+            {
+              over = true;
+              return;
+            }
+          for (int i = len; i > lo; --i)
+            row[i] = row[i - 1];
+          row[lo] = q;
+          ++len;
+        });
+      return over ? MAX_ROW + 1 : len;
+    }
+
+    __global__ void k_graph_degree(GraphIn g, const int *__restrict__ inc_ptr, const int *__restrict__ inc, long long *__restrict__ deg,
+                                   int *__restrict__ status)
+    {
+      const int32_t n = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+      if (n >= g.NO)
+        return;
+      int32_t row[MAX_ROW + 1];
+      const int len = gather_row(g, inc_ptr, inc, n, row);
+      if (len > MAX_ROW)
+        atomicMax(status, 1);
+      deg[n] = len;
+    }
+
+    __global__ void k_graph_rows(GraphIn g, const int *__restrict__ inc_ptr, const int *__restrict__ inc, const long long *__restrict__ nadj_ptr,
+                                 int32_t *__restrict__ nadj)
+    {
+      const int32_t n = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+      if (n >= g.NO)
+        return;
+      int32_t row[MAX_ROW + 1];
+      const int len = gather_row(g, inc_ptr, inc, n, row);
+      int32_t *out = nadj + nadj_ptr[n];
+      for (int i = 0; i < len && i <= MAX_ROW; ++i)
+        out[i] = row[i];
+    }
+  } // namespace
+
+  // Phase 1: everything up to the row pointers.  d_nadj_ptr [NO + 1] receives the exclusive scan of the row lengths; the
+  // scratch (incidence lists) is returned for phase 2 and freed by graph_build_finish.  All launches on stream s; the
+  // function returns after reading back the total (one 8-byte copy).  status: 0 ok, 1 = a row longer than 254.
+  int graph_build_begin(const int32_t *d_cells, long long NC, int nv, int32_t NO, const int32_t *d_hn_index, const long long *d_hn_ptr,
+                        const int32_t *d_hn_parents, long long *d_nadj_ptr, GraphScratch &sc, long long &total, hipStream_t s)
+  {
+    sc = GraphScratch{};
+    total = 0;
+    if (NO == 0)
+      return hipMemsetAsync(d_nadj_ptr, 0, sizeof(long long), s) == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+    GraphIn g{d_cells, NC, nv, NO, d_hn_index, d_hn_ptr, d_hn_parents};
+    int *cnt = nullptr, *inc_ptr = nullptr, *inc = nullptr, *status = nullptr;
+    long long *deg = nullptr;
+    void *tmp = nullptr;
+    auto fail = [&]() {
+      for (void *q : {(void *)cnt, (void *)inc_ptr, (void *)inc, (void *)status, (void *)deg, tmp})
+        if (q)
+          (void)hipFree(q);
+      return PFM_ERR_HIP;
+    };
+    if (hipMalloc((void **)&cnt, sizeof(int) * ((size_t)NO + 1)) != hipSuccess || hipMalloc((void **)&inc_ptr, sizeof(int) * ((size_t)NO + 1)) != hipSuccess ||
+        hipMalloc((void **)&deg, sizeof(long long) * ((size_t)NO + 1)) != hipSuccess || hipMalloc((void **)&status, sizeof(int)) != hipSuccess)
+      return fail();
+    if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)NO + 1), s) != hipSuccess || hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess ||
+        hipMemsetAsync(deg, 0, sizeof(long long) * ((size_t)NO + 1), s) != hipSuccess)
+      return fail();
+    const int bs = 256;
+    const unsigned nbc = (unsigned)((NC + bs - 1) / bs), nbn = (unsigned)((NO + bs - 1) / bs);
+    if (NC > 0)
+      hipLaunchKernelGGL(k_graph_count, dim3(nbc), dim3(bs), 0, s, g, cnt);
+    size_t tb1 = 0, tb2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, cnt, inc_ptr, NO + 1, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, deg, d_nadj_ptr, NO + 1, s);
+    const size_t tb = std::max(tb1, tb2);
+    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+      return fail();
+    size_t tbb = tb;
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, tbb, cnt, inc_ptr, NO + 1, s) != hipSuccess)
+      return fail();
+    int n_inc = 0;
+    if (hipMemcpyAsync(&n_inc, inc_ptr + NO, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return fail();
+    if (hipMalloc((void **)&inc, sizeof(int) * (size_t)std::max(n_inc, 1)) != hipSuccess)
+      return fail();
+    if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)NO + 1), s) != hipSuccess)
+      return fail();
+    if (NC > 0)
+      hipLaunchKernelGGL(k_graph_fill, dim3(nbc), dim3(bs), 0, s, g, inc_ptr, cnt, inc);
+    hipLaunchKernelGGL(k_graph_degree, dim3(nbn), dim3(bs), 0, s, g, inc_ptr, inc, deg, status);
+    tbb = tb;
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, tbb, deg, d_nadj_ptr, NO + 1, s) != hipSuccess)
+      return fail();
+    int st = 0;
+    if (hipMemcpyAsync(&total, d_nadj_ptr + NO, sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&st, status, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+        hipGetLastError() != hipSuccess)
+      return fail();
+    (void)hipFree(cnt);
+    (void)hipFree(deg);
+    (void)hipFree(status);
+    (void)hipFree(tmp);
+    sc.inc_ptr = inc_ptr;
+    sc.inc = inc;
+    if (st != 0)
+      {
+        graph_build_free(sc);
+        return PFM_ERR_UNSUPPORTED; // a node with more than 254 neighbours
+      }
+    return PFM_OK;
+  }
+
+  // Phase 2: the rows into d_nadj (allocated by the caller from the total of phase 1); asynchronous on s
+  int graph_build_rows(const int32_t *d_cells, long long NC, int nv, int32_t NO, const int32_t *d_hn_index, const long long *d_hn_ptr,
+                       const int32_t *d_hn_parents, const long long *d_nadj_ptr, int32_t *d_nadj, const GraphScratch &sc, hipStream_t s)
+  {
+    if (NO == 0)
+      return PFM_OK;
+    GraphIn g{d_cells, NC, nv, NO, d_hn_index, d_hn_ptr, d_hn_parents};
+    const int bs = 256;
+    hipLaunchKernelGGL(k_graph_rows, dim3((unsigned)((NO + bs - 1) / bs)), dim3(bs), 0, s, g, sc.inc_ptr, sc.inc, d_nadj_ptr, d_nadj);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+
+  void graph_build_free(GraphScratch &sc)
+  {
+    if (sc.inc_ptr)
+      (void)hipFree(sc.inc_ptr);
+    if (sc.inc)
+      (void)hipFree(sc.inc);
+    sc = GraphScratch{};
+  }
+} // namespace pfm

@@ -18,6 +18,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -83,22 +84,37 @@ namespace
     return n;
   }
 
-  // fn(begin, end) over [0, n) in contiguous chunks, one per thread
+  // fn(begin, end) over [0, n) in contiguous chunks, one per thread (at least `grain` items per thread).  An exception
+  // thrown by a worker (bad_alloc in a lambda that grows a vector) is carried to the caller instead of ending the
+  // process in std::terminate.
   template <class F>
-  void parallel_for(int64_t n, F &&fn)
+  void parallel_for(int64_t n, F &&fn, int64_t grain = 65536)
   {
-    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / 65536));
+    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(grain, 1)));
     if (nt <= 1)
       {
         fn((int64_t)0, n);
         return;
       }
     std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)nt);
     th.reserve(nt);
     for (int t = 0; t < nt; ++t)
-      th.emplace_back([&fn, n, nt, t] { fn(n * t / nt, n * (t + 1) / nt); });
+      th.emplace_back([&fn, &err, n, nt, t] {
+        try
+          {
+            fn(n * t / nt, n * (t + 1) / nt);
+          }
+        catch (...)
+          {
+            err[(size_t)t] = std::current_exception();
+          }
+      });
     for (auto &x : th)
       x.join();
+    for (auto &e : err)
+      if (e)
+        std::rethrow_exception(e);
   }
 
   // Host -> device copy of caller-owned (pageable) memory.  hipMemcpy from pageable memory ran at ~3.6 GB/s on the
@@ -322,6 +338,15 @@ namespace
   // the canonical rows (ascending local node id) of a lattice context whose host graph has not been materialised
   void ensure_host_graph(pfm_ctx *c)
   {
+    if (c->graph_dev_only && c->h_nadj.empty() && !c->h_nadj_ptr.empty() && c->h_nadj_ptr.back() > 0)
+      {
+        // general mesh: the rows were built on the device (pfm_graph.hip); the host copy is a cache for pattern queries
+        c->h_nadj.resize((size_t)c->h_nadj_ptr.back());
+        (void)hipSetDevice(c->device);
+        if (hipMemcpy(c->h_nadj.data(), c->v.nadj, sizeof(int32_t) * c->h_nadj.size(), hipMemcpyDeviceToHost) != hipSuccess)
+          throw HipFail{hipGetLastError(), "node graph D2H"};
+        return;
+      }
     if (!c->graph_lazy)
       return;
     const int32_t NO = c->v.n_owned;
@@ -670,97 +695,23 @@ extern "C"
 
         // ---- node graph over the constraint-resolved cells, rows = owned nodes, columns ascending by local node id
         // (ghost nodes, numbered after the owned ones, come last: the order of a host CSR sorted by local column id).
+        bool device_graph = false;
         lattice_ok = detect_lattice(m, lattice);
         clk.mark("detect_lattice");
         if (lattice_ok)
           lattice_graph(c, dim, NO, lattice);
         else
-          {
-            // pass 1: count cells incident to each owned node (through its own vertices and through hanging
-            // vertices it is a parent of)
-            auto for_each_resolved = [&](int64_t cell, auto &&fn) {
-              for (int a = 0; a < nv; ++a)
-                {
-                  const int32_t n = m->cell_nodes[cell * nv + a];
-                  const int32_t k = hn_index.empty() ? -1 : hn_index[n];
-                  fn(n);
-                  if (k >= 0)
-                    for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
-                      fn(m->hn_parents[j]);
-                }
-            };
-            std::vector<int64_t> inc_ptr((size_t)NO + 1, 0);
-            for (int64_t cell = 0; cell < NC; ++cell)
-              for_each_resolved(cell, [&](int32_t n) {
-                if (n < NO)
-                  ++inc_ptr[n + 1];
-              });
-            for (int32_t n = 0; n < NO; ++n)
-              inc_ptr[n + 1] += inc_ptr[n];
-            std::vector<int64_t> inc((size_t)inc_ptr[NO]);
-            {
-              std::vector<int64_t> fill(inc_ptr.begin(), inc_ptr.end() - 1);
-              for (int64_t cell = 0; cell < NC; ++cell)
-                for_each_resolved(cell, [&](int32_t n) {
-                  if (n < NO)
-                    inc[fill[n]++] = cell;
-                });
-            }
-            c->h_nadj_ptr.assign((size_t)NO + 1, 0);
-            std::vector<int32_t> &nadj = c->h_nadj;
-            nadj.clear();
-            nadj.reserve((size_t)NO * (dim == 2 ? 9 : 27));
-            std::vector<int32_t> tmp;
-            for (int32_t n = 0; n < NO; ++n)
-              {
-                tmp.clear();
-                for (int64_t k = inc_ptr[n]; k < inc_ptr[n + 1]; ++k)
-                  for_each_resolved(inc[k], [&](int32_t q) { tmp.push_back(q); });
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                if (tmp.size() > 254)
-                  return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
-                nadj.insert(nadj.end(), tmp.begin(), tmp.end());
-                c->h_nadj_ptr[n + 1] = (long long)nadj.size();
-              }
-          }
+          device_graph = true; // general mesh: built on the device below, from the uploaded cell table (pfm_graph.hip)
         std::vector<int32_t> &nadj = c->h_nadj;
         clk.mark("node graph");
 
-        // ---- device mirrors (SoA)
-        {
-          // host order (cell-major / node-major) -> SoA on the device: the raw tables are uploaded as they are and
-          // transposed by a kernel (a host transposition of 8e7 + 3e7 entries cost 0.25 s at 1e7 cells)
-          int32_t *raw = nullptr;
-          if (NC > 0 && hipMalloc((void **)&raw, sizeof(int32_t) * (size_t)NC * nv) != hipSuccess)
-            throw HipFail{hipGetLastError(), "hipMalloc"};
-          int32_t *conn = dev_alloc<int32_t>(c, (size_t)NC * nv);
-          clk.mark("  conn buffers");
-          hipError_t e2 = NC > 0 ? h2d(raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
-          clk.mark("  conn h2d");
-          const int rct = e2 == hipSuccess ? launch_aos_to_soa_i32(raw, conn, NC, nv, nullptr) : PFM_ERR_HIP;
-          double *rawx = nullptr;
-          if (hipMalloc((void **)&rawx, sizeof(double) * (size_t)N * dim) != hipSuccess)
+        // Colour classes (below) only read host tables: on a general mesh they are computed by a host thread NEXT TO the
+        // uploads and the device build of the node graph (1.7 of the remaining 5.8 ms of a rebuild at 2.7e5 cells).
+        std::vector<int32_t> order((size_t)NC);
+        std::exception_ptr colour_err;
+        auto colour_classes = [&]() {
+          try
             {
-              (void)hipFree(raw);
-              throw HipFail{hipGetLastError(), "hipMalloc"};
-            }
-          double *xs = dev_alloc<double>(c, (size_t)N * dim);
-          clk.mark("  coords buffers");
-          e2 = h2d(rawx, m->coords, sizeof(double) * (size_t)N * dim);
-          clk.mark("  coords h2d");
-          const int rcx = e2 == hipSuccess ? launch_aos_to_soa_f64(rawx, xs, N, dim, nullptr) : PFM_ERR_HIP;
-          const hipError_t es = hipDeviceSynchronize();
-          clk.mark("  transposes");
-          (void)hipFree(raw);
-          (void)hipFree(rawx);
-          if (rct != PFM_OK || rcx != PFM_OK || es != hipSuccess)
-            throw HipFail{hipGetLastError(), "mesh table upload"};
-          v.conn = conn;
-          v.coords = xs;
-        }
-        clk.mark("conn + coords upload");
-        {
           // Colour classes of the general cell kernel: cells of one class share no node and are assembled by one
           // launch with plain read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter
           // of a 2-D Jacobian took 1.1 of 1.2 ms).  Lattice: parity of the cell's lattice position; otherwise greedy
@@ -813,14 +764,114 @@ extern "C"
             ++c->color_ptr[col[cell] + 1];
           for (int k = 0; k <= n_col; ++k)
             c->color_ptr[k + 1] += c->color_ptr[k];
-          std::vector<int32_t> order((size_t)NC);
           {
             std::vector<long long> fill(c->color_ptr.begin(), c->color_ptr.end() - 1);
             for (int64_t cell = 0; cell < NC; ++cell)
               order[fill[col[cell]]++] = (int32_t)cell;
           }
-          v.color_cells = dev_upload(c, order.data(), order.size());
+            }
+          catch (...)
+            {
+              colour_err = std::current_exception();
+            }
+        };
+        std::thread colour_thread;
+        if (!lattice_ok && NC > 65536)
+          colour_thread = std::thread(colour_classes);
+        struct Joiner
+        {
+          std::thread &t;
+          ~Joiner()
+          {
+            if (t.joinable())
+              t.join();
+          }
+        } colour_joiner{colour_thread}; // an exception on the way must not leave a running thread behind
+
+        // ---- device mirrors (SoA)
+        {
+          // host order (cell-major / node-major) -> SoA on the device: the raw tables are uploaded as they are and
+          // transposed by a kernel (a host transposition of 8e7 + 3e7 entries cost 0.25 s at 1e7 cells)
+          int32_t *raw = nullptr;
+          if (NC > 0 && hipMalloc((void **)&raw, sizeof(int32_t) * (size_t)NC * nv) != hipSuccess)
+            throw HipFail{hipGetLastError(), "hipMalloc"};
+          int32_t *conn = dev_alloc<int32_t>(c, (size_t)NC * nv);
+          clk.mark("  conn buffers");
+          hipError_t e2 = NC > 0 ? h2d(raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
+          clk.mark("  conn h2d");
+          const int rct = e2 == hipSuccess ? launch_aos_to_soa_i32(raw, conn, NC, nv, nullptr) : PFM_ERR_HIP;
+          double *rawx = nullptr;
+          if (hipMalloc((void **)&rawx, sizeof(double) * (size_t)N * dim) != hipSuccess)
+            {
+              (void)hipFree(raw);
+              throw HipFail{hipGetLastError(), "hipMalloc"};
+            }
+          double *xs = dev_alloc<double>(c, (size_t)N * dim);
+          clk.mark("  coords buffers");
+          e2 = h2d(rawx, m->coords, sizeof(double) * (size_t)N * dim);
+          clk.mark("  coords h2d");
+          const int rcx = e2 == hipSuccess ? launch_aos_to_soa_f64(rawx, xs, N, dim, nullptr) : PFM_ERR_HIP;
+          int rcg = PFM_OK;
+          v.hn_index = nullptr;
+          v.hn_ptr = nullptr;
+          v.hn_parents = nullptr;
+          v.hn_weights = nullptr;
+          try
+            {
+              if (m->n_hanging > 0)
+                {
+                  v.hn_index = dev_upload(c, hn_index.data(), hn_index.size());
+                  std::vector<long long> hp(m->hn_ptr, m->hn_ptr + m->n_hanging + 1);
+                  v.hn_ptr = dev_upload(c, hp.data(), hp.size());
+                  v.hn_parents = dev_upload(c, m->hn_parents, (size_t)hp.back());
+                  v.hn_weights = dev_upload(c, m->hn_weights, (size_t)hp.back());
+                }
+              if (device_graph && rct == PFM_OK)
+                {
+                  // node graph of a general mesh on the device, from the cell table as the host handed it over
+                  long long *d_ptr = dev_alloc<long long>(c, (size_t)NO + 1);
+                  GraphScratch sc;
+                  long long total = 0;
+                  rcg = graph_build_begin(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, sc, total, nullptr);
+                  if (rcg == PFM_OK)
+                    {
+                      int32_t *d_adj = dev_alloc<int32_t>(c, (size_t)std::max<long long>(total, 1));
+                      rcg = graph_build_rows(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, d_adj, sc, nullptr);
+                      c->h_nadj_ptr.assign((size_t)NO + 1, 0);
+                      if (rcg == PFM_OK && hipMemcpy(c->h_nadj_ptr.data(), d_ptr, sizeof(long long) * ((size_t)NO + 1), hipMemcpyDeviceToHost) != hipSuccess)
+                        rcg = PFM_ERR_HIP;
+                      graph_build_free(sc);
+                      v.nadj_ptr = d_ptr;
+                      v.nadj = d_adj;
+                      c->graph_dev_only = true; // the host copy of the columns is fetched when a pattern query asks for it
+                    }
+                }
+            }
+          catch (...)
+            {
+              (void)hipFree(raw);
+              (void)hipFree(rawx);
+              throw;
+            }
+          const hipError_t es = hipDeviceSynchronize();
+          clk.mark("  transposes, node graph");
+          (void)hipFree(raw);
+          (void)hipFree(rawx);
+          if (rcg == PFM_ERR_UNSUPPORTED)
+            return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
+          if (rct != PFM_OK || rcx != PFM_OK || rcg != PFM_OK || es != hipSuccess)
+            throw HipFail{hipGetLastError(), "mesh table upload / node graph"};
+          v.conn = conn;
+          v.coords = xs;
         }
+        clk.mark("conn + coords upload");
+        if (colour_thread.joinable())
+          colour_thread.join();
+        else
+          colour_classes();
+        if (colour_err)
+          std::rethrow_exception(colour_err);
+        v.color_cells = dev_upload(c, order.data(), order.size());
         clk.mark("colour classes");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
@@ -828,32 +879,23 @@ extern "C"
             v.cell_lambda = dev_upload(c, m->cell_lambda, (size_t)NC);
             v.cell_mu = dev_upload(c, m->cell_mu, (size_t)NC);
           }
-        v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
+        if (!c->graph_dev_only)
+          v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
         // node graph columns + slot table of the general kernel family (position of vertex b's node in the row of
         // vertex a's node, searched on the device: 64 row searches per hex, 8 s on one host core at 1e7 cells); a
         // lattice context builds them when the general family is first used
-        v.nadj = nullptr;
+        if (!c->graph_dev_only)
+          v.nadj = nullptr;
         v.cslot = nullptr;
         c->general_ready = !c->graph_lazy;
         if (c->general_ready)
           {
-            v.nadj = dev_upload(c, nadj.data(), nadj.size());
+            if (!c->graph_dev_only)
+              v.nadj = dev_upload(c, nadj.data(), nadj.size());
             clk.mark("graph upload");
             v.cslot = dev_alloc<uint8_t>(c, (size_t)NC * nv * nv);
             if (launch_build_cslot(v, nullptr) != PFM_OK)
               throw HipFail{hipGetLastError(), "cslot kernel"};
-          }
-        v.hn_index = nullptr;
-        v.hn_ptr = nullptr;
-        v.hn_parents = nullptr;
-        v.hn_weights = nullptr;
-        if (m->n_hanging > 0)
-          {
-            v.hn_index = dev_upload(c, hn_index.data(), hn_index.size());
-            std::vector<long long> hp(m->hn_ptr, m->hn_ptr + m->n_hanging + 1);
-            v.hn_ptr = dev_upload(c, hp.data(), hp.size());
-            v.hn_parents = dev_upload(c, m->hn_parents, (size_t)hp.back());
-            v.hn_weights = dev_upload(c, m->hn_weights, (size_t)hp.back());
           }
         uint8_t *flags = dev_alloc<uint8_t>(c, (size_t)N);
         e = hipMemset(flags, 0, (size_t)N);

@@ -137,6 +137,16 @@ namespace pfm
   // round 3: the z-march with LDS-DMA plane prefetch and the residual from the rows (pfm_cart_uu5.hip)
   int launch_cart_uu5(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal, double *res_pde);
+  // node graph of a general mesh on the device (pfm_graph.hip)
+  struct GraphScratch
+  {
+    int *inc_ptr = nullptr, *inc = nullptr; // incidence lists: cells around every owned node
+  };
+  int graph_build_begin(const int32_t *d_cells, long long NC, int nv, int32_t NO, const int32_t *d_hn_index, const long long *d_hn_ptr,
+                        const int32_t *d_hn_parents, long long *d_nadj_ptr, GraphScratch &sc, long long &total, hipStream_t s);
+  int graph_build_rows(const int32_t *d_cells, long long NC, int nv, int32_t NO, const int32_t *d_hn_index, const long long *d_hn_ptr,
+                       const int32_t *d_hn_parents, const long long *d_nadj_ptr, int32_t *d_nadj, const GraphScratch &sc, hipStream_t s);
+  void graph_build_free(GraphScratch &sc);
   // host: indices of the tiles of k_cart_uu3 / k_cart_residual3 that read a ghost node (pfm_assemble_overlapped, phase 2)
   void cart_uu3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out);
   void cart_res3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out, int &zc);
@@ -170,6 +180,7 @@ struct pfm_ctx
   // cell kernel (v.cslot) are 1.1 + 1.1 + 0.65 GB at 1e7 cells and are only needed by pfm_pattern_get / _bind and by the
   // general family: built on first use (ensure_host_graph, ensure_general_tables in pfm_host.cpp)
   bool graph_lazy = false;    // h_nadj not materialised yet (h_nadj_ptr is)
+  bool graph_dev_only = false; // general mesh: v.nadj was built on the device (pfm_graph.hip), h_nadj is fetched on demand
   bool general_ready = true;  // v.nadj and v.cslot exist on the device
   std::vector<long long> color_ptr; // colour classes of the general cell kernel (DevView::color_cells)
   // owned device allocations
