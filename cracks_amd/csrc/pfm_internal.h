@@ -96,6 +96,8 @@ namespace pfm
   int launch_aos_to_soa_i32(const int32_t *d_in, int32_t *d_out, long long n, int w, hipStream_t s);
   int launch_aos_to_soa_f64(const double *d_in, double *d_out, long long n, int w, hipStream_t s);
   int launch_check_finite(const DevView &v, const double *d, int64_t n, hipStream_t s);
+  // neighbour masks of a full lexicographic lattice: bit o = lattice offset o lies inside the box (CartView::nbr_mask)
+  int launch_lattice_masks(uint32_t *d_mask, int NX, int NY, int NZ, int dim, hipStream_t s);
   int launch_halo_pack(const DevView &v, const int32_t *d_nodes, int64_t n, double *d_buf, hipStream_t s);
   // all peers at once: d_nodes = concatenated lists, d_ptr[n_peers + 1] = their offsets (device)
   int launch_halo_all(const DevView &v, const int32_t *d_nodes, const long long *d_ptr, int n_peers, int64_t n_total,

@@ -1054,6 +1054,34 @@ namespace pfm
     return check_launch();
   }
 
+  namespace
+  {
+    __global__ void k_lattice_masks(uint32_t *__restrict__ mask, int NX, int NY, int NZ, int dim)
+    {
+      const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (n >= (long long)NX * NY * NZ)
+        return;
+      const int i = (int)(n % NX), j = (int)((n / NX) % NY), k = (int)(n / ((long long)NX * NY));
+      const int no = dim == 3 ? 27 : 9;
+      uint32_t m = 0;
+      for (int o = 0; o < no; ++o)
+        {
+          const int ii = i + (o % 3) - 1, jj = j + ((o / 3) % 3) - 1, kk = k + (dim == 3 ? (o / 9) - 1 : 0);
+          if (ii >= 0 && ii < NX && jj >= 0 && jj < NY && kk >= 0 && kk < NZ)
+            m |= 1u << o;
+        }
+      mask[n] = m;
+    }
+  } // namespace
+  int launch_lattice_masks(uint32_t *d_mask, int NX, int NY, int NZ, int dim, hipStream_t s)
+  {
+    const long long n = (long long)NX * NY * NZ;
+    if (n == 0)
+      return PFM_OK;
+    hipLaunchKernelGGL(k_lattice_masks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_mask, NX, NY, NZ, dim);
+    return check_launch();
+  }
+
   int launch_check_finite(const DevView &v, const double *d, int64_t n, hipStream_t s)
   {
     if (n <= 0)
