@@ -75,8 +75,8 @@ def measured_valu_instructions(dim: int, n: int, residual_only: bool):
         return None, src
     tot = fp64 = 0.0
     for name, d in rec["per_launch"].items():
-        if name in ("k_aos_to_soa",):
-            continue
+        if not name.startswith(("k_cart", "k_state_set", "k_assemble_general")):
+            continue  # context creation (k_aos_to_soa, k_lattice_masks, k_graph_*, k_build_cslot) is not part of an assembly
         tot += d.get("SQ_INSTS_VALU", 0.0)
         fp64 += d.get("SQ_INSTS_VALU_ADD_F64", 0.0) + d.get("SQ_INSTS_VALU_MUL_F64", 0.0) + d.get("SQ_INSTS_VALU_FMA_F64", 0.0)
     return {"valu": tot, "fp64": fp64}, src
