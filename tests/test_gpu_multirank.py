@@ -316,3 +316,22 @@ def test_bench_two_gpus_over_rccl():
     a, b = np.array(one["checksum"]), np.array(two["checksum"])
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
     assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
+
+
+def test_library_rccl_binds_inside_a_torch_process():
+    """The in-library transport binds RCCL with dlopen at first use.  In a torch process the copy torch bundles is already
+    loaded; the library must find a usable one (same major version as the header it was compiled with), make an id and a
+    1-rank communicator on this GPU and destroy it again -- what every rank of `bench.py --gpus N` does first."""
+    import ctypes as C
+
+    import torch  # noqa: F401  (the bundled RCCL is in the process)
+    from cracks_amd import capi
+
+    lib = capi.load()
+    uid = np.zeros(capi.COMM_ID_BYTES, np.uint8)
+    assert lib.pfm_comm_unique_id(capi.np_ptr(uid, np.uint8)) == capi.PFM_OK
+    assert uid.any()
+    h = C.c_void_p()
+    assert lib.pfm_comm_create(C.byref(h), capi.np_ptr(uid, np.uint8), 1, 0, 0) == capi.PFM_OK
+    assert h.value
+    assert lib.pfm_comm_destroy(h) == capi.PFM_OK
