@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace pfm
 {
@@ -40,6 +41,7 @@ namespace pfm
     {
       double n[2][3]; // n_0 = 1 - xi, n_1 = xi
       double w[3];
+      double wn1[3]; // w n_1
     };
     __constant__ Tab1D c_t1;
 
@@ -53,6 +55,7 @@ namespace pfm
           t.n[0][q] = 1.0 - gx[q];
           t.n[1][q] = gx[q];
           t.w[q] = gw[q];
+          t.wn1[q] = gw[q] * gx[q];
         }
       return t;
     }
@@ -570,6 +573,14 @@ namespace pfm
     // LIN: pf_extra is a linear function of the two old phase fields up to its final clamp (no per-q-point clamping of
     // the old fields: not monolithic; no penalisation term that needs phi_old alone): the combination is formed once
     // per node when a plane is loaded and interpolated as ONE field (cracks.cc:2262-2277 are linear until the clamp).
+    // value of lane + 1 within a row of 16 lanes (0 for the last lane of the row)
+    __device__ __forceinline__ double row_shl1(double x)
+    {
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, true);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, true);
+      return __hiloint2double(hi, lo);
+    }
+
     template <bool LIN>
     __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3(DevView v, CartView cv, Scal S,
                                                                  double *__restrict__ res_pde,
@@ -577,7 +588,7 @@ namespace pfm
                                                                  int zc /* node planes per chunk */)
     {
       __shared__ double s_U[2][6][RPL]; // [ring][u_x u_y u_z phi phi_old phi_oldold][halo node]
-      __shared__ double s_P[16][RTX * RTY];
+      __shared__ double s_P[8][RTX * RTY]; // [ay * 4 + component]: the a_x = 0 / 1 parts are merged in registers (DPP)
 
       const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
       const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
@@ -630,12 +641,19 @@ namespace pfm
           }
       };
 
-      double R[2][2][2][4]; // [ax][ay][az][component]
+      // Accumulators in the moment basis of the trilinear test functions: along every direction index 0 stands for
+      // phi_0 + phi_1 = 1 (gradient 0) and index 1 for phi_1 (gradient 1/h).  The part of vertex 0 is a difference that is
+      // taken once per layer, and the sum index of a gradient factor contributes nothing: 61 accumulate-ops per (q_y, q_z)
+      // instead of 137 in the vertex basis.  M[x][y][z][component].
+      double M[2][2][2][4];
 #pragma unroll
       for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          R[a & 1][(a >> 1) & 1][a >> 2][c] = 0.0;
+          M[a & 1][(a >> 1) & 1][a >> 2][c] = 0.0;
+
+      // constants of the q-point law with the parameters folded (cracks.cc:2393-2432)
+      const double c_g = 1.0 - S.kappa, c_pd = S.aB1 * S.p, c_r2 = -2.0 * S.aB1 * S.p, c_r3 = S.Gc / S.eps, c_ge = S.Gc * S.eps;
 
       load_plane(kA - 1, 0);
       const int hb = cy * RHX + cx;
@@ -655,25 +673,29 @@ namespace pfm
                   lam = cv.cell_lam[cidx];
                   mu = cv.cell_mu[cidx];
                 }
-              double Dy[4][2]; // d/dy at x-vertex 0/1: depends on the z-level only
+              const double mu2 = 2 * mu;
+              double Dy0[4], dDy[4]; // d/dy at x-vertex 0 and its x-difference: depend on the z-level only
 #pragma unroll 1
               for (int p = 0; p < 9; ++p)
                 {
                   const int qy = p % 3, qz = p / 3;
-                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy], nz0 = c_t1.n[0][qz], nz1 = c_t1.n[1][qz];
+                  const double eta = c_t1.n[1][qy], zeta = c_t1.n[1][qz];
                   const double wyz = vol * c_t1.w[qy] * c_t1.w[qz];
                   if (qy == 0)
                     {
 #pragma unroll
                       for (int f = 0; f < 4; ++f)
                         {
-                          Dy[f][0] = (nz0 * (Ulo[f * RPL + RHX] - Ulo[f * RPL]) + nz1 * (Uhi[f * RPL + RHX] - Uhi[f * RPL])) * ihy;
-                          Dy[f][1] = (nz0 * (Ulo[f * RPL + RHX + 1] - Ulo[f * RPL + 1]) +
-                                      nz1 * (Uhi[f * RPL + RHX + 1] - Uhi[f * RPL + 1])) * ihy;
+                          const double s0 = Ulo[f * RPL + RHX] - Ulo[f * RPL], t0 = Uhi[f * RPL + RHX] - Uhi[f * RPL];
+                          const double s1 = Ulo[f * RPL + RHX + 1] - Ulo[f * RPL + 1], t1 = Uhi[f * RPL + RHX + 1] - Uhi[f * RPL + 1];
+                          const double g0 = fma(zeta, t0 - s0, s0), g1 = fma(zeta, t1 - s1, s1);
+                          Dy0[f] = ihy * g0;
+                          dDy[f] = ihy * (g1 - g0);
                         }
                     }
-                  double L[6][2], Dz[4][2], Dx[4];
-                  L[5][0] = L[5][1] = 0.0;
+                  // values at x-vertex 0 and x-differences of: the field (L0, dL), its z-derivative (Dz0, dDz); Dx = dL / h_x
+                  double L0[6], dL[6], Dz0[4], dDz[4], Dx[4];
+                  L0[5] = dL[5] = 0.0;
 #pragma unroll
                   for (int f = 0; f < (LIN ? 5 : 6); ++f)
                     {
@@ -681,140 +703,162 @@ namespace pfm
                                    a11 = Ulo[f * RPL + RHX + 1];
                       const double b00 = Uhi[f * RPL], b10 = Uhi[f * RPL + 1], b01 = Uhi[f * RPL + RHX],
                                    b11 = Uhi[f * RPL + RHX + 1];
-                      const double lo0 = ny0 * a00 + ny1 * a01, lo1 = ny0 * a10 + ny1 * a11;
-                      const double hi0 = ny0 * b00 + ny1 * b01, hi1 = ny0 * b10 + ny1 * b11;
-                      L[f][0] = nz0 * lo0 + nz1 * hi0;
-                      L[f][1] = nz0 * lo1 + nz1 * hi1;
+                      const double lo0 = fma(eta, a01 - a00, a00), lo1 = fma(eta, a11 - a10, a10);
+                      const double hi0 = fma(eta, b01 - b00, b00), hi1 = fma(eta, b11 - b10, b10);
+                      const double d0 = hi0 - lo0, d1 = hi1 - lo1;
+                      L0[f] = fma(zeta, d0, lo0);
+                      dL[f] = fma(zeta, d1, lo1) - L0[f];
                       if (f < 4)
                         {
-                          Dz[f][0] = (hi0 - lo0) * ihz;
-                          Dz[f][1] = (hi1 - lo1) * ihz;
-                          Dx[f] = (L[f][1] - L[f][0]) * ihx;
+                          Dz0[f] = ihz * d0;
+                          dDz[f] = ihz * (d1 - d0);
+                          Dx[f] = ihx * dL[f];
                         }
                       __builtin_amdgcn_sched_barrier(0); // one field at a time: keeps the 8 nodal values short-lived
                     }
-                  // x-stage accumulators: F_c = (Z_c0, Z_c1, Z_c2 | S_c), c = 3: (G_c eps grad phi | rq)
-                  double X0[4], X1[4][2], X2[4][2], XS[2];
+                  // x-stage: sums over q_x of the fluxes F_c = (Z_c0, Z_c1, Z_c2), c = 3: G_c eps grad phi, and of the value
+                  // term rq, against 1 (s) and phi_1 (1); the x-gradient factor needs the plain sum only
+                  double A0[4], Bs[4], B1[4], Cs[4], C1[4], rs, r1;
+                  auto xq = [&](const int qx, auto first) __attribute__((always_inline)) {
+                    const double xi = c_t1.n[1][qx], wq = c_t1.w[qx], wx = c_t1.wn1[qx];
+                    // Newton state at q (cracks.cc:2222-2232); along x every interpolated quantity is linear
+                    double gu[3][3], gpf[3];
 #pragma unroll
-                  for (int c = 0; c < 4; ++c)
-                    X0[c] = X1[c][0] = X1[c][1] = X2[c][0] = X2[c][1] = 0.0;
-                  XS[0] = XS[1] = 0.0;
-                  // along x every interpolated quantity is linear: value(q_x) = v0 + n_1(q_x) (v1 - v0), one FMA per
-                  // q-point instead of a multiply and an FMA (the differences are formed once per line)
-                  double dDy[4], dDz[4];
-#pragma unroll
-                  for (int f = 0; f < 4; ++f)
-                    {
-                      dDy[f] = Dy[f][1] - Dy[f][0];
-                      dDz[f] = Dz[f][1] - Dz[f][0];
-                    }
-                  const double dpf = L[3][1] - L[3][0], dpo = L[4][1] - L[4][0], dpoo = L[5][1] - L[5][0];
-                  const double mu2 = 2 * mu;
-#pragma unroll
-                  for (int qx = 0; qx < 3; ++qx)
-                    {
-                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
-                      const double JxW = wyz * c_t1.w[qx];
-                      // Newton state at q (cracks.cc:2222-2232)
-                      double gu[3][3], gpf[3];
-#pragma unroll
-                      for (int c = 0; c < 3; ++c)
-                        {
-                          gu[c][0] = Dx[c];
-                          gu[c][1] = fma(nx1, dDy[c], Dy[c][0]);
-                          gu[c][2] = fma(nx1, dDz[c], Dz[c][0]);
-                        }
-                      gpf[0] = Dx[3];
-                      gpf[1] = fma(nx1, dDy[3], Dy[3][0]);
-                      gpf[2] = fma(nx1, dDz[3], Dz[3][0]);
-                      double pf = fma(nx1, dpf, L[3][0]);
-                      double pfo = fma(nx1, dpo, L[4][0]); // LIN: the combined field
-                      double pen = 0.0, pfx;
-                      if constexpr (LIN)
-                        {
+                    for (int c = 0; c < 3; ++c)
+                      {
+                        gu[c][0] = Dx[c];
+                        gu[c][1] = fma(xi, dDy[c], Dy0[c]);
+                        gu[c][2] = fma(xi, dDz[c], Dz0[c]);
+                      }
+                    gpf[0] = Dx[3];
+                    gpf[1] = fma(xi, dDy[3], Dy0[3]);
+                    gpf[2] = fma(xi, dDz[3], Dz0[3]);
+                    double pf = fma(xi, dL[3], L0[3]);
+                    double pfo = fma(xi, dL[4], L0[4]); // LIN: the combined field
+                    double pen = 0.0, pfx;
+                    if constexpr (LIN)
+                      {
+                        pfx = pfo;
+                        if (!S.use_old)
+                          pfx = fmin(fmax(pfx, 0.0), 1.0);
+                      }
+                    else
+                      {
+                        double pfoo = fma(xi, dL[5], L0[5]);
+                        if (S.monolithic)
+                          {
+                            pf = fmax(0.0, pf);
+                            pfo = fmax(0.0, pfo);
+                            pfoo = fmax(0.0, pfoo);
+                          }
+                        pen = fmax(0.0, pf - pfo);
+                        pfx = pfoo + S.tfac * (pfo - pfoo);
+                        if (pfx <= 0.0)
+                          pfx = 0.0;
+                        if (pfx >= 1.0)
+                          pfx = 1.0;
+                        if (S.use_old)
                           pfx = pfo;
-                          if (!S.use_old)
-                            pfx = fmin(fmax(pfx, 0.0), 1.0);
+                      }
+                    const double pf2 = pfx * pfx;
+                    const double g = fma(c_g, pf2, S.kappa);
+                    // sigma+ = lambda tr(E) I + 2 mu E; with t_ab = g_ab + g_ba: sigma_ab = mu t_ab and
+                    // sigma : E = sum_a sigma_aa g_aa + sum_{a<b} sigma_ab t_ab
+                    const double t01 = gu[0][1] + gu[1][0], t02 = gu[0][2] + gu[2][0], t12 = gu[1][2] + gu[2][1];
+                    const double trE = gu[0][0] + gu[1][1] + gu[2][2];
+                    const double lt = lam * trE;
+                    const double s00 = fma(mu2, gu[0][0], lt), s11 = fma(mu2, gu[1][1], lt), s22 = fma(mu2, gu[2][2], lt);
+                    const double s01 = mu * t01, s02 = mu * t02, s12 = mu * t12;
+                    const double spE = fma(s00, gu[0][0], fma(s11, gu[1][1], s22 * gu[2][2])) + fma(s01, t01, fma(s02, t02, s12 * t12));
+                    // Z = g sigma+ - (alpha_B - 1) p pfx^2 I (symmetric); the weights enter with the sums
+                    const double pd = c_pd * pf2;
+                    const double z00 = fma(g, s00, -pd), z11 = fma(g, s11, -pd), z22 = fma(g, s22, -pd);
+                    const double z01 = g * s01, z02 = g * s02, z12 = g * s12;
+                    // gamma pen + (1 - kappa) sigma:E pf - G_c/eps (1 - pf) - 2 (alpha_B - 1) p pf tr(E)
+                    double rq = fma(pf, fma(c_r2, trE, fma(c_g, spE, c_r3)), -c_r3);
+                    if constexpr (!LIN)
+                      rq = fma(S.gamma_fac, pen, rq);
+                    const double F[4][3] = {{z00, z01, z02}, {z01, z11, z12}, {z02, z12, z22}, {c_ge * gpf[0], c_ge * gpf[1], c_ge * gpf[2]}};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                      if constexpr (decltype(first)::value)
+                        {
+                          A0[c] = wq * F[c][0];
+                          Bs[c] = wq * F[c][1];
+                          B1[c] = wx * F[c][1];
+                          Cs[c] = wq * F[c][2];
+                          C1[c] = wx * F[c][2];
                         }
                       else
                         {
-                          double pfoo = fma(nx1, dpoo, L[5][0]);
-                          if (S.monolithic)
-                            {
-                              pf = fmax(0.0, pf);
-                              pfo = fmax(0.0, pfo);
-                              pfoo = fmax(0.0, pfoo);
-                            }
-                          pen = fmax(0.0, pf - pfo);
-                          pfx = pfoo + S.tfac * (pfo - pfoo);
-                          if (pfx <= 0.0)
-                            pfx = 0.0;
-                          if (pfx >= 1.0)
-                            pfx = 1.0;
-                          if (S.use_old)
-                            pfx = pfo;
+                          A0[c] = fma(wq, F[c][0], A0[c]);
+                          Bs[c] = fma(wq, F[c][1], Bs[c]);
+                          B1[c] = fma(wx, F[c][1], B1[c]);
+                          Cs[c] = fma(wq, F[c][2], Cs[c]);
+                          C1[c] = fma(wx, F[c][2], C1[c]);
                         }
-                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-                      // sigma+ = lambda tr(E) I + 2 mu E; with t_ab = g_ab + g_ba: sigma_ab = mu t_ab and
-                      // sigma : E = sum_a sigma_aa g_aa + sum_{a<b} sigma_ab t_ab
-                      const double t01 = gu[0][1] + gu[1][0], t02 = gu[0][2] + gu[2][0], t12 = gu[1][2] + gu[2][1];
-                      const double trE = gu[0][0] + gu[1][1] + gu[2][2];
-                      const double lt = lam * trE;
-                      const double s00 = fma(mu2, gu[0][0], lt), s11 = fma(mu2, gu[1][1], lt), s22 = fma(mu2, gu[2][2], lt);
-                      const double s01 = mu * t01, s02 = mu * t02, s12 = mu * t12;
-                      const double spE = fma(s00, gu[0][0], fma(s11, gu[1][1], s22 * gu[2][2])) +
-                                         fma(s01, t01, fma(s02, t02, s12 * t12));
-                      const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;
-                      // Z = (g sigma+ - (alpha_B-1) p pfx^2 I) JxW (symmetric)
-                      const double z00 = gJ * s00 - pd, z11 = gJ * s11 - pd, z22 = gJ * s22 - pd;
-                      const double z01 = gJ * s01, z02 = gJ * s02, z12 = gJ * s12;
-                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
-                                         2.0 * S.aB1 * S.p * pf * trE) *
-                                        JxW;
-                      const double ge = S.Gc * S.eps * JxW;
-                      const double F[4][3] = {{z00, z01, z02}, {z01, z11, z12}, {z02, z12, z22},
-                                              {ge * gpf[0], ge * gpf[1], ge * gpf[2]}};
-#pragma unroll
-                      for (int c = 0; c < 4; ++c)
-                        {
-                          X0[c] += F[c][0];
-                          X1[c][0] += F[c][1] * nx0;
-                          X1[c][1] += F[c][1] * nx1;
-                          X2[c][0] += F[c][2] * nx0;
-                          X2[c][1] += F[c][2] * nx1;
-                        }
-                      XS[0] += rq * nx0;
-                      XS[1] += rq * nx1;
-                    }
-                  // y and z factors of the 8 test vertices
+                    if constexpr (decltype(first)::value)
+                      {
+                        rs = wq * rq;
+                        r1 = wx * rq;
+                      }
+                    else
+                      {
+                        rs = fma(wq, rq, rs);
+                        r1 = fma(wx, rq, r1);
+                      }
+                  };
+                  xq(0, std::true_type{});
+                  xq(1, std::false_type{});
+                  xq(2, std::false_type{});
+                  // y and z factors: M[i][j][k] += P Y_j Z_k + B dY_j Z_k + C Y_j dZ_k with (Y, dY) = (1, 0) | (eta, 1/h_y)
+                  const double kx = ihx * wyz, ky = ihy * wyz, kz = ihz * wyz, kze = kz * eta;
 #pragma unroll
                   for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int ax = 0; ax < 2; ++ax)
-                      {
-                        double tA = (ax ? ihx : -ihx) * X0[c];
+                    {
+                      { // x index 1: value factor phi_1 (sums against wx), gradient factor 1/h_x
+                        double P = kx * A0[c];
                         if (c == 3)
-                          tA += XS[ax];
-#pragma unroll
-                        for (int ay = 0; ay < 2; ++ay)
-                          {
-                            const double nay = ay ? ny1 : ny0;
-                            const double uA = nay * tA + (ay ? ihy : -ihy) * X1[c][ax];
-                            const double tC = nay * ihz * X2[c][ax];
-                            R[ax][ay][0][c] -= nz0 * uA - tC;
-                            R[ax][ay][1][c] -= nz1 * uA + tC;
-                          }
+                          P = fma(wyz, r1, P);
+                        const double u = fma(eta, P, ky * B1[c]);
+                        M[1][0][0][c] += P;
+                        M[1][0][1][c] = fma(kz, C1[c], fma(zeta, P, M[1][0][1][c]));
+                        M[1][1][0][c] += u;
+                        M[1][1][1][c] = fma(kze, C1[c], fma(zeta, u, M[1][1][1][c]));
                       }
+                      if (c == 3) // x index 0 (the sum): the gradient factor vanishes, only rq has a value term
+                        {
+                          const double P = wyz * rs;
+                          const double u = fma(eta, P, ky * Bs[c]);
+                          M[0][0][0][c] += P;
+                          M[0][0][1][c] = fma(kz, Cs[c], fma(zeta, P, M[0][0][1][c]));
+                          M[0][1][0][c] += u;
+                          M[0][1][1][c] = fma(kze, Cs[c], fma(zeta, u, M[0][1][1][c]));
+                        }
+                      else
+                        {
+                          const double u = ky * Bs[c];
+                          M[0][0][1][c] = fma(kz, Cs[c], M[0][0][1][c]);
+                          M[0][1][0][c] += u;
+                          M[0][1][1][c] = fma(kze, Cs[c], fma(zeta, u, M[0][1][1][c]));
+                        }
+                    }
                 }
             }
           const bool emit = ck >= kA;
           if (emit)
             {
+              // lower z-vertex part of the layer, then from the moment basis to the vertices in y and x.  A node's a_x = 1
+              // part is this thread's, its a_x = 0 part the next cell column's: lane + 1 of the same 16-lane row
+              // (RTX = 16; the last lane of a row owns no node)
 #pragma unroll
-              for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                  s_P[a * 4 + c][t] = R[a & 1][a >> 1][0][c];
+              for (int c = 0; c < 4; ++c)
+                {
+                  const double l01 = M[0][1][0][c] - M[0][1][1][c], l11 = M[1][1][0][c] - M[1][1][1][c];
+                  const double l00 = (M[0][0][0][c] - M[0][0][1][c]) - l01, l10 = (M[1][0][0][c] - M[1][0][1][c]) - l11;
+                  s_P[0 * 4 + c][t] = l10 + row_shl1(l00 - l10);
+                  s_P[1 * 4 + c][t] = l11 + row_shl1(l01 - l11);
+                }
             }
           __syncthreads();
           if (emit && node_ok)
@@ -824,9 +868,8 @@ namespace pfm
 #pragma unroll
               for (int c = 0; c < 4; ++c)
                 {
-                  // cells (i-1,j-1), (i,j-1), (i-1,j), (i,j) of the plane, lower + upper layer already merged
-                  const double r = ((s_P[3 * 4 + c][t] + s_P[2 * 4 + c][t + 1]) + s_P[1 * 4 + c][t + RTX]) +
-                                   s_P[0 * 4 + c][t + RTX + 1];
+                  // cell columns (i-1,j-1), (i,j-1) | (i-1,j), (i,j) of the plane, lower + upper layer already merged
+                  const double r = -s_P[4 + c][t] - s_P[c][t + RTX];
                   const bool con = (fl >> c) & 1u;
                   const long long di = dof_index_c<3>(v, row, c);
                   res_pde[di] = con ? 0.0 : r; // constrained scatter = masked store (cracks.cc:2440-2456)
@@ -834,14 +877,14 @@ namespace pfm
                     res_tot[di] = (con && S.total_via_update) ? 0.0 : r;
                 }
             }
-          // the upper-vertex part becomes the lower-vertex part of the next layer
+          // the upper-vertex part becomes the lower-vertex part of the next layer (z index 0 = lower + upper)
 #pragma unroll
           for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
               {
-                R[a & 1][a >> 1][0][c] = R[a & 1][a >> 1][1][c];
-                R[a & 1][a >> 1][1][c] = 0.0;
+                M[a & 1][a >> 1][0][c] = M[a & 1][a >> 1][1][c];
+                M[a & 1][a >> 1][1][c] = 0.0;
               }
         }
     }
