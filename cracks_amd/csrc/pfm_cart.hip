@@ -714,7 +714,7 @@ namespace pfm
                           dDz[f] = ihz * (d1 - d0);
                           Dx[f] = ihx * dL[f];
                         }
-                      __builtin_amdgcn_sched_barrier(0); // one field at a time: keeps the 8 nodal values short-lived
+                      if (f & 1) __builtin_amdgcn_sched_barrier(0); // two fields at a time: 16 nodal values in flight
                     }
                   // x-stage: sums over q_x of the fluxes F_c = (Z_c0, Z_c1, Z_c2), c = 3: G_c eps grad phi, and of the value
                   // term rq, against 1 (s) and phi_1 (1); the x-gradient factor needs the plain sum only

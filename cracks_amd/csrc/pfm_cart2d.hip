@@ -17,6 +17,7 @@
 #include "pfm_cart_common.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 
 namespace pfm
@@ -353,6 +354,431 @@ namespace pfm
             }
         }
     }
+
+    // =====================================================================================
+    // Second generation: one wave <-> a block of 8 x 8 cells, lane <-> cell, sum-factorised.
+    //
+    // The lattice is uniform and the law unsplit, so every entry of the element matrix is a moment of a q-point field
+    // against products of 1-D shape functions: lane (c_x, c_y) evaluates the 9 q-point states of ITS cell once and
+    // reduces them to 59 moments (x-sums per q_y line, then the y-factors), forms the rows of vertex A = 3, 2, 1, 0 from
+    // them and hands the rows of the three vertices it does not own to the lanes that do (lane + 9, + 8, + 1: the
+    // node of lane (c_x, c_y) is the lower-left vertex of its cell; the receiver pulls through ds_bpermute).  A node
+    // receives its four cells in the order of a lexicographic cell loop as before; lanes of block row / column 0 only
+    // contribute (7 x 7 owned nodes per wave: 1.31 cell evaluations per node instead of 4, ~1.2k instead of ~1.8k
+    // operations per evaluation).  Rows c = 0, 1 are completed and stored first, then the phase-field row: the moments
+    // and the accumulators of one group fit the registers of two waves per SIMD.  No LDS allocation, no barrier.
+    // =====================================================================================
+    constexpr int B2 = 8, O2 = B2 - 1; // cells per block side, owned nodes per block side
+
+    struct Cst2 // per-launch constants of the sum-factorised kernel
+    {
+      double omk2, aB1p2, aB1p, omk, gc_eps, gc_eps_vol_x, gc_eps_vol_y; // 2(1-kappa), 2(aB-1)p, (aB-1)p, 1-kappa, G_c/eps, G_c eps vol/h_x^2, .../h_y^2
+      double gce;                                                        // G_c eps
+    };
+
+    __global__ __launch_bounds__(64, 2) void k_cart2d_cells(DevView v, CartView cv, Prm2 P, Cst2 K, Vals2 vals, double *__restrict__ res_pde,
+                                                            double *__restrict__ res_tot, int write_total, int total_via_update)
+    {
+      const int lane = threadIdx.x, cx = lane & (B2 - 1), cy = lane >> 3;
+      const int OWX = cv.o1[0] - cv.o0[0] + 1;
+      const int ntx = (OWX + O2 - 1) / O2;
+      const int tix = (int)(blockIdx.x % ntx), tiy = (int)(blockIdx.x / ntx);
+      // this lane's cell (i, j) = its lower-left node
+      const int i = cv.o0[0] + tix * O2 + cx - 1, j = cv.o0[1] + tiy * O2 + cy - 1;
+      const bool owner = cx >= 1 && cy >= 1 && i <= cv.o1[0] && j <= cv.o1[1];
+      bool cell_ok = i >= 0 && i < cv.NX - 1 && j >= 0 && j < cv.NY - 1;
+
+      // ---- nodal data of the cell: [field][vertex b = b_x + 2 b_y], fields u_x u_y phi phi_old phi_oldold
+      double F[5][4];
+#pragma unroll
+      for (int f = 0; f < 5; ++f)
+        F[f][0] = F[f][1] = F[f][2] = F[f][3] = 0.0;
+      if (cell_ok)
+        {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            {
+              const int n = cart_local_id(cv, i + (b & 1), j + (b >> 1), 0);
+              if (n < 0)
+                {
+                  cell_ok = false; // a cell this rank does not know completely touches none of its rows
+                  continue;
+                }
+              F[0][b] = v.u[0][n];
+              F[1][b] = v.u[1][n];
+              F[2][b] = v.phi[n];
+              F[3][b] = v.phi_old[n];
+              F[4][b] = v.phi_oldold[n];
+            }
+        }
+      double lam = P.lam, mu = P.mu;
+      if (cv.cell_lam && cell_ok) // heterogeneous material, cracks.cc:2207-2216
+        {
+          lam = cv.cell_lam[i + (long long)(cv.NX - 1) * j];
+          mu = cv.cell_mu[i + (long long)(cv.NX - 1) * j];
+        }
+      const double mu2 = 2.0 * mu;
+
+      // ---- moments (names: field, then the 1-D functions along x / y: 1, n_a, m_g = (n_0 n_0, n_0 n_1, n_1 n_1))
+      double Mxx[3], Mxy[2][2], Myy[3];                 // g w JxW:   [1][m], [n][n], [m][1]
+      double Px0[2][3], Px1[2][3], Py0[3][2], Py1[3][2]; // T_d,x: [n][m];  T_d,y: [m][n]
+      double Q[3][3];                                   // C: [m][m]
+      double RZx0[2], RZx1[2], RZy0[2], RZy1[2];        // Z_c,x: [1][n];  Z_c,y: [n][1]
+      double RS[2][2], RHx[2], RHy[2];                  // S: [n][n];  H_x: [1][n];  H_y: [n][1]
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        {
+          Mxx[a] = Myy[a] = 0.0;
+          Q[a][0] = Q[a][1] = Q[a][2] = 0.0;
+          Py0[a][0] = Py0[a][1] = Py1[a][0] = Py1[a][1] = 0.0;
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        {
+          Mxy[a][0] = Mxy[a][1] = 0.0;
+          Px0[a][0] = Px0[a][1] = Px0[a][2] = Px1[a][0] = Px1[a][1] = Px1[a][2] = 0.0;
+          RZx0[a] = RZx1[a] = RZy0[a] = RZy1[a] = RS[a][0] = RS[a][1] = RHx[a] = RHy[a] = 0.0;
+        }
+      if (cell_ok)
+        {
+          double Dy0[3], dDy[3]; // d/dy of u_x u_y phi at x-vertex 0 and its x-difference: constant in the cell
+#pragma unroll
+          for (int f = 0; f < 3; ++f)
+            {
+              Dy0[f] = (F[f][2] - F[f][0]) * P.ihy;
+              dDy[f] = (F[f][3] - F[f][1]) * P.ihy - Dy0[f];
+            }
+#pragma unroll 1
+          for (int qy = 0; qy < 3; ++qy)
+            {
+              const double ny0 = c_g1.n[0][qy], ny1 = c_g1.n[1][qy];
+              const double wy = P.vol * c_g1.w[qy];
+              double L0[5], dL[5];
+#pragma unroll
+              for (int f = 0; f < 5; ++f)
+                {
+                  L0[f] = ny0 * F[f][0] + ny1 * F[f][2];
+                  dL[f] = (ny0 * F[f][1] + ny1 * F[f][3]) - L0[f];
+                }
+              const double g00 = dL[0] * P.ihx, g10 = dL[1] * P.ihx, gpx = dL[2] * P.ihx; // d/dx: constant along the line
+              double Xg1 = 0.0, Xgn[2] = {0.0, 0.0}, Xgm[3] = {0.0, 0.0, 0.0};
+              double XT00n[2] = {0.0, 0.0}, XT01n[2] = {0.0, 0.0}, XT01m[3] = {0.0, 0.0, 0.0}, XT11m[3] = {0.0, 0.0, 0.0};
+              double XCm[3] = {0.0, 0.0, 0.0};
+              double XZ00 = 0.0, XZ01 = 0.0, XZ01n[2] = {0.0, 0.0}, XZ11n[2] = {0.0, 0.0};
+              double XSn[2] = {0.0, 0.0}, XHx = 0.0, XHyn[2] = {0.0, 0.0};
+#pragma unroll
+              for (int qx = 0; qx < 3; ++qx)
+                {
+                  const double nx0 = c_g1.n[0][qx], nx1 = c_g1.n[1][qx];
+                  const double m0 = c_g1.m[0][qx], m1 = c_g1.m[1][qx], m2 = c_g1.m[2][qx];
+                  const double JxW = wy * c_g1.w[qx];
+                  // Newton state at q (cracks.cc:2222-2232)
+                  const double g01 = fma(nx1, dDy[0], Dy0[0]), g11 = fma(nx1, dDy[1], Dy0[1]), gpy = fma(nx1, dDy[2], Dy0[2]);
+                  double pf = fma(nx1, dL[2], L0[2]), pfo = fma(nx1, dL[3], L0[3]), pfoo = fma(nx1, dL[4], L0[4]);
+                  // q-point state, cracks.cc:2248-2306
+                  if (P.monolithic)
+                    {
+                      pf = fmax(0.0, pf);
+                      pfo = fmax(0.0, pfo);
+                      pfoo = fmax(0.0, pfoo);
+                    }
+                  const double pen_plus = fmax(0.0, pf - pfo);
+                  const bool pen_on = !((pf - pfo) < 0.0); // shadowed variable, cracks.cc:2311-2315
+                  double pfx = pfoo + P.tfac * (pfo - pfoo);
+                  if (pfx <= 0.0)
+                    pfx = 0.0;
+                  if (pfx >= 1.0)
+                    pfx = 1.0;
+                  if (P.use_old)
+                    pfx = pfo;
+                  const double pf2 = pfx * pfx;
+                  const double g = fma(K.omk, pf2, P.kappa);
+                  const double trE = g00 + g11, t01 = g01 + g10;
+                  const double lt = lam * trE;
+                  const double s00 = fma(mu2, g00, lt), s11 = fma(mu2, g11, lt), s01 = mu * t01; // sigma+ (no split: cracks.cc:2299-2305)
+                  const double spE = fma(s00, g00, fma(s11, g11, s01 * t01));
+                  // the integrands (module header): Jacobian
+                  const double gw = g * JxW;
+                  const double pj = pf * JxW;
+                  const double T00 = pj * fma(K.omk2, s00, -K.aB1p2), T11 = pj * fma(K.omk2, s11, -K.aB1p2), T01 = pj * (K.omk2 * s01);
+                  const double C = JxW * (fma(K.omk, spE, K.gc_eps) - K.aB1p2 * trE + (pen_on ? P.penal_fac : 0.0));
+                  // residual
+                  const double pd = K.aB1p * pf2;
+                  const double Z00 = JxW * fma(g, s00, -pd), Z11 = JxW * fma(g, s11, -pd), Z01 = gw * s01;
+                  const double Sq = JxW * (P.penal_fac * pen_plus + fma(pf, fma(-K.aB1p2, trE, fma(K.omk, spE, K.gc_eps)), -K.gc_eps));
+                  const double Hx = (K.gce * JxW) * gpx, Hy = (K.gce * JxW) * gpy;
+                  // x-sums
+                  Xg1 += gw;
+                  Xgn[0] = fma(gw, nx0, Xgn[0]), Xgn[1] = fma(gw, nx1, Xgn[1]);
+                  Xgm[0] = fma(gw, m0, Xgm[0]), Xgm[1] = fma(gw, m1, Xgm[1]), Xgm[2] = fma(gw, m2, Xgm[2]);
+                  XT00n[0] = fma(T00, nx0, XT00n[0]), XT00n[1] = fma(T00, nx1, XT00n[1]);
+                  XT01n[0] = fma(T01, nx0, XT01n[0]), XT01n[1] = fma(T01, nx1, XT01n[1]);
+                  XT01m[0] = fma(T01, m0, XT01m[0]), XT01m[1] = fma(T01, m1, XT01m[1]), XT01m[2] = fma(T01, m2, XT01m[2]);
+                  XT11m[0] = fma(T11, m0, XT11m[0]), XT11m[1] = fma(T11, m1, XT11m[1]), XT11m[2] = fma(T11, m2, XT11m[2]);
+                  XCm[0] = fma(C, m0, XCm[0]), XCm[1] = fma(C, m1, XCm[1]), XCm[2] = fma(C, m2, XCm[2]);
+                  XZ00 += Z00;
+                  XZ01 += Z01;
+                  XZ01n[0] = fma(Z01, nx0, XZ01n[0]), XZ01n[1] = fma(Z01, nx1, XZ01n[1]);
+                  XZ11n[0] = fma(Z11, nx0, XZ11n[0]), XZ11n[1] = fma(Z11, nx1, XZ11n[1]);
+                  XSn[0] = fma(Sq, nx0, XSn[0]), XSn[1] = fma(Sq, nx1, XSn[1]);
+                  XHx += Hx;
+                  XHyn[0] = fma(Hy, nx0, XHyn[0]), XHyn[1] = fma(Hy, nx1, XHyn[1]);
+                }
+              // y-factors of the line
+              const double my[3] = {c_g1.m[0][qy], c_g1.m[1][qy], c_g1.m[2][qy]}, ny[2] = {ny0, ny1};
+#pragma unroll
+              for (int g = 0; g < 3; ++g)
+                {
+                  Mxx[g] = fma(Xg1, my[g], Mxx[g]);
+                  Myy[g] += Xgm[g];
+#pragma unroll
+                  for (int a = 0; a < 2; ++a)
+                    {
+                      Px0[a][g] = fma(XT00n[a], my[g], Px0[a][g]);
+                      Px1[a][g] = fma(XT01n[a], my[g], Px1[a][g]);
+                      Py0[g][a] = fma(XT01m[g], ny[a], Py0[g][a]);
+                      Py1[g][a] = fma(XT11m[g], ny[a], Py1[g][a]);
+                    }
+#pragma unroll
+                  for (int h = 0; h < 3; ++h)
+                    Q[g][h] = fma(XCm[g], my[h], Q[g][h]);
+                }
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+                {
+                  Mxy[a][0] = fma(Xgn[0], ny[a], Mxy[a][0]); // [A_y][b_x]
+                  Mxy[a][1] = fma(Xgn[1], ny[a], Mxy[a][1]);
+                  RZx0[a] = fma(XZ00, ny[a], RZx0[a]);
+                  RZx1[a] = fma(XZ01, ny[a], RZx1[a]);
+                  RZy0[a] += XZ01n[a];
+                  RZy1[a] += XZ11n[a];
+                  RS[0][a] = fma(XSn[0], ny[a], RS[0][a]); // [A_x][A_y]
+                  RS[1][a] = fma(XSn[1], ny[a], RS[1][a]);
+                  RHx[a] = fma(XHx, ny[a], RHx[a]);
+                  RHy[a] += XHyn[a];
+                }
+            }
+        }
+
+      // ---- entries of the element matrix from the moments
+      const double ihx2 = P.ihx * P.ihx, ihy2 = P.ihy * P.ihy, ihxy = P.ihx * P.ihy;
+      const double kxx_d = (lam + mu2) * ihx2, kxx_o = mu * ihx2, kyy_d = (lam + mu2) * ihy2, kyy_o = mu * ihy2;
+      const double kl = lam * ihxy, km = mu * ihxy;
+      auto uu_entry = [&](auto Aa, auto Bb, auto Cc, auto Dd) __attribute__((always_inline)) -> double {
+        constexpr int A = decltype(Aa)::value, b = decltype(Bb)::value, c = decltype(Cc)::value, d = decltype(Dd)::value;
+        constexpr int Ax = A & 1, Ay = A >> 1, bx = b & 1, by = b >> 1;
+        constexpr double sxx = ((Ax == bx) ? 1.0 : -1.0), syy = ((Ay == by) ? 1.0 : -1.0);
+        if constexpr (c == 0 && d == 0)
+          return fma(sxx * kxx_d, Mxx[Ay + by], (syy * kyy_o) * Myy[Ax + bx]);
+        else if constexpr (c == 1 && d == 1)
+          return fma(syy * kyy_d, Myy[Ax + bx], (sxx * kxx_o) * Mxx[Ay + by]);
+        else
+          {
+            // G_xy = s(A_x) s(b_y) M_xy[A_y][b_x],  G_yx = s(A_y) s(b_x) M_xy[b_y][A_x]
+            constexpr double sxy = ((Ax == 1) == (by == 1)) ? 1.0 : -1.0, syx = ((Ay == 1) == (bx == 1)) ? 1.0 : -1.0;
+            if constexpr (c == 0) // lambda G_xy + mu G_yx
+              return fma(sxy * kl, Mxy[Ay][bx], (syx * km) * Mxy[by][Ax]);
+            else // lambda G_yx + mu G_xy
+              return fma(syx * kl, Mxy[by][Ax], (sxy * km) * Mxy[Ay][bx]);
+          }
+      };
+      auto pu_entry = [&](auto Aa, auto Bb, auto Dd) __attribute__((always_inline)) -> double {
+        constexpr int A = decltype(Aa)::value, b = decltype(Bb)::value, d = decltype(Dd)::value;
+        constexpr int Ax = A & 1, Ay = A >> 1, bx = b & 1, by = b >> 1;
+        constexpr double sx = bx ? 1.0 : -1.0, sy = by ? 1.0 : -1.0;
+        if constexpr (d == 0)
+          return fma(sx * P.ihx, Px0[Ax][Ay + by], (sy * P.ihy) * Py0[Ax + bx][Ay]);
+        else
+          return fma(sx * P.ihx, Px1[Ax][Ay + by], (sy * P.ihy) * Py1[Ax + bx][Ay]);
+      };
+      auto pp_entry = [&](auto Aa, auto Bb) __attribute__((always_inline)) -> double {
+        constexpr int A = decltype(Aa)::value, b = decltype(Bb)::value;
+        constexpr int Ax = A & 1, Ay = A >> 1, bx = b & 1, by = b >> 1;
+        constexpr double sxx = ((Ax == bx) ? 1.0 : -1.0), syy = ((Ay == by) ? 1.0 : -1.0);
+        // G_c eps sum_q JxW grad N_A . grad N_b: the same for every cell of the box
+        const double lap = (sxx * K.gc_eps_vol_x) * c_g1.mb[Ay + by] + (syy * K.gc_eps_vol_y) * c_g1.mb[Ax + bx];
+        return cell_ok ? Q[Ax + bx][Ay + by] + lap : 0.0;
+      };
+      auto res_entry = [&](auto Aa, auto Cc) __attribute__((always_inline)) -> double {
+        constexpr int A = decltype(Aa)::value, c = decltype(Cc)::value;
+        constexpr int Ax = A & 1, Ay = A >> 1;
+        constexpr double sx = Ax ? 1.0 : -1.0, sy = Ay ? 1.0 : -1.0;
+        if constexpr (c == 0)
+          return -fma(sx * P.ihx, RZx0[Ay], (sy * P.ihy) * RZy0[Ax]);
+        else if constexpr (c == 1)
+          return -fma(sx * P.ihx, RZx1[Ay], (sy * P.ihy) * RZy1[Ax]);
+        else
+          return -(RS[Ax][Ay] + fma(sx * P.ihx, RHx[Ay], (sy * P.ihy) * RHy[Ax]));
+      };
+      using std::integral_constant;
+      // mean |diagonal| of the element matrix: deal.II's placeholder when a constrained row's own entry vanishes
+      double avg = 0.0;
+      static_for<4>([&](auto Aa) __attribute__((always_inline)) {
+        avg += fabs(uu_entry(Aa, Aa, integral_constant<int, 0>{}, integral_constant<int, 0>{})) +
+               fabs(uu_entry(Aa, Aa, integral_constant<int, 1>{}, integral_constant<int, 1>{})) + fabs(pp_entry(Aa, Aa));
+      });
+      avg *= 1.0 / 12.0;
+
+      // ---- the node of this lane: row info
+      int row = 0;
+      unsigned fP = 0u, mask = 0u;
+      long long off = 0;
+      bool writes = owner;
+      if (owner && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
+        writes = false; // overlapped assembly: the other launch owns this node's rows
+      if (writes)
+        {
+          row = cart_local_id(cv, i, j, 0);
+          fP = v.node_flags[row];
+          mask = cv.nbr_mask[row];
+          off = v.nadj_ptr[row];
+        }
+      const int deg = __popc(mask & 0x1ffu);
+      const bool blocked = v.layout == PFM_LAYOUT_BLOCKED;
+      // what the lane of vertex A's node pulls from this cell: lane - 9, - 8, - 1 for A = 3, 2, 1 (own cell: A = 0)
+      auto pull = [&](auto Aa, double x) __attribute__((always_inline)) -> double {
+        constexpr int A = decltype(Aa)::value;
+        if constexpr (A == 0)
+          return x;
+        else
+          return __shfl(x, lane - ((A & 1) + B2 * (A >> 1)));
+      };
+      auto slot_of = [&](int o) __attribute__((always_inline)) -> int {
+        int sl = __popc(mask & ((1u << o) - 1u));
+        if (mask >> 31)
+          sl = cv.row_perm[off + sl];
+        return sl;
+      };
+
+      // ---- rows c = 0, 1: (u,u) block, the (u,phi) block is structurally zero (cracks.cc:2333-2337)
+      {
+        double acc[9][2][2], R[2] = {0.0, 0.0}, dg[2] = {0.0, 0.0};
+#pragma unroll
+        for (int o = 0; o < 9; ++o)
+          acc[o][0][0] = acc[o][0][1] = acc[o][1][0] = acc[o][1][1] = 0.0;
+        static_for<4>([&](auto Ee) __attribute__((always_inline)) {
+          constexpr int A = 3 - decltype(Ee)::value, ax = A & 1, ay = A >> 1;
+          using IA = integral_constant<int, A>;
+          const double avg_e = pull(IA{}, avg);
+          static_for<4>([&](auto Bb) __attribute__((always_inline)) {
+            constexpr int b = decltype(Bb)::value, o = ((b & 1) - ax + 1) + 3 * ((b >> 1) - ay + 1);
+            static_for<2>([&](auto Cc) __attribute__((always_inline)) {
+              static_for<2>([&](auto Dd) __attribute__((always_inline)) {
+                constexpr int c = decltype(Cc)::value, d = decltype(Dd)::value;
+                const double x = pull(IA{}, uu_entry(IA{}, Bb, Cc, Dd));
+                acc[o][c][d] += x;
+                if constexpr (b == A && c == d)
+                  {
+                    const double k = fabs(x);
+                    dg[c] += k != 0.0 ? k : avg_e;
+                  }
+              });
+            });
+          });
+          R[0] += pull(IA{}, res_entry(IA{}, integral_constant<int, 0>{}));
+          R[1] += pull(IA{}, res_entry(IA{}, integral_constant<int, 1>{}));
+        });
+        if (writes)
+          {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              {
+                const bool con = (fP >> c) & 1u;
+                const long long di = blocked ? (long long)row * 2 + c : (long long)row * 3 + c;
+                res_pde[di] = con ? 0.0 : R[c]; // constrained scatter as masks (cracks.cc:2439-2464)
+                if (write_total)
+                  res_tot[di] = (con && total_via_update) ? 0.0 : R[c];
+              }
+#pragma unroll
+            for (int o = 0; o < 9; ++o)
+              {
+                if (!((mask >> o) & 1u))
+                  continue;
+                const int sl = slot_of(o);
+                const int q = cart_local_id(cv, i + (o % 3) - 1, j + (o / 3) - 1, 0);
+                const unsigned fQ = v.node_flags[q];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                  {
+                    const bool rcon = (fP >> c) & 1u;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                      {
+                        double x = d < 2 ? acc[o][c][d < 2 ? d : 0] : 0.0;
+                        if (rcon)
+                          x = (o == 4 && c == d) ? dg[c] : 0.0;
+                        else if ((fQ >> d) & 1u)
+                          x = 0.0;
+                        double *dst;
+                        if (!blocked)
+                          dst = vals.b[0] + (9 * off + (long long)c * 3 * deg + (long long)sl * 3 + d);
+                        else
+                          dst = d < 2 ? vals.b[0] + (4 * off + (long long)c * 2 * deg + (long long)sl * 2 + d)
+                                      : vals.b[1] + (2 * off + (long long)c * deg + sl);
+                        *dst = x;
+                      }
+                  }
+              }
+          }
+      }
+      // ---- row c = 2: (phi,u) and (phi,phi) blocks
+      {
+        double apu[9][2], app[9], R2 = 0.0, dg2 = 0.0;
+#pragma unroll
+        for (int o = 0; o < 9; ++o)
+          apu[o][0] = apu[o][1] = app[o] = 0.0;
+        static_for<4>([&](auto Ee) __attribute__((always_inline)) {
+          constexpr int A = 3 - decltype(Ee)::value, ax = A & 1, ay = A >> 1;
+          using IA = integral_constant<int, A>;
+          const double avg_e = pull(IA{}, avg);
+          static_for<4>([&](auto Bb) __attribute__((always_inline)) {
+            constexpr int b = decltype(Bb)::value, o = ((b & 1) - ax + 1) + 3 * ((b >> 1) - ay + 1);
+            apu[o][0] += pull(IA{}, pu_entry(IA{}, Bb, integral_constant<int, 0>{}));
+            apu[o][1] += pull(IA{}, pu_entry(IA{}, Bb, integral_constant<int, 1>{}));
+            const double x = pull(IA{}, pp_entry(IA{}, Bb));
+            app[o] += x;
+            if constexpr (b == A)
+              {
+                const double k = fabs(x);
+                dg2 += k != 0.0 ? k : avg_e;
+              }
+          });
+          R2 += pull(IA{}, res_entry(IA{}, integral_constant<int, 2>{}));
+        });
+        if (writes)
+          {
+            const bool rcon = (fP >> 2) & 1u;
+            const long long di = blocked ? (long long)v.n_owned * 2 + row : (long long)row * 3 + 2;
+            res_pde[di] = rcon ? 0.0 : R2;
+            if (write_total)
+              res_tot[di] = (rcon && total_via_update) ? 0.0 : R2;
+#pragma unroll
+            for (int o = 0; o < 9; ++o)
+              {
+                if (!((mask >> o) & 1u))
+                  continue;
+                const int sl = slot_of(o);
+                const int q = cart_local_id(cv, i + (o % 3) - 1, j + (o / 3) - 1, 0);
+                const unsigned fQ = v.node_flags[q];
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                  {
+                    double x = d < 2 ? apu[o][d < 2 ? d : 0] : app[o];
+                    if (rcon)
+                      x = (o == 4 && d == 2) ? dg2 : 0.0;
+                    else if ((fQ >> d) & 1u)
+                      x = 0.0;
+                    double *dst;
+                    if (!blocked)
+                      dst = vals.b[0] + (9 * off + (long long)2 * 3 * deg + (long long)sl * 3 + d);
+                    else
+                      dst = d < 2 ? vals.b[2] + (2 * off + (long long)sl * 2 + d) : vals.b[3] + (off + sl);
+                    *dst = x;
+                  }
+              }
+          }
+      }
+    }
   } // namespace
 
   // 2-D cartesian boxes: Jacobian + residual without the stress split (the plain 2-D residual has its own kernel in
@@ -395,10 +821,26 @@ namespace pfm
 #define PFM_L2D(F) hipLaunchKernelGGL((k_cart2d_rows<F>), dim3(nb), dim3(128), 0, s, v, cv, P, vals, res_pde, res_tot, residual_only, total_via_update)
     if (split)
       return PFM_ERR_UNSUPPORTED; // stress-split runs stay on the general family (header of this file, pfm_host.cpp)
+    static const bool first_gen = getenv("PFM_CART2D_OLD") != nullptr; // A/B: the row-owner kernel of round 2
     if (residual_only)
       PFM_L2D(false);
-    else
+    else if (first_gen)
       PFM_L2D(true);
+    else
+      {
+        Cst2 K{};
+        K.omk = 1.0 - P.kappa;
+        K.omk2 = 2.0 * (1.0 - P.kappa);
+        K.aB1p = P.aB1 * P.p;
+        K.aB1p2 = 2.0 * P.aB1 * P.p;
+        K.gc_eps = P.Gc / P.eps;
+        K.gce = P.Gc * P.eps;
+        K.gc_eps_vol_x = P.Gc * P.eps * P.vol * P.ihx * P.ihx;
+        K.gc_eps_vol_y = P.Gc * P.eps * P.vol * P.ihy * P.ihy;
+        const long long ntx = (cv.o1[0] - cv.o0[0] + 1 + O2 - 1) / O2, nty = (cv.o1[1] - cv.o0[1] + 1 + O2 - 1) / O2;
+        hipLaunchKernelGGL(k_cart2d_cells, dim3((unsigned)(ntx * nty)), dim3(64), 0, s, v, cv, P, K, vals, res_pde, res_tot, residual_only,
+                           total_via_update);
+      }
 #undef PFM_L2D
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
