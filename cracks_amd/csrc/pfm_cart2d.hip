@@ -635,6 +635,36 @@ namespace pfm
         }
       const int deg = __popc(mask & 0x1ffu);
       const bool blocked = v.layout == PFM_LAYOUT_BLOCKED;
+      // Blocked layout: the rows of the 7 nodes of a block row are one contiguous piece of each of the four value arrays
+      // when the nodes are consecutive CSR rows -- they are staged in LDS and stored as whole cache lines (a lane
+      // storing its own 81 values touches 49 lines per store instruction, and the L2 sees 8 partial writes per line:
+      // the first version of this kernel spent 81 % of its wave cycles waiting on that).
+      __shared__ double s_rows[O2][4 * 9 * O2];
+      const int lane_first = cy * B2 + 1;                              // first owner lane of this block row
+      const int n_row = min(O2, cv.o1[0] - (cv.o0[0] + tix * O2) + 1); // owned nodes in a block row
+      const long long off_first = __shfl(off, lane_first);
+      const long long off_next = __shfl(off, lane + 1);
+      const bool chain_ok = !owner || (writes && (cx == n_row || off_next == off + deg)); // consecutive CSR rows
+      const bool staged = blocked && __all(chain_ok);
+      const int rel = (int)(off - off_first); // position of this node's row in the block row, in entries
+      const long long row_len = __shfl(off + deg, cy * B2 + n_row) - off_first; // entries of the block row
+      const bool row_live = cy >= 1 && (cv.o0[1] + tiy * O2 + cy - 1) <= cv.o1[1];
+      // stores `len` staged doubles of every live block row to dst + scale * off_first
+      auto flush = [&](double *dst, int scale, int base) __attribute__((always_inline)) {
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < O2; ++r)
+          {
+            const long long o_f = __shfl(off_first, (r + 1) * B2 + 1);
+            const int len = scale * (int)__shfl(row_len, (r + 1) * B2 + 1);
+            const bool live = __shfl((int)row_live, (r + 1) * B2 + 1) != 0;
+            if (!live)
+              continue;
+            for (int k = lane; k < len; k += 64)
+              dst[scale * o_f + k] = s_rows[r][base + k];
+          }
+        __syncthreads();
+      };
       // what the lane of vertex A's node pulls from this cell: lane - 9, - 8, - 1 for A = 3, 2, 1 (own cell: A = 0)
       auto pull = [&](auto Aa, double x) __attribute__((always_inline)) -> double {
         constexpr int A = decltype(Aa)::value;
@@ -709,6 +739,12 @@ namespace pfm
                           x = (o == 4 && c == d) ? dg[c] : 0.0;
                         else if ((fQ >> d) & 1u)
                           x = 0.0;
+                        if (staged)
+                          {
+                            if (d < 2)
+                              s_rows[cy - 1][4 * rel + c * 2 * deg + sl * 2 + d] = x;
+                            continue; // the (u,phi) block is zero-filled below
+                          }
                         double *dst;
                         if (!blocked)
                           dst = vals.b[0] + (9 * off + (long long)c * 3 * deg + (long long)sl * 3 + d);
@@ -718,6 +754,20 @@ namespace pfm
                         *dst = x;
                       }
                   }
+              }
+          }
+        if (staged)
+          {
+            flush(vals.b[0], 4, 0);
+#pragma unroll 1
+            for (int r = 0; r < O2; ++r) // (u,phi): structurally zero (cracks.cc:2333-2337)
+              {
+                const long long o_f = __shfl(off_first, (r + 1) * B2 + 1);
+                const int len = 2 * (int)__shfl(row_len, (r + 1) * B2 + 1);
+                if (__shfl((int)row_live, (r + 1) * B2 + 1) == 0)
+                  continue;
+                for (int k = lane; k < len; k += 64)
+                  vals.b[1][2 * o_f + k] = 0.0;
               }
           }
       }
@@ -768,6 +818,14 @@ namespace pfm
                       x = (o == 4 && d == 2) ? dg2 : 0.0;
                     else if ((fQ >> d) & 1u)
                       x = 0.0;
+                    if (staged)
+                      {
+                        if (d < 2)
+                          s_rows[cy - 1][2 * rel + sl * 2 + d] = x;
+                        else
+                          s_rows[cy - 1][2 * 9 * O2 + rel + sl] = x;
+                        continue;
+                      }
                     double *dst;
                     if (!blocked)
                       dst = vals.b[0] + (9 * off + (long long)2 * 3 * deg + (long long)sl * 3 + d);
@@ -775,6 +833,22 @@ namespace pfm
                       dst = d < 2 ? vals.b[2] + (2 * off + (long long)sl * 2 + d) : vals.b[3] + (off + sl);
                     *dst = x;
                   }
+              }
+          }
+        if (staged)
+          {
+            __syncthreads();
+#pragma unroll 1
+            for (int r = 0; r < O2; ++r)
+              {
+                const long long o_f = __shfl(off_first, (r + 1) * B2 + 1);
+                const int len = (int)__shfl(row_len, (r + 1) * B2 + 1);
+                if (__shfl((int)row_live, (r + 1) * B2 + 1) == 0)
+                  continue;
+                for (int k = lane; k < 2 * len; k += 64)
+                  vals.b[2][2 * o_f + k] = s_rows[r][k];
+                for (int k = lane; k < len; k += 64)
+                  vals.b[3][o_f + k] = s_rows[r][2 * 9 * O2 + k];
               }
           }
       }
