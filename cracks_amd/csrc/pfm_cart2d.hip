@@ -1,18 +1,17 @@
-// pfm_cart2d.hip — 2-D row-owner kernel for uniform Cartesian boxes: Jacobian + residual (cracks.cc:2200-2464) of the
-// 2-D Sneddon configurations (tests/sneddon_2d_1.prm on a uniform mesh, BASELINE config 2 with the matrix).  Runs with
-// the stress split of cracks.cc:2294 active stay on the general family: a row owner would evaluate the linearised split
-// of every trial dof 12 times (4 cells around the node x 3 row components to fit the registers) where the general
-// family's quad evaluates it once (pfm_kernels.hip); the launcher refuses them and the host routes them there.
+// pfm_cart2d.hip — 2-D Jacobian + residual kernels for uniform Cartesian boxes (cracks.cc:2200-2464): the 2-D Sneddon
+// configurations (tests/sneddon_2d_1.prm on a uniform mesh, BASELINE config 2 with the matrix).  Runs with the stress split
+// of cracks.cc:2294 active stay on the general family (the linearised split is not a moment of a q-point field; the
+// launcher refuses them and the host routes them there).
 //
-// Work is assigned by output row: thread <-> owned node.  The thread visits the (up to) 4 cells around its node and
-// integrates, per cell, only the 3 rows of its own vertex -- the loop body of cracks.cc:2308-2432 for j = (a, c) -- into
-// 81 register accumulators (9 neighbour slots x 3 row components x 3 column components) in a fixed cell order, applies the
-// constraints as masks and writes every value of its rows exactly once: no atomics, no zeroing pass, bitwise reproducible.
-// Every q-point state is evaluated by the 4 threads around the cell (4x redundant; in 2-D the state is ~60 flops, the
-// entries ~400 per q-point) -- the price for not staging anything: the kernel has no LDS and no barrier.
-//
-// The 3-D family (pfm_cart_uu3/phi4) sum-factorises the element matrix; this kernel integrates the reference's formulas
-// directly (9 q-points, the unsplit law written out).
+// Two generations, both without atomics or a zeroing pass, every value of a row written exactly once, constraints applied
+// as masks, bitwise reproducible:
+//   k_cart2d_cells (default, round 3): wave <-> block of 8 x 8 cells, lane <-> cell.  The 9 q-point states of a cell are
+//     evaluated ONCE and reduced to 59 moments; the rows of the cell's four vertices are formed from the moments and handed
+//     to the lanes that own the nodes (ds_bpermute), which complete their rows in the order of a lexicographic cell loop.
+//     Block rows are staged in LDS and stored as whole cache lines.  0.31 ms at 1000^2 (first generation: 0.85 ms).
+//   k_cart2d_rows (PFM_CART2D_OLD=1; residual-only variant unused by the launcher): thread <-> node, the 4 cells around
+//     the node integrated directly (9 q-points, the unsplit law written out) into 81 register accumulators -- every
+//     q-point state evaluated by 4 threads, every value stored as a lone 8-byte write.
 #include "pfm_internal.h"
 #include "pfm_cart_common.h"
 
@@ -411,6 +410,34 @@ namespace pfm
               F[4][b] = v.phi_oldold[n];
             }
         }
+      // ---- the node of this lane: row info and the constraint flags of the 9 lattice neighbours, requested before the
+      // arithmetic (a load per neighbour inside the store loops is a chain of exposed round trips)
+      int row = 0;
+      unsigned fP = 0u, mask = 0u, fN = 0u; // fN: 3 flag bits per lattice offset o
+      long long off = 0;
+      bool writes = owner;
+      if (owner && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
+        writes = false; // overlapped assembly: the other launch owns this node's rows
+      if (writes)
+        {
+          row = cart_local_id(cv, i, j, 0);
+          fP = v.node_flags[row];
+          mask = cv.nbr_mask[row];
+          off = v.nadj_ptr[row];
+          unsigned fl[9];
+#pragma unroll
+          for (int o = 0; o < 9; ++o)
+            {
+              const int qi = i + (o % 3) - 1, qj = j + (o / 3) - 1;
+              int q = -1;
+              if (qi >= 0 && qi < cv.NX && qj >= 0 && qj < cv.NY)
+                q = cart_local_id(cv, qi, qj, 0);
+              fl[o] = q >= 0 ? (unsigned)v.node_flags[q] & 7u : 0u;
+            }
+#pragma unroll
+          for (int o = 0; o < 9; ++o)
+            fN |= fl[o] << (3 * o);
+        }
       double lam = P.lam, mu = P.mu;
       if (cv.cell_lam && cell_ok) // heterogeneous material, cracks.cc:2207-2216
         {
@@ -619,39 +646,27 @@ namespace pfm
       });
       avg *= 1.0 / 12.0;
 
-      // ---- the node of this lane: row info
-      int row = 0;
-      unsigned fP = 0u, mask = 0u;
-      long long off = 0;
-      bool writes = owner;
-      if (owner && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
-        writes = false; // overlapped assembly: the other launch owns this node's rows
-      if (writes)
-        {
-          row = cart_local_id(cv, i, j, 0);
-          fP = v.node_flags[row];
-          mask = cv.nbr_mask[row];
-          off = v.nadj_ptr[row];
-        }
       const int deg = __popc(mask & 0x1ffu);
       const bool blocked = v.layout == PFM_LAYOUT_BLOCKED;
       // Blocked layout: the rows of the 7 nodes of a block row are one contiguous piece of each of the four value arrays
       // when the nodes are consecutive CSR rows -- they are staged in LDS and stored as whole cache lines (a lane
       // storing its own 81 values touches 49 lines per store instruction, and the L2 sees 8 partial writes per line:
       // the first version of this kernel spent 81 % of its wave cycles waiting on that).
-      __shared__ double s_rows[O2][4 * 9 * O2];
+      __shared__ double s_rows[O2][4 * 9 * O2 + 5]; // 257: block rows start 2 banks apart
       const int lane_first = cy * B2 + 1;                              // first owner lane of this block row
       const int n_row = min(O2, cv.o1[0] - (cv.o0[0] + tix * O2) + 1); // owned nodes in a block row
       const long long off_first = __shfl(off, lane_first);
       const long long off_next = __shfl(off, lane + 1);
       const bool chain_ok = !owner || (writes && (cx == n_row || off_next == off + deg)); // consecutive CSR rows
       const bool staged = blocked && __all(chain_ok);
+      // regular interior blocks (all 9 neighbours, no constraint anywhere in the stencils): slots and masks are compile-time
+      const bool plain = staged && __all(!writes || (mask == 0x1ffu && fP == 0u && fN == 0u));
       const int rel = (int)(off - off_first); // position of this node's row in the block row, in entries
       const long long row_len = __shfl(off + deg, cy * B2 + n_row) - off_first; // entries of the block row
       const bool row_live = cy >= 1 && (cv.o0[1] + tiy * O2 + cy - 1) <= cv.o1[1];
       // stores `len` staged doubles of every live block row to dst + scale * off_first
       auto flush = [&](double *dst, int scale, int base) __attribute__((always_inline)) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll 1
         for (int r = 0; r < O2; ++r)
           {
@@ -663,7 +678,7 @@ namespace pfm
             for (int k = lane; k < len; k += 64)
               dst[scale * o_f + k] = s_rows[r][base + k];
           }
-        __syncthreads();
+        lds_barrier();
       };
       // what the lane of vertex A's node pulls from this cell: lane - 9, - 8, - 1 for A = 3, 2, 1 (own cell: A = 0)
       auto pull = [&](auto Aa, double x) __attribute__((always_inline)) -> double {
@@ -708,7 +723,29 @@ namespace pfm
           R[0] += pull(IA{}, res_entry(IA{}, integral_constant<int, 0>{}));
           R[1] += pull(IA{}, res_entry(IA{}, integral_constant<int, 1>{}));
         });
-        if (writes)
+        if (plain)
+          {
+            if (writes)
+              {
+                res_pde[(long long)row * 2] = R[0];
+                res_pde[(long long)row * 2 + 1] = R[1];
+                if (write_total)
+                  {
+                    res_tot[(long long)row * 2] = R[0];
+                    res_tot[(long long)row * 2 + 1] = R[1];
+                  }
+                double *dl = &s_rows[cy - 1][4 * rel];
+#pragma unroll
+                for (int o = 0; o < 9; ++o)
+#pragma unroll
+                  for (int c = 0; c < 2; ++c)
+                    {
+                      dl[c * 18 + o * 2] = acc[o][c][0];
+                      dl[c * 18 + o * 2 + 1] = acc[o][c][1];
+                    }
+              }
+          }
+        else if (writes)
           {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -725,8 +762,7 @@ namespace pfm
                 if (!((mask >> o) & 1u))
                   continue;
                 const int sl = slot_of(o);
-                const int q = cart_local_id(cv, i + (o % 3) - 1, j + (o / 3) - 1, 0);
-                const unsigned fQ = v.node_flags[q];
+                const unsigned fQ = (fN >> (3 * o)) & 7u;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                   {
@@ -795,7 +831,25 @@ namespace pfm
           });
           R2 += pull(IA{}, res_entry(IA{}, integral_constant<int, 2>{}));
         });
-        if (writes)
+        if (plain)
+          {
+            if (writes)
+              {
+                const long long di = (long long)v.n_owned * 2 + row;
+                res_pde[di] = R2;
+                if (write_total)
+                  res_tot[di] = R2;
+                double *dl = &s_rows[cy - 1][2 * rel], *dp = &s_rows[cy - 1][2 * 9 * O2 + rel];
+#pragma unroll
+                for (int o = 0; o < 9; ++o)
+                  {
+                    dl[o * 2] = apu[o][0];
+                    dl[o * 2 + 1] = apu[o][1];
+                    dp[o] = app[o];
+                  }
+              }
+          }
+        else if (writes)
           {
             const bool rcon = (fP >> 2) & 1u;
             const long long di = blocked ? (long long)v.n_owned * 2 + row : (long long)row * 3 + 2;
@@ -808,8 +862,7 @@ namespace pfm
                 if (!((mask >> o) & 1u))
                   continue;
                 const int sl = slot_of(o);
-                const int q = cart_local_id(cv, i + (o % 3) - 1, j + (o / 3) - 1, 0);
-                const unsigned fQ = v.node_flags[q];
+                const unsigned fQ = (fN >> (3 * o)) & 7u;
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                   {
@@ -837,7 +890,7 @@ namespace pfm
           }
         if (staged)
           {
-            __syncthreads();
+            lds_barrier();
 #pragma unroll 1
             for (int r = 0; r < O2; ++r)
               {

@@ -347,6 +347,41 @@ def test_cart2d_random_constraints_and_placeholders(blocked, kappa_zero):
     assert all(np.array_equal(a, b) for a, b in zip(v0, v1)) and np.array_equal(r0, r1)
 
 
+def test_cart2d_first_generation_kernel_agrees(tmp_path):
+    """PFM_CART2D_OLD=1 keeps the row-owner kernel of round 2 (thread <-> node, direct quadrature) for A/B runs: both
+    generations against each other on boxes with partial blocks and constraints (round-off apart: the second generation
+    sums moments).  The variant is chosen when the library is first used, hence two processes."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "run2d.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
+        "import test_gpu_cart as T\n"
+        "from gpu_util import make_context\n"
+        "out, rhs = [], []\n"
+        "for blocked in (True, False):\n"
+        "    for n in ((33, 20), (7, 15)):\n"
+        "        c = T.box_case(2, n, -10.0, 10.0, blocked)\n"
+        "        ctx = make_context(c)\n"
+        "        values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)\n"
+        "        out.extend(values)\n"
+        "        rhs.append(res)\n"
+        "np.save(sys.argv[1], np.concatenate(out))\n"
+        "np.save(sys.argv[2], np.concatenate(rhs))\n")
+    val, rhs = {}, {}
+    for tag, env in (("cells", {}), ("rows", {"PFM_CART2D_OLD": "1"})):
+        f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
+        e = {k: v for k, v in os.environ.items() if k != "PFM_CART2D_OLD"}
+        e.update(env)
+        subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
+        val[tag], rhs[tag] = np.load(f), np.load(g)
+    assert val["cells"].shape == val["rows"].shape and not np.array_equal(val["cells"], val["rows"])
+    assert linf_scaled(val["cells"], val["rows"]) < TOL and linf_scaled(rhs["cells"], rhs["rows"]) < TOL
+
+
 def test_cart2d_split_runs_stay_on_the_general_family():
     """decompose_stress_matrix > 0 and timestep_number > 0 on a 2-D lattice: correct through the general family."""
     c = box_case(2, (9, 8), 0.0, 1.0, False)
