@@ -403,16 +403,19 @@ namespace pfm
               }
           }
       };
-      double lo[NF], up[NF], carry[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+      // Accumulators in the moment basis of the bilinear test functions (see k_cart_residual3): index 0 stands for
+      // phi_0 + phi_1 = 1 (gradient 0), index 1 for phi_1; M[x][y][component].  The part of y-vertex 1 is carried to the
+      // next cell row, where it is the part of y-vertex 0.
+      double lo[NF], up[NF], M[2][2][3];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        M[a & 1][a >> 1][0] = M[a & 1][a >> 1][1] = M[a & 1][a >> 1][2] = 0.0;
+      const double c_g = 1.0 - S.kappa, c_pd = S.aB1 * S.p, c_r2 = -2.0 * S.aB1 * S.p, c_r3 = S.Gc / S.eps, c_ge = S.Gc * S.eps;
       load_row(jA - 1, lo);
 #pragma unroll 1
       for (int cj = jA - 1; cj < jB; ++cj)
         {
           load_row(cj + 1, up);
-          double R[2][2][3]; // [ax][ay][component]
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-            R[a & 1][a >> 1][0] = R[a & 1][a >> 1][1] = R[a & 1][a >> 1][2] = 0.0;
           // right-hand vertices: the nodes of lane + 1
           double lo1[NF], up1[NF];
 #pragma unroll
@@ -429,105 +432,131 @@ namespace pfm
                   lam = cv.cell_lam[i + (long long)(cv.NX - 1) * cj];
                   mu = cv.cell_mu[i + (long long)(cv.NX - 1) * cj];
                 }
-              double Dy[3][2], dDy[3]; // d/dy at x-vertex 0/1 (constant along y) and its x-difference
+              double Dy0[3], dDy[3]; // d/dy at x-vertex 0 (constant along y) and its x-difference
 #pragma unroll
               for (int f = 0; f < 3; ++f)
                 {
-                  Dy[f][0] = (up[f] - lo[f]) * ihy;
-                  Dy[f][1] = (up1[f] - lo1[f]) * ihy;
-                  dDy[f] = Dy[f][1] - Dy[f][0];
+                  Dy0[f] = (up[f] - lo[f]) * ihy;
+                  dDy[f] = (up1[f] - lo1[f]) * ihy - Dy0[f];
                 }
               const double mu2 = 2 * mu;
 #pragma unroll 1
               for (int qy = 0; qy < 3; ++qy)
                 {
-                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy];
+                  const double eta = c_t1.n[1][qy];
                   const double wy = vol * c_t1.w[qy];
                   double L0[NF], dL[NF];
 #pragma unroll
                   for (int f = 0; f < NF; ++f)
                     {
-                      L0[f] = ny0 * lo[f] + ny1 * up[f];
-                      dL[f] = (ny0 * lo1[f] + ny1 * up1[f]) - L0[f];
+                      L0[f] = fma(eta, up[f] - lo[f], lo[f]);
+                      dL[f] = fma(eta, up1[f] - lo1[f], lo1[f]) - L0[f];
                     }
                   const double Dx0 = dL[0] * ihx, Dx1 = dL[1] * ihx, Dxp = dL[2] * ihx;
-                  double X0[3] = {0.0, 0.0, 0.0}, X1[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, XS[2] = {0.0, 0.0};
-#pragma unroll
-                  for (int qx = 0; qx < 3; ++qx)
-                    {
-                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
-                      const double JxW = wy * c_t1.w[qx];
-                      const double g00 = Dx0, g10 = Dx1;
-                      const double g01 = fma(nx1, dDy[0], Dy[0][0]), g11 = fma(nx1, dDy[1], Dy[1][0]);
-                      const double gp0 = Dxp, gp1 = fma(nx1, dDy[2], Dy[2][0]);
-                      double pf = fma(nx1, dL[2], L0[2]);
-                      double pfo = fma(nx1, dL[3], L0[3]); // LIN: the combined field
-                      double pen = 0.0, pfx;
-                      if constexpr (LIN)
-                        {
+                  // x-sums of the fluxes against 1 (s) and phi_1 (1); the x-gradient factor needs the plain sum only
+                  double A0[3], Bs[3], B1[3], rs, r1;
+                  auto xq = [&](const int qx, auto first) __attribute__((always_inline)) {
+                    const double xi = c_t1.n[1][qx], wq = c_t1.w[qx], wx = c_t1.wn1[qx];
+                    const double g00 = Dx0, g10 = Dx1;
+                    const double g01 = fma(xi, dDy[0], Dy0[0]), g11 = fma(xi, dDy[1], Dy0[1]);
+                    const double gp0 = Dxp, gp1 = fma(xi, dDy[2], Dy0[2]);
+                    double pf = fma(xi, dL[2], L0[2]);
+                    double pfo = fma(xi, dL[3], L0[3]); // LIN: the combined field
+                    double pen = 0.0, pfx;
+                    if constexpr (LIN)
+                      {
+                        pfx = pfo;
+                        if (!S.use_old)
+                          pfx = fmin(fmax(pfx, 0.0), 1.0);
+                      }
+                    else
+                      {
+                        double pfoo = fma(xi, dL[NF - 1], L0[NF - 1]);
+                        if (S.monolithic)
+                          {
+                            pf = fmax(0.0, pf);
+                            pfo = fmax(0.0, pfo);
+                            pfoo = fmax(0.0, pfoo);
+                          }
+                        pen = fmax(0.0, pf - pfo);
+                        pfx = pfoo + S.tfac * (pfo - pfoo);
+                        if (pfx <= 0.0)
+                          pfx = 0.0;
+                        if (pfx >= 1.0)
+                          pfx = 1.0;
+                        if (S.use_old)
                           pfx = pfo;
-                          if (!S.use_old)
-                            pfx = fmin(fmax(pfx, 0.0), 1.0);
+                      }
+                    const double pf2 = pfx * pfx;
+                    const double g = fma(c_g, pf2, S.kappa);
+                    const double t01 = g01 + g10, trE = g00 + g11;
+                    const double lt = lam * trE;
+                    const double s00 = fma(mu2, g00, lt), s11 = fma(mu2, g11, lt), s01 = mu * t01;
+                    const double spE = fma(s00, g00, fma(s11, g11, s01 * t01));
+                    const double pd = c_pd * pf2;
+                    const double z00 = fma(g, s00, -pd), z11 = fma(g, s11, -pd), z01 = g * s01;
+                    double rq = fma(pf, fma(c_r2, trE, fma(c_g, spE, c_r3)), -c_r3);
+                    if constexpr (!LIN)
+                      rq = fma(S.gamma_fac, pen, rq);
+                    const double F[3][2] = {{z00, z01}, {z01, z11}, {c_ge * gp0, c_ge * gp1}};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                      if constexpr (decltype(first)::value)
+                        {
+                          A0[c] = wq * F[c][0];
+                          Bs[c] = wq * F[c][1];
+                          B1[c] = wx * F[c][1];
                         }
                       else
                         {
-                          double pfoo = fma(nx1, dL[NF - 1], L0[NF - 1]);
-                          if (S.monolithic)
-                            {
-                              pf = fmax(0.0, pf);
-                              pfo = fmax(0.0, pfo);
-                              pfoo = fmax(0.0, pfoo);
-                            }
-                          pen = fmax(0.0, pf - pfo);
-                          pfx = pfoo + S.tfac * (pfo - pfoo);
-                          if (pfx <= 0.0)
-                            pfx = 0.0;
-                          if (pfx >= 1.0)
-                            pfx = 1.0;
-                          if (S.use_old)
-                            pfx = pfo;
+                          A0[c] = fma(wq, F[c][0], A0[c]);
+                          Bs[c] = fma(wq, F[c][1], Bs[c]);
+                          B1[c] = fma(wx, F[c][1], B1[c]);
                         }
-                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-                      const double t01 = g01 + g10, trE = g00 + g11;
-                      const double lt = lam * trE;
-                      const double s00 = fma(mu2, g00, lt), s11 = fma(mu2, g11, lt), s01 = mu * t01;
-                      const double spE = fma(s00, g00, s11 * g11) + s01 * t01;
-                      const double gJ = g * JxW, pd = S.aB1 * S.p * pfx * pfx * JxW;
-                      const double z00 = gJ * s00 - pd, z11 = gJ * s11 - pd, z01 = gJ * s01;
-                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
-                                         2.0 * S.aB1 * S.p * pf * trE) *
-                                        JxW;
-                      const double ge = S.Gc * S.eps * JxW;
-                      const double F[3][2] = {{z00, z01}, {z01, z11}, {ge * gp0, ge * gp1}};
-#pragma unroll
-                      for (int c = 0; c < 3; ++c)
-                        {
-                          X0[c] += F[c][0];
-                          X1[c][0] += F[c][1] * nx0;
-                          X1[c][1] += F[c][1] * nx1;
-                        }
-                      XS[0] += rq * nx0;
-                      XS[1] += rq * nx1;
-                    }
+                    if constexpr (decltype(first)::value)
+                      {
+                        rs = wq * rq;
+                        r1 = wx * rq;
+                      }
+                    else
+                      {
+                        rs = fma(wq, rq, rs);
+                        r1 = fma(wx, rq, r1);
+                      }
+                  };
+                  xq(0, std::true_type{});
+                  xq(1, std::false_type{});
+                  xq(2, std::false_type{});
+                  // y factors: M[i][j] += P Y_j + B dY_j with (Y, dY) = (1, 0) | (eta, 1/h_y)
+                  const double kx = ihx * wy, ky = ihy * wy;
 #pragma unroll
                   for (int c = 0; c < 3; ++c)
-#pragma unroll
-                    for (int ax = 0; ax < 2; ++ax)
-                      {
-                        double tA = (ax ? ihx : -ihx) * X0[c];
-                        if (c == 2)
-                          tA += XS[ax];
-                        const double tB = ihy * X1[c][ax];
-                        R[ax][0][c] -= ny0 * tA - tB;
-                        R[ax][1][c] -= ny1 * tA + tB;
-                      }
+                    {
+                      double P = kx * A0[c];
+                      if (c == 2)
+                        P = fma(wy, r1, P);
+                      M[1][0][c] += P;
+                      M[1][1][c] = fma(eta, P, fma(ky, B1[c], M[1][1][c]));
+                      if (c == 2)
+                        {
+                          const double Ps = wy * rs;
+                          M[0][0][c] += Ps;
+                          M[0][1][c] = fma(eta, Ps, fma(ky, Bs[c], M[0][1][c]));
+                        }
+                      else
+                        M[0][1][c] = fma(ky, Bs[c], M[0][1][c]);
+                    }
                 }
             }
-          // node row cj: own a_x = 0 parts + the a_x = 1 parts of the cell column on the left (lane - 1)
+          // node row cj: the y-vertex-0 parts; own a_x = 0 part + the a_x = 1 part of the cell column on the left (lane - 1)
           double tot[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            tot[c] = (R[0][0][c] + carry[0][c]) + __shfl_up(R[1][0][c] + carry[1][c], 1);
+            {
+              const double l1 = M[1][0][c] - M[1][1][c];           // x-vertex 1
+              const double l0 = (M[0][0][c] - M[0][1][c]) - l1;    // x-vertex 0
+              tot[c] = -(l0 + __shfl_up(l1, 1));
+            }
           if (cj >= jA && owner)
             {
               const int row = cart_local_id3(cv, i, cj, 0);
@@ -542,11 +571,13 @@ namespace pfm
                     res_tot[di] = (con && S.total_via_update) ? 0.0 : tot[c];
                 }
             }
+          // the y-vertex-1 part becomes the y-vertex-0 part of the next cell row (y index 0 = lower + upper)
 #pragma unroll
           for (int c = 0; c < 3; ++c)
             {
-              carry[0][c] = R[0][1][c];
-              carry[1][c] = R[1][1][c];
+              M[0][0][c] = M[0][1][c];
+              M[1][0][c] = M[1][1][c];
+              M[0][1][c] = M[1][1][c] = 0.0;
             }
 #pragma unroll
           for (int f = 0; f < NF; ++f)
