@@ -399,7 +399,7 @@ def main():
     dim = args.dim
     n = args.n or (216 if dim == 3 else 1000)
     ncell = (n,) * dim
-    p = P.factor_ranks(world, dim)
+    p = P.bench_grid(world, dim, n)
     t0 = time.perf_counter()
     lp = P.build_local_problem(dim, ncell, p, rank)
     h = (20.0 / n) * np.sqrt(dim)

@@ -21,6 +21,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import math
+
 import numpy as np
 
 from .mesh import Mesh
@@ -39,6 +41,24 @@ def factor_ranks(world: int, dim: int) -> Tuple[int, ...]:
         w //= f
         d += 1
     return tuple(p)
+
+
+def bench_grid(world: int, dim: int, n: int) -> Tuple[int, ...]:
+    """Process grid of the strong-scaling bench.  3-D boxes are cut into z-slabs while a slab keeps >= 16 node planes: the
+    row-owner kernels tile (x, y) and march / iterate over z, so a slab keeps the tile efficiency of the whole box (217
+    nodes = 31 tiles of 7 exactly) and has two peers instead of seven.  Measured on one MI355X, time of one rank's share
+    of 216^3 (tools/bench_extra.py rank --grid): 2 ranks 7.38 (1x1x2) against 7.70 ms (2x1x1), 4 ranks 3.89 (1x1x4) against
+    4.12 ms (2x2x1), 8 ranks 2.15 (1x1x8) = 2.16 ms (2x2x2).  PFM_BENCH_GRID=a,b,c overrides."""
+    import os
+
+    g = os.environ.get("PFM_BENCH_GRID")
+    if g:
+        p = tuple(int(x) for x in g.split(","))
+        assert len(p) == dim and int(math.prod(p)) == world, f"PFM_BENCH_GRID={g} is not a {dim}-D grid of {world} ranks"
+        return p
+    if dim == 3 and world > 1 and (n + 1) // world >= 16:
+        return (1, 1, world)
+    return factor_ranks(world, dim)
 
 
 def _split(n: int, p: int, i: int) -> Tuple[int, int]:

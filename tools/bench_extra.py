@@ -296,7 +296,8 @@ def rank_share(args):
     from cracks_amd.assembler import Assembler
 
     n, world = args.n, args.world
-    p = P.factor_ranks(world, 3)
+    p = tuple(int(x) for x in args.grid.split(",")) if args.grid else P.factor_ranks(world, 3)
+    assert int(np.prod(p)) == world
     rows = []
     for rank in ([0, world - 1] if world > 1 else [0]):
         lp = P.build_local_problem(3, (n,) * 3, p, rank)
@@ -383,6 +384,7 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=None)
     ap.add_argument("--dist", action="store_true", help="config5: one process per GPU under torch.distributed.run")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--grid", default=None, help="rank: process grid instead of the near-cubic one, e.g. 1,1,8")
     a = ap.parse_args()
     if a.what == "config5" and (a.dist or int(os.environ.get("WORLD_SIZE", "1")) > 1):
         config5_dist(a)
