@@ -296,7 +296,7 @@ def rank_share(args):
     from cracks_amd.assembler import Assembler
 
     n, world = args.n, args.world
-    p = tuple(int(x) for x in args.grid.split(",")) if args.grid else P.factor_ranks(world, 3)
+    p = tuple(int(x) for x in args.grid.split(",")) if args.grid else P.bench_grid(world, 3, n)
     assert int(np.prod(p)) == world
     rows = []
     for rank in ([0, world - 1] if world > 1 else [0]):
