@@ -938,7 +938,7 @@ namespace pfm
   } // namespace
 
   int launch_cart_matrix(const DevView &v, const CartView &cv, const pfm_params &p, double *const *d_values,
-                         hipStream_t s, void *d_scal, double *res_pde, int phase);
+                         hipStream_t s, void *d_scal, double *res_pde, int phase, hipStream_t s_phi);
 
   int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu)
   {
@@ -961,6 +961,18 @@ namespace pfm
       if (((double)tiles * ((planes + zc - 1) / zc) / slots + 0.5) * (zc + 1) <= 1.01 * tmin)
         best = zc;
     return best;
+  }
+
+  // the conditions of `rows_residual` in launch_assemble_cart + what the pair needs: the default (u,u) kernel
+  bool cart_jacobian_pair(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, int phase)
+  {
+    if (v.dim != 3 || residual_only || phase != 0 || cv.cell_lam)
+      return false;
+    if ((p.decompose_stress_matrix > 0 && p.timestep_number > 0) || getenv("PFM_RES_KERNEL") || getenv("PFM_UU4") || getenv("PFM_UU5") ||
+        getenv("PFM_UU_CLK") || getenv("PFM_PHI_CLK"))
+      return false;
+    const Scal S = make_scal(p, cv, v.dim);
+    return !S.monolithic && S.gamma_fac == 0.0 && S.kappa < 0.5;
   }
 
   // phase: 0 = the whole assembly; 1 / 2 = the two halves of pfm_assemble_overlapped: 1 launches what reads no ghost
@@ -991,8 +1003,8 @@ namespace pfm
     static const bool res_kernel_forced = getenv("PFM_RES_KERNEL") != nullptr;
     const bool rows_residual = v.dim == 3 && !residual_only && !S.monolithic && S.gamma_fac == 0.0 && S.kappa < 0.5 && !res_kernel_forced &&
                                !cv.cell_lam; // (the heterogeneous (u,u) variant has no registers left for it)
-    if (rows_residual)
-      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, res_pde, phase);
+    if (rows_residual) // s_residual != s_jac: the caller forked it off for the phase-field kernel (cart_jacobian_pair)
+      return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, res_pde, phase, (phase == 0 && cv.patch_count) ? s : s_jac);
     const int bs = 256;
     const long long OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = v.dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
     const long long n_waves = OWY * OWZ * ((OWX + 62) / 63);
@@ -1035,7 +1047,7 @@ namespace pfm
     // the residual kernel was the first of the sequence (and the one split into interior / boundary tiles): the Jacobian
     // kernels follow it completely, in the second phase of an overlapped assembly
     if (!residual_only && phase != 1)
-      return launch_cart_matrix(v, cv_in, p, d_values, s_jac, d_scal, nullptr, 0);
+      return launch_cart_matrix(v, cv_in, p, d_values, s_jac, d_scal, nullptr, 0, s_jac);
     return PFM_OK;
   }
 } // namespace pfm

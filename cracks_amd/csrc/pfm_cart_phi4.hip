@@ -954,7 +954,20 @@ namespace pfm
                         sself = cv.row_perm[off + sself];
                       for (int c = 0; c < 3; ++c)
                         if ((row_flag >> c) & 1u)
-                          vals_uu[(long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c] += patch;
+                          {
+                            const long long at = (long long)NCOL * NCOL * off + (long long)c * NCOL * deg + sself * NCOL + c;
+                            if (cv.patch_count) // the (u,u) kernel may still be writing: deferred (launch_cart_apply_patches)
+                              {
+                                const int e = atomicAdd(cv.patch_count, 1);
+                                if (e < cv.patch_cap)
+                                  {
+                                    cv.patch_idx[e] = at;
+                                    cv.patch_val[e] = patch;
+                                  }
+                              }
+                            else
+                              vals_uu[at] += patch;
+                          }
                     }
                 }
             }
@@ -1049,8 +1062,10 @@ namespace pfm
 
   // Jacobian of a cartesian box: (u,u) rows first, k_cart_phi4 patches constrained (u,u) diagonals afterwards
   // (same stream) and clears the structurally zero (u,phi) block (cracks.cc:2333-2337) along with its (phi,u) stores
+  // s_phi != s: the two kernels next to each other (the caller has forked s_phi off s and joins them; CartView::patch_*
+  // must be set: the phase-field kernel defers its (u,u) patches)
   int launch_cart_matrix(const DevView &v, const CartView &cv_in, const pfm_params &p, double *const *d_values, hipStream_t s,
-                         void *d_scal, double *res_pde, int phase)
+                         void *d_scal, double *res_pde, int phase, hipStream_t s_phi)
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
@@ -1073,11 +1088,34 @@ namespace pfm
     else
       {
         cv.tile_sel = cut ? phase : 0;
-        rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde);
+        // next to the phase-field kernel: the same LDS allocation as that kernel (64 granules of 1280 B; 79,472 B are 63), so
+        // that a slot freed by either kernel takes a workgroup of either
+        rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde, s_phi != s ? 2048 : 0);
         cv.tile_sel = 0;
       }
     if (rc || phase == 1)
       return rc;
-    return launch_cart_phi4(v, cv, p, d_values, s, d_scal, res_pde);
+    if (s_phi != s && !cv.patch_count)
+      return PFM_ERR_BAD_ARG; // concurrent kernels need the deferred patch list
+    return launch_cart_phi4(v, cv, p, d_values, s_phi, d_scal, res_pde);
+  }
+
+  namespace
+  {
+    __global__ void k_cart_apply_patches(double *__restrict__ vals_uu, const long long *__restrict__ idx, const double *__restrict__ val,
+                                         const int *__restrict__ count, int cap)
+    {
+      const int n = min(*count, cap); // (the list holds one entry per flagged displacement dof at most: cap is never exceeded)
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        vals_uu[idx[i]] += val[i]; // one entry per matrix value at most: no two threads share an address
+    }
+  } // namespace
+
+  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s)
+  {
+    if (!cv.patch_count)
+      return PFM_OK;
+    hipLaunchKernelGGL(k_cart_apply_patches, dim3(64), dim3(256), 0, s, vals_uu, cv.patch_idx, cv.patch_val, cv.patch_count, cv.patch_cap);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
 } // namespace pfm

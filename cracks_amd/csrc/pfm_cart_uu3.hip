@@ -745,7 +745,7 @@ namespace pfm
   } // namespace
 
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal, double *res_pde)
+                      const void *d_scal, double *res_pde, int lds_pad /* bytes of unused dynamic LDS: launch_cart_matrix */)
   {
     int rc = ensure_g1();
     if (rc)
@@ -761,7 +761,7 @@ namespace pfm
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
     static const int prio = getenv("PFM_UU_PRIO") ? atoi(getenv("PFM_UU_PRIO")) : 0; // bit 0: halo loads, 1: w*g, 2: copy-out
-#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, 0, s, v, cv, S, vals_uu, nullptr, res_pde, prio)
+#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, lds_pad, s, v, cv, S, vals_uu, nullptr, res_pde, prio)
     if (getenv("PFM_UU_CLK") && !il && !het && !res) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;

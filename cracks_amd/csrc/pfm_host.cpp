@@ -983,7 +983,8 @@ extern "C"
           (void)hipFree(p.d_recv);
       }
     for (void *q : {(void *)c->d_send_all, (void *)c->d_recv_all, (void *)c->d_send_ptr, (void *)c->d_recv_ptr,
-                    (void *)c->d_halo_send, (void *)c->d_halo_recv})
+                    (void *)c->d_halo_send, (void *)c->d_halo_recv, (void *)c->cv.patch_idx, (void *)c->cv.patch_val,
+                    (void *)c->cv.patch_count})
       if (q)
         (void)hipFree(q);
     if (c->side_stream)
@@ -1042,6 +1043,18 @@ extern "C"
     (void)hipSetDevice(c->device);
     hipError_t e = hipMemcpyAsync(const_cast<uint8_t *>(c->v.node_flags), node_flags,
                                   (size_t)c->v.n_nodes, hipMemcpyHostToDevice, c->stream);
+    // capacity of the deferred patch list of the cartesian 3-D Jacobian (counted while the copy is in flight)
+    if (c->cart_ok && c->v.dim == 3)
+      {
+        std::atomic<int64_t> nf{0};
+        parallel_for(c->v.n_owned, [&](int64_t nb, int64_t ne) {
+          int64_t k = 0;
+          for (int64_t n = nb; n < ne; ++n)
+            k += __builtin_popcount(node_flags[n] & 7u);
+          nf += k;
+        });
+        c->n_flag_u = nf;
+      }
     if (e == hipSuccess)
       e = hipStreamSynchronize(c->stream); // node_flags is a borrowed host buffer
     return e == hipSuccess ? PFM_OK : hipfail(c, e, "set_constraints copy");
@@ -1681,7 +1694,33 @@ extern "C"
     // Optional (PFM_SIDE_STREAM=1): residual kernel on a side stream next to the Jacobian kernels.  Measured on MI355X at 216^3: no gain (21.4 vs 21.1 ms per assembly),
     // the kernels do not share CUs usefully; off by default.
     hipStream_t s_res = c->stream;
-    const bool fork = cart && !residual_only && phase == 0 && getenv("PFM_SIDE_STREAM");
+    // The two Jacobian kernels of a 3-D box next to each other (default): with equal LDS allocations (64 granules of 1280 B
+    // each) any freed slot of a CU takes a workgroup of either kernel, the (u,u) and the phase-field workgroups mix and
+    // fill each other's stalls: 14.07 -> 13.75 ms per assembly at 216^3 (PFM_JAC_SEQUENTIAL=1: one after the other).
+    static const bool jac_sequential = getenv("PFM_JAC_SEQUENTIAL") != nullptr;
+    const bool pair = cart && !jac_sequential && cart_jacobian_pair(c->v, c->cv, c->prm, residual_only, phase);
+    if (pair)
+      {
+        // deferred placeholder patches: one entry per flagged displacement dof at most
+        if (c->cv.patch_cap < c->n_flag_u || !c->cv.patch_count)
+          {
+            for (void *q : {(void *)c->cv.patch_idx, (void *)c->cv.patch_val, (void *)c->cv.patch_count})
+              if (q)
+                (void)hipFree(q);
+            c->device_bytes -= (int64_t)c->cv.patch_cap * 16 + (c->cv.patch_count ? 4 : 0);
+            c->cv.patch_idx = nullptr, c->cv.patch_val = nullptr, c->cv.patch_count = nullptr;
+            const size_t cap = (size_t)std::max<int64_t>(c->n_flag_u, 1);
+            if (hipMalloc((void **)&c->cv.patch_idx, cap * sizeof(long long)) != hipSuccess ||
+                hipMalloc((void **)&c->cv.patch_val, cap * sizeof(double)) != hipSuccess ||
+                hipMalloc((void **)&c->cv.patch_count, sizeof(int)) != hipSuccess)
+              return fail(c, PFM_ERR_NOMEM, "patch list");
+            c->cv.patch_cap = (int)std::min<size_t>(cap, 0x7fffffff);
+            c->device_bytes += (int64_t)c->cv.patch_cap * 16 + 4;
+          }
+        if (hipMemsetAsync(c->cv.patch_count, 0, sizeof(int), c->stream) != hipSuccess)
+          return fail(c, PFM_ERR_HIP, "patch list reset");
+      }
+    const bool fork = cart && !residual_only && phase == 0 && (pair || getenv("PFM_SIDE_STREAM"));
     if (fork)
       {
         if (!c->side_stream)
@@ -1728,7 +1767,10 @@ extern "C"
           return fail(c, rcs, "scalar tables");
         c->scal_dirty = false;
       }
-    int rc = cart ? launch_assemble_cart(c->v, c->cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, s_res, c->d_scal, phase)
+    pfm::CartView cv_launch = c->cv;
+    if (!pair)
+      cv_launch.patch_idx = nullptr, cv_launch.patch_val = nullptr, cv_launch.patch_count = nullptr, cv_launch.patch_cap = 0;
+    int rc = cart ? launch_assemble_cart(c->v, cv_launch, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, pair || fork ? s_res : c->stream, c->d_scal, phase)
                   : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr);
     if (fork)
       {
@@ -1738,6 +1780,8 @@ extern "C"
         if (e != hipSuccess)
           return hipfail(c, e, "join");
       }
+    if (pair && rc == PFM_OK)
+      rc = launch_cart_apply_patches(c->cv, d_values[0], c->stream);
     if (phase == 1)
       return rc ? fail(c, rc, "assemble launch failed (interior tiles)") : PFM_OK;
     if (rc == PFM_OK && overlay_uu && c->scal_dirty)

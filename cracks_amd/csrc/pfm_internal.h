@@ -55,6 +55,14 @@ namespace pfm
     // an early-exit launch over the full grid costs ~3 ns per skipped workgroup, 0.4 ms at 1.5e5 tiles)
     const int32_t *bnd_uu3, *bnd_res3; // tile indices of k_cart_uu3 / k_cart_residual3 (the latter for its z-chunk length)
     int n_bnd_uu3, n_bnd_res3, zc_res3;
+    // Deferred (u,u) placeholder patches of k_cart_phi4 (constrained displacement rows whose element diagonal vanished in
+    // some cell, deal.II's mean-|diagonal| rule): when the two Jacobian kernels run next to each other the phase-field kernel
+    // must not add to values the (u,u) kernel may still be writing -- it appends (index, value) here and
+    // launch_cart_apply_patches adds them after the join.  nullptr: patched in place (the kernels run one after the other).
+    long long *patch_idx;
+    double *patch_val;
+    int *patch_count;
+    int patch_cap;
     int tile_sel;                     // 0: every tile; 1: only tiles that read no ghost node ("interior"); 2: only the
                                       // others -- the two launches of pfm_assemble_overlapped, between which the ghost
                                       // import lands (cracks.cc:2147-2154 next to the cell loop instead of in front of it)
@@ -110,6 +118,10 @@ namespace pfm
   int launch_assemble_cart(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only,
                            double *const *d_values, double *d_res_pde, double *d_res_tot, hipStream_t s,
                            hipStream_t s_residual, void *d_scal, int phase = 0);
+  // true: this assembly is the pair k_cart_uu3<RES> + k_cart_phi4<RES> and may run them on two streams (s, s_residual of
+  // launch_assemble_cart) -- the caller forks / joins and applies the deferred patches (CartView::patch_*)
+  bool cart_jacobian_pair(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, int phase);
+  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s);
   bool cart_matrix_supported(int dim);
   // 2-D boxes: row-owner Jacobian + residual of runs WITHOUT the stress split (pfm_cart2d.hip; PFM_ERR_UNSUPPORTED otherwise)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
@@ -131,7 +143,7 @@ namespace pfm
                        const void *d_scal, double *res_pde);
   // res_pde != nullptr: the kernel also writes the displacement rows of the residual (from its matrix rows, see the kernel)
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal, double *res_pde);
+                      const void *d_scal, double *res_pde, int lds_pad = 0);
   // z-marching variant of launch_cart_uu3 (pfm_cart_uu4.hip): bitwise identical results, measured equal in time;
   // selected by PFM_UU4=1 (A/B runs, tests/test_gpu_cart.py runs both)
   int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
@@ -199,6 +211,7 @@ struct pfm_ctx
   double *d_halo_send = nullptr, *d_halo_recv = nullptr; // message buffers of pfm_halo_exchange
   int64_t halo_buf_bytes = 0;                            // their share of device_bytes
   void *d_scal = nullptr; // per-launch scalar tables of the cartesian kernels (PFM_SCAL_BYTES)
+  int64_t n_flag_u = 0;   // displacement dofs with a constraint flag (capacity of the deferred patch list, CartView::patch_*)
   uint8_t *d_row_perm = nullptr; // CartView::row_perm storage (in allocs)
   bool overlap_lists_ready = false; // CartView::bnd_uu3 / bnd_res3 built
   pfm::LatticeHost lat;          // host lattice tables (cartesian path only)

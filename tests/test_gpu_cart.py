@@ -290,15 +290,19 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
     # default: k_cart_uu3 / k_cart_phi4 also write the residual (from their matrix rows); PFM_RES_KERNEL=1: the quadrature
     # residual kernel; PFM_UU4=1 (+ PFM_RES_KERNEL=1, the z-marching kernel has no residual variant): k_cart_uu4
     val, rhs = {}, {}
-    for tag, env in (("rows", {}), ("uu3", {"PFM_RES_KERNEL": "1"}), ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"}),
-                     ("uu5", {"PFM_UU5": "1", "PFM_RES_KERNEL": "1"}), ("uu5rows", {"PFM_UU5": "1"})):
+    for tag, env in (("rows", {}), ("rows_seq", {"PFM_JAC_SEQUENTIAL": "1"}), ("uu3", {"PFM_RES_KERNEL": "1"}),
+                     ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"}), ("uu5", {"PFM_UU5": "1", "PFM_RES_KERNEL": "1"}),
+                     ("uu5rows", {"PFM_UU5": "1"})):
         f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
-        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_UU5", "PFM_RES_KERNEL")}
+        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_UU5", "PFM_RES_KERNEL", "PFM_JAC_SEQUENTIAL")}
         e.update(env)
         subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
         val[tag], rhs[tag] = np.load(f), np.load(g)
     assert val["uu3"].shape == val["uu4"].shape == val["rows"].shape
     assert np.array_equal(val["uu3"], val["uu4"]) and np.array_equal(rhs["uu3"], rhs["uu4"])
+    # default: the (u,u) and the phase-field kernel next to each other on two streams (deferred placeholder patches);
+    # PFM_JAC_SEQUENTIAL=1: one after the other -- the same kernels, the same bits
+    assert np.array_equal(val["rows"], val["rows_seq"]) and np.array_equal(rhs["rows"], rhs["rows_seq"])
     # the residual variant of the (u,u) kernel writes the same matrix bits; its residual equals the quadrature one to round-off
     assert np.array_equal(val["rows"], val["uu3"])
     assert rhs["rows"].shape == rhs["uu3"].shape and linf_scaled(rhs["rows"], rhs["uu3"]) < TOL
