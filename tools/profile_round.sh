@@ -90,6 +90,11 @@ for k, d in res.items():
         print(k, {a: "%.3e" % b for a, b in d.items()})
 PY
 rm -rf $O/stats $O/stats_res $O/pmc_sq $O/pmc_lds $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE
+# the headline line once more, now that the counter summaries of THESE kernel sources exist (bench.py quotes the newest
+# profiles/r*/ summary whose source hash matches; the first run above could only see the previous ones)
+mkdir -p $R/profiles/$tag
+cp $O/hbm_traffic_3d_216.json $O/instruction_mix_*.json $R/profiles/$tag/
+cd $R && python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err; cd /tmp
 grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
 python -c "
 import json
