@@ -968,8 +968,8 @@ namespace pfm
   {
     if (v.dim != 3 || residual_only || phase != 0 || cv.cell_lam)
       return false;
-    if ((p.decompose_stress_matrix > 0 && p.timestep_number > 0) || getenv("PFM_RES_KERNEL") || getenv("PFM_UU4") || getenv("PFM_UU5") ||
-        getenv("PFM_UU_CLK") || getenv("PFM_PHI_CLK"))
+    static const bool other_mode = getenv("PFM_RES_KERNEL") || getenv("PFM_UU4") || getenv("PFM_UU5") || getenv("PFM_UU_CLK") || getenv("PFM_PHI_CLK");
+    if ((p.decompose_stress_matrix > 0 && p.timestep_number > 0) || other_mode)
       return false;
     const Scal S = make_scal(p, cv, v.dim);
     return !S.monolithic && S.gamma_fac == 0.0 && S.kappa < 0.5;

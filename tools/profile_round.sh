@@ -2,8 +2,8 @@
 # usage: tools/profile_round.sh <tag>      (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r02')
 # One pass over everything the round's DESIGN/VERDICT numbers come from; results under gpurun_out/<tag>/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=${1:-rXX}
-O=$R/gpurun_out/$tag
+TAG=${1:-rXX}
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 HASH=$(python -c "import bench; print(bench.kernel_source_hash())")
@@ -92,8 +92,8 @@ PY
 rm -rf $O/stats $O/stats_res $O/pmc_sq $O/pmc_lds $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE
 # the headline line once more, now that the counter summaries of THESE kernel sources exist (bench.py quotes the newest
 # profiles/r*/ summary whose source hash matches; the first run above could only see the previous ones)
-mkdir -p $R/profiles/$tag
-cp $O/hbm_traffic_3d_216.json $O/instruction_mix_*.json $R/profiles/$tag/
+mkdir -p $R/profiles/$TAG
+cp $O/hbm_traffic_3d_216.json $O/instruction_mix_*.json $R/profiles/$TAG/
 cd $R && python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err; cd /tmp
 grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
 python -c "
