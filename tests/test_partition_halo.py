@@ -110,6 +110,26 @@ def _owned_rows_match(lp, g, f, prm, dirichlet):
     assert G[gdof[own]].nnz == Gsub.nnz  # no column of an owned row outside the local node set
 
 
+
+def test_bench_grid_cuts_3d_boxes_into_z_slabs(monkeypatch):
+    """bench.py's process grid: 1 x 1 x N while a slab keeps >= 16 node planes (the row-owner kernels tile (x, y)), the
+    near-cubic grid otherwise and in 2-D; PFM_BENCH_GRID overrides.  Every grid partitions the box completely."""
+    monkeypatch.delenv("PFM_BENCH_GRID", raising=False)
+    assert P.bench_grid(8, 3, 216) == (1, 1, 8) and P.bench_grid(2, 3, 216) == (1, 1, 2) and P.bench_grid(1, 3, 216) == (1, 1, 1)
+    assert P.bench_grid(8, 3, 100) == P.factor_ranks(8, 3) == (2, 2, 2)  # 12 planes per slab: too thin
+    assert P.bench_grid(4, 2, 1000) == P.factor_ranks(4, 2)
+    monkeypatch.setenv("PFM_BENCH_GRID", "2,1,4")
+    assert P.bench_grid(8, 3, 216) == (2, 1, 4)
+    monkeypatch.delenv("PFM_BENCH_GRID")
+    n, world = 9, 4
+    grid = (1, 1, 4)
+    owned = 0
+    for rank in range(world):
+        lp = P.build_local_problem(3, (n,) * 3, grid, rank)
+        owned += lp.n_owned
+        assert len(lp.peers) <= 2
+    assert owned == (n + 1) ** 3
+
 @pytest.mark.parametrize("kind,world", [("slit2d", 2), ("slit2d", 3), ("slit2d", 4), ("box3d", 2), ("box3d", 3)])
 def test_general_partition_structure_and_owned_rows(kind, world):
     g = amr_mesh(kind)
