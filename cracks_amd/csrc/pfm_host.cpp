@@ -724,6 +724,8 @@ extern "C"
         // Colour classes (below) only read host tables: on a general mesh they are computed by a host thread NEXT TO the
         // uploads and the device build of the node graph (1.7 of the remaining 5.8 ms of a rebuild at 2.7e5 cells).
         std::vector<int32_t> order((size_t)NC);
+        std::vector<uint8_t> ring;
+        bool any_ring = false;
         std::exception_ptr colour_err;
         auto colour_classes = [&]() {
           try
@@ -774,6 +776,40 @@ extern "C"
               for (int64_t cell = 0; cell < NC; ++cell)
                 if (col[cell] >= 62)
                   col[cell] = (uint8_t)n_col; // hanging vertices (or more than 62 classes): the atomic class
+            }
+          // Cells of the plain classes that share a constraint-resolved node with a cell of the atomic class add
+          // atomically as well (DevView::cell_ring): every row the atomic class touches then only ever receives atomic
+          // adds, and the class -- 68 latency-bound waves, 15 % of a Jacobian at 2.7e5 cells -- runs next to the others
+          ring.assign((size_t)NC, 0);
+          any_ring = false;
+          if (!lattice_ok && !hn_index.empty())
+            {
+              std::vector<uint8_t> touched((size_t)N, 0);
+              bool any_atomic = false;
+              for (int64_t cell = 0; cell < NC; ++cell)
+                if (col[cell] == n_col)
+                  {
+                    any_atomic = true;
+                    for (int a = 0; a < nv; ++a)
+                      {
+                        const int32_t n = m->cell_nodes[cell * nv + a];
+                        touched[n] = 1;
+                        const int32_t k = hn_index[n];
+                        if (k >= 0)
+                          for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
+                            touched[m->hn_parents[j]] = 1;
+                      }
+                  }
+              if (any_atomic)
+                for (int64_t cell = 0; cell < NC; ++cell)
+                  if (col[cell] != n_col)
+                    {
+                      bool r = false;
+                      for (int a = 0; a < nv; ++a)
+                        r = r || touched[m->cell_nodes[cell * nv + a]] != 0;
+                      ring[cell] = r ? 1 : 0;
+                      any_ring = any_ring || r;
+                    }
             }
           c->color_ptr.assign((size_t)n_col + 2, 0);
           for (int64_t cell = 0; cell < NC; ++cell)
@@ -888,6 +924,7 @@ extern "C"
         if (colour_err)
           std::rethrow_exception(colour_err);
         v.color_cells = dev_upload(c, order.data(), order.size());
+        v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
         clk.mark("colour classes");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
@@ -1757,6 +1794,26 @@ extern "C"
         }
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
+    // general family: the atomic class (cells with hanging vertices) on the side stream next to the colour classes, behind
+    // the zeroing of the outputs (DevView::cell_ring; PFM_GENERAL_SEQUENTIAL=1: one after the other)
+    static const bool general_sequential = getenv("PFM_GENERAL_SEQUENTIAL") != nullptr;
+    // (a residual-only assembly keeps the stream order: its atomic class takes 15 us, less than a fork and a join)
+    const bool fork_general = !cart && !residual_only && c->v.cell_ring != nullptr && !general_sequential;
+    if (fork_general)
+      {
+        if (!c->side_stream)
+          {
+            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+              return fail(c, PFM_ERR_HIP, "side stream");
+          }
+        e = hipEventRecord(c->ev_fork, c->stream);
+        if (e == hipSuccess)
+          e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);
+        if (e != hipSuccess)
+          return hipfail(c, e, "fork (general family)");
+      }
     if (cart && !residual_only && c->v.dim == 3 && c->scal_dirty)
       {
         // off the hot path: once per pfm_set_params, complete before any kernel of any stream may read it
@@ -1771,7 +1828,16 @@ extern "C"
     if (!pair)
       cv_launch.patch_idx = nullptr, cv_launch.patch_val = nullptr, cv_launch.patch_count = nullptr, cv_launch.patch_cap = 0;
     int rc = cart ? launch_assemble_cart(c->v, cv_launch, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, pair || fork ? s_res : c->stream, c->d_scal, phase)
-                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr);
+                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr,
+                                            fork_general ? c->side_stream : nullptr);
+    if (fork_general)
+      {
+        e = hipEventRecord(c->ev_join, c->side_stream);
+        if (e == hipSuccess)
+          e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        if (e != hipSuccess)
+          return hipfail(c, e, "join (general family)");
+      }
     if (fork)
       {
         e = hipEventRecord(c->ev_join, s_res);

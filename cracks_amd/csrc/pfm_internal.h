@@ -29,6 +29,9 @@ namespace pfm
     const int32_t *hn_parents;
     const double *hn_weights;
     const uint8_t *node_flags; // [n_nodes] bit c: dof (node,c) has a homogeneous constraint line
+    const uint8_t *cell_ring;  // [n_cells] or nullptr: 1 = a cell of a plain colour class that shares a (constraint-resolved) node
+                               // with a cell of the atomic class: it adds atomically too, so that the atomic class may run NEXT
+                               // TO the colour classes (general family, pfm_kernels.hip)
     // node state (cracks.cc:2147-2154 after the ghost import)
     double *u[3];
     double *phi, *phi_old, *phi_oldold;
@@ -170,7 +173,7 @@ namespace pfm
   // hanging vertices (their rows are distributed to the parents, which other vertices of the same cell may be: atomics)
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
-                              hipStream_t s, const std::vector<long long> &color_ptr);
+                              hipStream_t s, const std::vector<long long> &color_ptr, hipStream_t s_atomic = nullptr);
 } // namespace pfm
 
 struct pfm_ctx

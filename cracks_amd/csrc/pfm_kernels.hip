@@ -665,6 +665,8 @@ namespace pfm
           const bool owned = A < v.n_owned; // rows of ghost nodes belong to another rank
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           const unsigned fA = v.node_flags[A];
+          // a cell next to the atomic class (which may be running on another stream): atomic adds, see DevView::cell_ring
+          const bool ring = v.cell_ring != nullptr && v.cell_ring[cell] != 0;
           if (owned && RESID)
             {
             double *pr[nc], *pt[nc], o_r[nc], o_t[nc];
@@ -674,18 +676,28 @@ namespace pfm
                 const long long di = dof_index<dim>(v, A, c);
                 pr[c] = res_pde + di;
                 pt[c] = res_tot + di;
-                o_r[c] = *pr[c];
+                o_r[c] = ring ? 0.0 : *pr[c];
                 if (residual_only)
-                  o_t[c] = *pt[c];
+                  o_t[c] = ring ? 0.0 : *pt[c];
               }
 #pragma unroll
             for (int c = 0; c < nc; ++c)
               {
                 const bool con = (fA >> c) & 1u;
                 if (!con)
-                  *pr[c] = o_r[c] + R[c];
+                  {
+                    if (ring)
+                      add_to<true>(pr[c], R[c]);
+                    else
+                      *pr[c] = o_r[c] + R[c];
+                  }
                 if (residual_only && (!con || !total_via_update))
-                  *pt[c] = o_t[c] + R[c];
+                  {
+                    if (ring)
+                      add_to<true>(pt[c], R[c]);
+                    else
+                      *pt[c] = o_t[c] + R[c];
+                  }
               }
           }
           if constexpr (FULL)
@@ -749,11 +761,16 @@ namespace pfm
                   on[NE - 1] = !((fA >> dim) & 1u) && !((fQ >> dim) & 1u);
 #pragma unroll
                   for (int e = 0; e < NE; ++e)
-                    oe[e] = *pe[e];
+                    oe[e] = ring ? 0.0 : *pe[e];
 #pragma unroll
                   for (int e = 0; e < NE; ++e)
                     if (on[e])
-                      *pe[e] = oe[e] + ke[e];
+                      {
+                        if (ring)
+                          add_to<true>(pe[e], ke[e]);
+                        else
+                          *pe[e] = oe[e] + ke[e];
+                      }
                 }
               // diagonal of constrained rows (deal.II distribute_local_to_global): |K_ii| or, when that is zero, the
               // mean |diagonal| of the element matrix
@@ -773,7 +790,10 @@ namespace pfm
                     if ((fA >> c) & 1u)
                       {
                         double *pd = entry(c, slot, c);
-                        *pd += diag[c] != 0.0 ? diag[c] : avg;
+                        if (ring)
+                          add_to<true>(pd, diag[c] != 0.0 ? diag[c] : avg);
+                        else
+                          *pd += diag[c] != 0.0 ? diag[c] : avg;
                       }
                 }
             }
@@ -1187,7 +1207,7 @@ namespace pfm
 
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *res_pde, double *res_tot, hipStream_t s,
-                              const std::vector<long long> &color_ptr)
+                              const std::vector<long long> &color_ptr, hipStream_t s_atomic)
   {
     int rc = ensure_tables();
     if (rc)
@@ -1207,12 +1227,17 @@ namespace pfm
     const int n_classes = (int)color_ptr.size() - 1;
     // one launch per colour class, in class order (stream order = the summation order of a row: reproducible);
     // the last class (cells with hanging vertices) adds atomically
-    for (int k = 0; k < n_classes; ++k)
+    // s_atomic: the caller has forked it off s behind the zeroing of the outputs and joins it afterwards; the atomic class
+    // goes first, on that stream (needs DevView::cell_ring)
+    hipStream_t s_main = s;
+    for (int kk = 0; kk < n_classes; ++kk)
       {
+        const int k = (s_atomic && v.cell_ring) ? (kk == 0 ? n_classes - 1 : kk - 1) : kk;
         const long long c0 = color_ptr[k], cn = color_ptr[k + 1] - c0;
         if (cn == 0)
           continue;
         const bool atomic = k == n_classes - 1;
+        s = (atomic && s_atomic && v.cell_ring) ? s_atomic : s_main;
         const dim3 grid((unsigned)((cn + cpb - 1) / cpb)), block(256);
 #define PFM_LAUNCH(DIM, FULLV, SPLITV)                                                                                       \
   do                                                                                                                         \
