@@ -197,7 +197,7 @@ namespace pfm
     // row accumulators of a hex vertex need 374 registers -- one wave per SIMD plus accumulation-register moves; two
     // launches with 54 accumulators each run at two waves per SIMD).  The residual and the constrained diagonals are
     // written by the launch with BH < 0 or BH == 1 (the upper half has the registers to spare).
-    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1>
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1, bool RING = false /* DevView::cell_ring is set */>
     __global__ __launch_bounds__(256, (dim == 3 && FULL) ? 2 : 1) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
                                                               double *res_pde, double *res_tot,
                                                               int residual_only, long long class_begin, long long class_size)
@@ -666,7 +666,7 @@ namespace pfm
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           const unsigned fA = v.node_flags[A];
           // a cell next to the atomic class (which may be running on another stream): atomic adds, see DevView::cell_ring
-          const bool ring = v.cell_ring != nullptr && v.cell_ring[cell] != 0;
+          const bool ring = RING && v.cell_ring[cell] != 0;
           if (owned && RESID)
             {
             double *pr[nc], *pt[nc], o_r[nc], o_t[nc];
@@ -1245,6 +1245,9 @@ namespace pfm
       if (atomic)                                                                                                            \
         hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,  \
                            residual_only, c0, cn);                                                                           \
+      else if (v.cell_ring)                                                                                                  \
+        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false, -1, true>), grid, block, 0, s, v, p, vals, res_pde, \
+                           res_tot, residual_only, c0, cn);                                                                  \
       else                                                                                                                   \
         hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
                            residual_only, c0, cn);                                                                           \
@@ -1279,6 +1282,13 @@ namespace pfm
                     hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 0>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
                                        residual_only, c0, cn);
                     hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 1>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                  }
+                else if (v.cell_ring)
+                  {
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 0, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
+                                       residual_only, c0, cn);
+                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 1, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
                                        residual_only, c0, cn);
                   }
                 else
