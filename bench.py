@@ -99,7 +99,7 @@ def measured_hbm_traffic(dim: int, n: int, residual_only: bool):
         return None, src
     total = 0.0
     for name, d in rec["per_launch"].items():
-        if residual_only and name not in ("k_cart_residual3", "k_cart_residual", "k_state_set"):
+        if residual_only and name not in ("k_cart_residual3", "k_cart_residual2m", "k_state_set", "k_state_set_solution"):
             continue
         total += d.get("write_bytes", 0.0) + d.get("fetch_bytes", 0.0)
     return total, src
@@ -284,6 +284,10 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
         rec = {"ms_per_call": wall, "kernel_ms": k_ms, "DoFs_per_s": n_dofs / (wall * 1e-3),
                "hbm_frac": ab / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
                "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)}
+        if residual_only:
+            # the line-search call (cracks.cc:2942-2957): only `solution` is scattered again between two residuals
+            rec["state_scatter"] = "solution_only"
+            rec["launch_and_scatter_ms"] = wall - k_ms
         vi, src = measured_valu_instructions(dim, n, residual_only)
         if vi is not None:
             to_ms = 4.0 / N_SIMD / (CLOCK_GHZ * 1e9) * 1e3
@@ -518,6 +522,7 @@ def main():
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
                                    f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (%d nnz/row-node-comp)' % (4 * 3 ** dim)}",
                        "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
+                       "state_scatter": "solution_only" if residual_only else "all three vectors, every step",
                        "setup_s": round(t_setup, 2),  # mesh + synthetic state in numpy + context
                        # pfm_ctx_create alone: what a setup_system() after refine_mesh costs (cracks.cc:4148)
                        "ctx_create_s": round(asm.ctx.create_seconds, 3), "ctx_rebuild_s": ctx_rebuild_s},

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libpfm_hip.so")
 
 PFM_OK = 0
 STATUS_NAMES = {0: "PFM_OK", 1: "PFM_ERR_BAD_ARG", 2: "PFM_ERR_HIP", 3: "PFM_ERR_NOT_ORTHOGONAL",
-                4: "PFM_ERR_NONFINITE", 5: "PFM_ERR_UNSUPPORTED", 6: "PFM_ERR_NOMEM", 7: "PFM_ERR_COMM"}
+                4: "PFM_ERR_NONFINITE", 5: "PFM_ERR_UNSUPPORTED", 6: "PFM_ERR_NOMEM", 7: "PFM_ERR_COMM", 8: "PFM_ERR_INTERNAL"}
 COMM_ID_BYTES = 128
 LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 
@@ -23,7 +23,7 @@ LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 EXPORTS = [
     "pfm_ctx_create", "pfm_ctx_destroy", "pfm_last_error", "pfm_ctx_set_stream", "pfm_set_params",
     "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_pattern_bind", "pfm_pattern_bind_i32",
-    "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_destroy", "pfm_halo_exchange", "pfm_assemble_overlapped",
+    "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_wrap", "pfm_comm_destroy", "pfm_comm_aborted", "pfm_halo_exchange", "pfm_assemble_overlapped",
     "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
     "pfm_assemble_device",
@@ -104,6 +104,8 @@ def load():
     lib.pfm_comm_unique_id.argtypes = [vp]
     lib.pfm_comm_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32]
     lib.pfm_comm_destroy.argtypes = [vp]
+    lib.pfm_comm_wrap.argtypes = [C.POINTER(vp), vp]
+    lib.pfm_comm_aborted.argtypes = [vp]
     lib.pfm_halo_exchange.argtypes = [vp, vp, vp]
     lib.pfm_assemble_overlapped.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     lib.pfm_check_finite.argtypes = [vp, vp, i64]

@@ -110,244 +110,6 @@ namespace pfm
 
 
     // =====================================================================================
-    // Residual, row owner (cracks.cc:2393-2432 gathered per test vertex).  One wave covers 63
-    // x-consecutive owned nodes of one lattice row (+ 1 halo lane): lane l evaluates the q-point state
-    // of the 2^(dim-1) cells to the RIGHT of its node once and integrates it against the test functions
-    // of both x-neighbours of the cell (a_x = 0: its own node, a_x = 1: the node of lane l+1, handed over
-    // with one wave shift).  Every cell column is thus evaluated once per (j,k) row instead of twice.
-    // =====================================================================================
-    template <int dim>
-    __global__ __launch_bounds__(256) void k_cart_residual(DevView v, CartView cv, Scal S,
-                                                           double *__restrict__ res_pde,
-                                                           double *__restrict__ res_tot, int write_total)
-    {
-      constexpr int nv = 1 << dim, nc = dim + 1;
-      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
-      const int OWZ = dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
-      const int lane = threadIdx.x & 63;
-      const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-      const int chunks = (OWX + 62) / 63;
-      const long long n_rows = (long long)OWY * OWZ;
-      if (wave >= n_rows * chunks)
-        return; // whole wave
-      const int chunk = (int)(wave % chunks);
-      const long long rowid = wave / chunks;
-      const int j = cv.o0[1] + (int)(rowid % OWY);
-      const int k = dim == 3 ? cv.o0[2] + (int)(rowid / OWY) : 0;
-      const int xi = chunk * 63 + lane - 1; // lane 0 is the halo lane of the chunk
-      const int i = cv.o0[0] + xi;
-      {
-        const int iA = cv.o0[0] + chunk * 63;
-        if (cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, iA - 1, iA + 63) || cart_range_has_ghost(cv, 1, j - 1, j + 1) ||
-                                      (dim == 3 && cart_range_has_ghost(cv, 2, k - 1, k + 1))))
-          return; // overlapped assembly: the other launch owns this wave's chunk
-      }
-
-      const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = dim == 3 ? 1.0 / cv.h[2] : 0.0;
-      const double vol = cv.h[0] * cv.h[1] * (dim == 3 ? cv.h[2] : 1.0);
-      double R0[nc], R1[nc]; // contributions to node i (a_x = 0) and to node i+1 (a_x = 1)
-#pragma unroll
-      for (int c = 0; c < nc; ++c)
-        R0[c] = R1[c] = 0.0;
-
-      const int ci = i; // the cell column to the right of node i
-      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && xi < OWX;
-#pragma unroll 1
-      for (int e = 0; e < nv / 2; ++e)
-        {
-          const int ay = e & 1, az = (e >> 1) & 1;
-          const int cj = j - ay, ck = k - az;
-          if (!col_ok || cj < 0 || cj >= cv.NY - 1)
-            continue;
-          if (dim == 3 && (ck < 0 || ck >= cv.NZ - 1))
-            continue;
-          double lam = S.lam, mu = S.mu;
-          if (cv.cell_lam) // heterogeneous material, cracks.cc:2207-2216
-            {
-              const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * (dim == 3 ? ck : 0));
-              lam = cv.cell_lam[cidx];
-              mu = cv.cell_mu[cidx];
-            }
-          // nodal values of the cell: [field][vertex]; fields u(dim), phi, phi_old, phi_oldold
-          double U[dim + 3][nv];
-#pragma unroll
-          for (int b = 0; b < nv; ++b)
-            {
-              // arithmetic for owned nodes (no index load in front of the field loads)
-              const int n = cart_local_id3(cv, ci + (b & 1), cj + ((b >> 1) & 1), dim == 3 ? ck + ((b >> 2) & 1) : 0);
-#pragma unroll
-              for (int d = 0; d < dim; ++d)
-                U[d][b] = v.u[d][n];
-              U[dim][b] = v.phi[n];
-              U[dim + 1][b] = v.phi_old[n];
-              U[dim + 2][b] = v.phi_oldold[n];
-            }
-          constexpr int NZQ = dim == 3 ? 3 : 1;
-#pragma unroll 1
-          for (int qz = 0; qz < NZQ; ++qz)
-            {
-              double Pl[dim + 3][4], Dz[dim + 1][4];
-              const double nz0 = dim == 3 ? c_t1.n[0][qz] : 1.0, nz1 = dim == 3 ? c_t1.n[1][qz] : 0.0;
-#pragma unroll
-              for (int f = 0; f < dim + 3; ++f)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                  {
-                    if constexpr (dim == 3)
-                      Pl[f][b] = nz0 * U[f][b] + nz1 * U[f][b + 4];
-                    else
-                      Pl[f][b] = U[f][b];
-                  }
-#pragma unroll
-              for (int f = 0; f < dim + 1; ++f)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                  {
-                    if constexpr (dim == 3)
-                      Dz[f][b] = (U[f][b + 4] - U[f][b]) * ihz;
-                    else
-                      Dz[f][b] = 0.0;
-                  }
-              const double naz = dim == 3 ? (az ? nz1 : nz0) : 1.0;
-              const double wz = dim == 3 ? c_t1.w[qz] : 1.0;
-#pragma unroll 1
-              for (int qy = 0; qy < 3; ++qy)
-                {
-                  const double ny0 = c_t1.n[0][qy], ny1 = c_t1.n[1][qy];
-                  double L[dim + 3][2], Dy[dim + 1][2], DzL[dim + 1][2];
-#pragma unroll
-                  for (int f = 0; f < dim + 3; ++f)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                      L[f][b] = ny0 * Pl[f][b] + ny1 * Pl[f][b + 2];
-#pragma unroll
-                  for (int f = 0; f < dim + 1; ++f)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                      {
-                        Dy[f][b] = (Pl[f][b + 2] - Pl[f][b]) * ihy;
-                        DzL[f][b] = ny0 * Dz[f][b] + ny1 * Dz[f][b + 2];
-                      }
-                  const double nay = ay ? ny1 : ny0;
-                  const double wyz = c_t1.w[qy] * wz;
-                  double Dx[dim + 1];
-#pragma unroll
-                  for (int f = 0; f < dim + 1; ++f)
-                    Dx[f] = (L[f][1] - L[f][0]) * ihx;
-                  for (int qx = 0; qx < 3; ++qx)
-                    {
-                      const double nx0 = c_t1.n[0][qx], nx1 = c_t1.n[1][qx];
-                      const double JxW = vol * c_t1.w[qx] * wyz;
-                      // Newton state at q (cracks.cc:2222-2232)
-                      double gu[dim][dim], gpf[dim];
-#pragma unroll
-                      for (int c = 0; c < dim; ++c)
-                        {
-                          gu[c][0] = Dx[c];
-                          gu[c][1] = nx0 * Dy[c][0] + nx1 * Dy[c][1];
-                          if constexpr (dim == 3)
-                            gu[c][2] = nx0 * DzL[c][0] + nx1 * DzL[c][1];
-                        }
-                      gpf[0] = Dx[dim];
-                      gpf[1] = nx0 * Dy[dim][0] + nx1 * Dy[dim][1];
-                      if constexpr (dim == 3)
-                        gpf[2] = nx0 * DzL[dim][0] + nx1 * DzL[dim][1];
-                      double pf = nx0 * L[dim][0] + nx1 * L[dim][1];
-                      double pfo = nx0 * L[dim + 1][0] + nx1 * L[dim + 1][1];
-                      double pfoo = nx0 * L[dim + 2][0] + nx1 * L[dim + 2][1];
-                      if (S.monolithic)
-                        {
-                          pf = fmax(0.0, pf);
-                          pfo = fmax(0.0, pfo);
-                          pfoo = fmax(0.0, pfoo);
-                        }
-                      const double pen = fmax(0.0, pf - pfo);
-                      double pfx = pfoo + S.tfac * (pfo - pfoo);
-                      if (pfx <= 0.0)
-                        pfx = 0.0;
-                      if (pfx >= 1.0)
-                        pfx = 1.0;
-                      if (S.use_old)
-                        pfx = pfo;
-                      const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-                      double E[dim][dim], trE = 0.0, divu = 0.0;
-#pragma unroll
-                      for (int a = 0; a < dim; ++a)
-                        {
-                          divu += gu[a][a];
-#pragma unroll
-                          for (int b = 0; b < dim; ++b)
-                            E[a][b] = 0.5 * (gu[a][b] + gu[b][a]);
-                          trE += E[a][a];
-                        }
-                      // Z = (g sigma+ - (alpha_B-1) p pfx^2 I) JxW, scalar part of the phi row
-                      double Z[dim][dim], spE = 0.0;
-#pragma unroll
-                      for (int a = 0; a < dim; ++a)
-#pragma unroll
-                        for (int b = 0; b < dim; ++b)
-                          {
-                            const double sp = lam * trE * (a == b ? 1.0 : 0.0) + 2 * mu * E[a][b];
-                            spE += sp * E[a][b];
-                            Z[a][b] = (g * sp - (a == b ? S.aB1 * S.p * pfx * pfx : 0.0)) * JxW;
-                          }
-                      const double rq = (S.gamma_fac * pen + (1.0 - S.kappa) * spE * pf - S.Gc / S.eps * (1.0 - pf) -
-                                         2.0 * S.aB1 * S.p * pf * divu) *
-                                        JxW;
-                      const double ge = S.Gc * S.eps * JxW;
-                      // test functions of the two x-neighbours of the cell at q
-#pragma unroll
-                      for (int ax = 0; ax < 2; ++ax)
-                        {
-                          const double nax = ax ? nx1 : nx0;
-                          double gNa[dim];
-                          gNa[0] = (ax ? ihx : -ihx) * nay * naz;
-                          gNa[1] = (ay ? ihy : -ihy) * nax * naz;
-                          if constexpr (dim == 3)
-                            gNa[2] = (az ? ihz : -ihz) * nax * nay;
-                          double *R = ax ? R1 : R0;
-#pragma unroll
-                          for (int c = 0; c < dim; ++c)
-                            {
-                              double tt = 0.0;
-#pragma unroll
-                              for (int kk = 0; kk < dim; ++kk)
-                                tt += Z[c][kk] * gNa[kk];
-                              R[c] -= tt;
-                            }
-                          double gg = 0.0;
-#pragma unroll
-                          for (int kk = 0; kk < dim; ++kk)
-                            gg += gpf[kk] * gNa[kk];
-                          R[dim] -= rq * (nax * nay * naz) + ge * gg;
-                        }
-                    }
-                }
-            }
-        }
-      // node i = own a_x = 0 part + the a_x = 1 part of the cell column on its left (lane - 1)
-      double R[nc];
-#pragma unroll
-      for (int c = 0; c < nc; ++c)
-        R[c] = R0[c] + __shfl_up(R1[c], 1);
-      if (lane == 0 || xi >= OWX)
-        return;
-      const int row = cart_local_id3(cv, i, j, k);
-      // constrained scatter degenerates to a masked store (cracks.cc:2440-2456)
-      const unsigned fl = v.node_flags[row];
-#pragma unroll
-      for (int c = 0; c < nc; ++c)
-        {
-          const bool con = (fl >> c) & 1u;
-          const long long di = dof_index_c<dim>(v, row, c);
-          res_pde[di] = con ? 0.0 : R[c];
-          if (write_total)
-            res_tot[di] = (con && S.total_via_update) ? 0.0 : R[c];
-        }
-    }
-
-
-    // =====================================================================================
     // 2-D residual, y-marching cell columns (cracks.cc:2393-2432), no LDS and no barrier.
     //
     // A wave (= a workgroup) owns 62 x-consecutive nodes over a chunk of node rows; lane l <-> the cell column between
@@ -355,7 +117,7 @@ namespace pfm
     // per row (the next row is requested before the current cell is evaluated), gets the right-hand vertices from lane
     // l + 1 (DPP shift), evaluates its cell once, keeps the part that belongs to the upper node row for the next step and
     // completes node row j from its own a_x = 0 parts and the a_x = 1 parts of lane l - 1.  Every cell is evaluated once
-    // per chunk (the first-generation kernel below evaluates it for both node rows it touches), every nodal value is
+    // per chunk (the first-generation kernel, removed in round 4, evaluated it for both node rows it touches), every nodal value is
     // read once per tile, and a wave waits for one memory round trip per row that the evaluation of the previous row
     // covers.  LIN: one combined old phase field as in k_cart_residual3.
     // =====================================================================================
@@ -968,7 +730,7 @@ namespace pfm
   {
     if (v.dim != 3 || residual_only || phase != 0 || cv.cell_lam)
       return false;
-    static const bool other_mode = getenv("PFM_RES_KERNEL") || getenv("PFM_UU4") || getenv("PFM_UU5") || getenv("PFM_UU_CLK") || getenv("PFM_PHI_CLK");
+    static const bool other_mode = getenv("PFM_RES_KERNEL") || getenv("PFM_UU_CLK") || getenv("PFM_PHI_CLK");
     if ((p.decompose_stress_matrix > 0 && p.timestep_number > 0) || other_mode)
       return false;
     const Scal S = make_scal(p, cv, v.dim);
@@ -1005,26 +767,19 @@ namespace pfm
                                !cv.cell_lam; // (the heterogeneous (u,u) variant has no registers left for it)
     if (rows_residual) // s_residual != s_jac: the caller forked it off for the phase-field kernel (cart_jacobian_pair)
       return launch_cart_matrix(v, cv, p, d_values, s_jac, d_scal, res_pde, phase, (phase == 0 && cv.patch_count) ? s : s_jac);
-    const int bs = 256;
     const long long OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = v.dim == 3 ? cv.o1[2] - cv.o0[2] + 1 : 1;
-    const long long n_waves = OWY * OWZ * ((OWX + 62) / 63);
-    const unsigned nb = (unsigned)((n_waves + 3) / 4);
     if (v.dim == 2)
       {
-        static const bool first_gen = getenv("PFM_RES2_OLD") != nullptr; // A/B: the first-generation kernel
-        if (first_gen)
-          hipLaunchKernelGGL(k_cart_residual<2>, dim3(nb), dim3(bs), 0, s, v, cv, S, res_pde, res_tot, residual_only);
+        const int ntx = (int)((OWX + R2N - 1) / R2N);
+        static const int zc_force = getenv("PFM_RES2_ZC") ? atoi(getenv("PFM_RES2_ZC")) : 0; // tuning only
+        const int zc = zc_force > 0 ? zc_force : choose_zchunk(ntx, (int)OWY, 4, 64, 8);
+        const unsigned nw = (unsigned)(ntx * ((OWY + zc - 1) / zc));
+        if (nw == 0)
+          ;
+        else if (!S.monolithic && S.gamma_fac == 0.0)
+          hipLaunchKernelGGL(k_cart_residual2m<true>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
         else
-          {
-            const int ntx = (int)((OWX + R2N - 1) / R2N);
-            static const int zc_force = getenv("PFM_RES2_ZC") ? atoi(getenv("PFM_RES2_ZC")) : 0; // tuning only
-            const int zc = zc_force > 0 ? zc_force : choose_zchunk(ntx, (int)OWY, 4, 64, 8);
-            const unsigned nw = (unsigned)(ntx * ((OWY + zc - 1) / zc));
-            if (!S.monolithic && S.gamma_fac == 0.0)
-              hipLaunchKernelGGL(k_cart_residual2m<true>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
-            else
-              hipLaunchKernelGGL(k_cart_residual2m<false>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
-          }
+          hipLaunchKernelGGL(k_cart_residual2m<false>, dim3(nw), dim3(64), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
       }
     else
       {

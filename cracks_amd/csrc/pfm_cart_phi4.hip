@@ -1069,30 +1069,15 @@ namespace pfm
   {
     if (v.dim != 3)
       return PFM_ERR_UNSUPPORTED;
-    // (u,u) kernel: k_cart_uu3 (tile per plane); PFM_UU5=1: the z-march of round 3 (pfm_cart_uu5.hip); PFM_UU4=1: the
-    // z-march of round 2 (no residual rows, no heterogeneous material)
-    static const int uu_sel = getenv("PFM_UU5") ? 5 : (getenv("PFM_UU4") ? 4 : 3);
     // phase 1 / 2 of an overlapped assembly: the (u,u) kernel is cut into interior and boundary tiles (CartView::tile_sel),
     // the phase-field kernel follows completely in phase 2 -- it patches (u,u) diagonals of constrained rows and must see
     // every (u,u) tile written, and the ghost import (~0.1 ms) is hidden behind the interior (u,u) tiles alone
     CartView cv = cv_in;
+    cv.tile_sel = phase;
+    // next to the phase-field kernel: the same LDS allocation as that kernel (64 granules of 1280 B; 79,472 B are 63), so
+    // that a slot freed by either kernel takes a workgroup of either
+    int rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde, s_phi != s ? 2048 : 0);
     cv.tile_sel = 0;
-    const bool cut = phase != 0 && (uu_sel == 3 || cv.cell_lam);
-    if (phase == 1 && !cut)
-      return PFM_OK; // the marching variants are not cut: everything in phase 2
-    int rc;
-    if (uu_sel == 5 && !cv.cell_lam)
-      rc = launch_cart_uu5(v, cv, p, d_values[0], s, d_scal, res_pde);
-    else if (uu_sel == 4 && !cv.cell_lam && !res_pde)
-      rc = launch_cart_uu4(v, cv, p, d_values[0], s, d_scal);
-    else
-      {
-        cv.tile_sel = cut ? phase : 0;
-        // next to the phase-field kernel: the same LDS allocation as that kernel (64 granules of 1280 B; 79,472 B are 63), so
-        // that a slot freed by either kernel takes a workgroup of either
-        rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde, s_phi != s ? 2048 : 0);
-        cv.tile_sel = 0;
-      }
     if (rc || phase == 1)
       return rc;
     if (s_phi != s && !cv.patch_count)
@@ -1103,19 +1088,24 @@ namespace pfm
   namespace
   {
     __global__ void k_cart_apply_patches(double *__restrict__ vals_uu, const long long *__restrict__ idx, const double *__restrict__ val,
-                                         const int *__restrict__ count, int cap)
+                                         const int *__restrict__ count, int cap, int *__restrict__ status)
     {
-      const int n = min(*count, cap); // (the list holds one entry per flagged displacement dof at most: cap is never exceeded)
+      // the list holds one entry per flagged displacement dof at most (capacity from pfm_set_constraints); should that
+      // invariant ever break, the dropped patches are reported instead of lost silently
+      if (*count > cap && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicMax(status, (int)PFM_ERR_INTERNAL);
+      const int n = min(*count, cap);
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         vals_uu[idx[i]] += val[i]; // one entry per matrix value at most: no two threads share an address
     }
   } // namespace
 
-  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s)
+  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s, int *status)
   {
     if (!cv.patch_count)
       return PFM_OK;
-    hipLaunchKernelGGL(k_cart_apply_patches, dim3(64), dim3(256), 0, s, vals_uu, cv.patch_idx, cv.patch_val, cv.patch_count, cv.patch_cap);
+    hipLaunchKernelGGL(k_cart_apply_patches, dim3(64), dim3(256), 0, s, vals_uu, cv.patch_idx, cv.patch_val, cv.patch_count, cv.patch_cap,
+                       status);
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
 } // namespace pfm

@@ -829,9 +829,6 @@ namespace pfm
   int launch_cart_uu_only(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                           void *d_scal)
   {
-    static const int uu_sel = getenv("PFM_UU5") ? 5 : (getenv("PFM_UU4") ? 4 : 3);
-    if (uu_sel == 5 && !cv.cell_lam)
-      return launch_cart_uu5(v, cv, p, vals_uu, s, d_scal, nullptr);
-    return (uu_sel == 3 || cv.cell_lam) ? launch_cart_uu3(v, cv, p, vals_uu, s, d_scal, nullptr) : launch_cart_uu4(v, cv, p, vals_uu, s, d_scal);
+    return launch_cart_uu3(v, cv, p, vals_uu, s, d_scal, nullptr);
   }
 } // namespace pfm

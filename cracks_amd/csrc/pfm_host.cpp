@@ -882,20 +882,26 @@ extern "C"
                 {
                   // node graph of a general mesh on the device, from the cell table as the host handed it over
                   long long *d_ptr = dev_alloc<long long>(c, (size_t)NO + 1);
-                  GraphScratch sc;
+                  struct ScratchGuard // the incidence lists are freed on every way out, a throwing dev_alloc included
+                  {
+                    GraphScratch sc;
+                    ~ScratchGuard() { graph_build_free(sc); }
+                  } g;
                   long long total = 0;
-                  rcg = graph_build_begin(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, sc, total, nullptr);
+                  rcg = graph_build_begin(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, g.sc, total, nullptr);
                   if (rcg == PFM_OK)
                     {
                       int32_t *d_adj = dev_alloc<int32_t>(c, (size_t)std::max<long long>(total, 1));
-                      rcg = graph_build_rows(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, d_adj, sc, nullptr);
+                      rcg = graph_build_rows(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, d_adj, g.sc, nullptr);
                       c->h_nadj_ptr.assign((size_t)NO + 1, 0);
                       if (rcg == PFM_OK && hipMemcpy(c->h_nadj_ptr.data(), d_ptr, sizeof(long long) * ((size_t)NO + 1), hipMemcpyDeviceToHost) != hipSuccess)
                         rcg = PFM_ERR_HIP;
-                      graph_build_free(sc);
-                      v.nadj_ptr = d_ptr;
-                      v.nadj = d_adj;
-                      c->graph_dev_only = true; // the host copy of the columns is fetched when a pattern query asks for it
+                      if (rcg == PFM_OK)
+                        {
+                          v.nadj_ptr = d_ptr;
+                          v.nadj = d_adj;
+                          c->graph_dev_only = true; // the host copy of the columns is fetched when a pattern query asks for it
+                        }
                     }
                 }
             }
@@ -1332,6 +1338,8 @@ extern "C"
 
   int pfm_state_set_solution(pfm_ctx *c, const double *sol, int on_device) { return state_set_impl(c, sol, nullptr, nullptr, on_device); }
 
+  static int ensure_halo_buffers(pfm_ctx *c);
+
   int pfm_halo_register(pfm_ctx *c, int n_peers, const int64_t *send_ptr, const int32_t *send_nodes,
                         const int64_t *recv_ptr, const int32_t *recv_nodes)
   {
@@ -1408,6 +1416,12 @@ extern "C"
           e = hipMemcpy(c->d_recv_ptr, rp.data(), sizeof(long long) * rp.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess)
           return hipfail(c, e, "halo_register (concatenated lists)");
+        // the message buffers of pfm_halo_exchange are allocated HERE, a local call whose outcome the ranks can agree on,
+        // not inside the exchange: an allocation failing on one rank between its peers' enqueued sends and receives would
+        // leave them waiting
+        const int rcb = ensure_halo_buffers(c);
+        if (rcb)
+          return rcb;
       }
     return PFM_OK;
   }
@@ -1529,6 +1543,16 @@ extern "C"
   } // namespace
   } // extern "C++"
 
+  // what a communicator handle of this ABI points to: the RCCL communicator and whether a failed exchange aborted it
+  // (ncclCommAbort frees the communicator; the owner still holds the handle and must be able to destroy it)
+  struct PfmComm
+  {
+    ncclComm_t cm = nullptr;
+    bool aborted = false;
+    bool owned = true; // false: the host's own communicator (pfm_comm_wrap), never destroyed here
+    int n_ranks = 0, rank = 0;
+  };
+
   int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES])
   {
     if (!id)
@@ -1557,19 +1581,51 @@ extern "C"
     ncclComm_t cm = nullptr;
     if (R.CommInitRank(&cm, n_ranks, u, rank) != ncclSuccess)
       return PFM_ERR_COMM;
-    *comm = cm;
+    PfmComm *h = new (std::nothrow) PfmComm;
+    if (!h)
+      {
+        (void)R.CommAbort(cm);
+        return PFM_ERR_NOMEM;
+      }
+    h->cm = cm;
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    *comm = h;
     return PFM_OK;
   }
 
+  // The handle outlives an aborted communicator (a failed exchange aborts it so that no peer waits for a message that
+  // will never come): destroying it afterwards only frees the handle, using it again reports PFM_ERR_COMM.
   int pfm_comm_destroy(void *comm)
   {
     if (!comm)
       return PFM_OK;
-    const RcclApi &R = rccl();
-    if (!R.ok)
-      return PFM_ERR_COMM;
-    return R.CommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? PFM_OK : PFM_ERR_COMM;
+    PfmComm *h = static_cast<PfmComm *>(comm);
+    int rc = PFM_OK;
+    if (!h->aborted && h->owned)
+      {
+        const RcclApi &R = rccl();
+        rc = (R.ok && R.CommDestroy(h->cm) == ncclSuccess) ? PFM_OK : PFM_ERR_COMM;
+      }
+    h->cm = nullptr;
+    delete h;
+    return rc;
   }
+
+  int pfm_comm_wrap(void **comm, void *nccl_comm)
+  {
+    if (!comm || !nccl_comm)
+      return PFM_ERR_BAD_ARG;
+    PfmComm *h = new (std::nothrow) PfmComm;
+    if (!h)
+      return PFM_ERR_NOMEM;
+    h->cm = static_cast<ncclComm_t>(nccl_comm);
+    h->owned = false;
+    *comm = h;
+    return PFM_OK;
+  }
+
+  int pfm_comm_aborted(const void *comm) { return comm ? (static_cast<const PfmComm *>(comm)->aborted ? 1 : 0) : 0; }
 
   // both staging buffers or none: a half-allocated pair must not survive a failed call
   static int ensure_halo_buffers(pfm_ctx *c)
@@ -1605,14 +1661,25 @@ extern "C"
     const RcclApi &R = rccl();
     if (!R.ok)
       return fail(c, PFM_ERR_COMM, "RCCL unavailable: " + R.why);
+    PfmComm *h = static_cast<PfmComm *>(comm);
+    if (h->aborted || !h->cm)
+      return fail(c, PFM_ERR_COMM, "communicator was aborted by an earlier failed exchange");
+    ncclComm_t cm = h->cm;
+    // A rank that fails locally before its sends and receives are enqueued must not leave its peers waiting for them:
+    // the communicator is aborted on EVERY failure from here on (the buffers themselves come from pfm_halo_register)
+    auto abort_comm = [&](int code, const std::string &msg) {
+      (void)R.CommAbort(cm);
+      h->aborted = true; // the handle stays valid for pfm_comm_destroy; further exchanges on it are refused
+      h->cm = nullptr;
+      return fail(c, code, msg + " (communicator aborted)");
+    };
     int rc = ensure_halo_buffers(c);
     if (rc)
-      return rc;
+      return abort_comm(rc, "halo buffers");
     const int rec = PFM_HALO_DOUBLES_PER_NODE(c->v.dim);
     rc = launch_halo_all(c->v, c->d_send_all, c->d_send_ptr, (int)c->peers.size(), c->n_send_all, c->d_halo_send, 0, st);
     if (rc)
-      return fail(c, rc, "halo pack launch failed");
-    ncclComm_t cm = static_cast<ncclComm_t>(comm);
+      return abort_comm(rc, "halo pack launch failed");
     ncclResult_t r = R.GroupStart();
     int64_t so = 0, ro = 0;
     for (size_t k = 0; k < c->peers.size() && r == ncclSuccess; ++k)
@@ -1632,8 +1699,7 @@ extern "C"
       {
         // work may already be enqueued on the peers: there is no safe fall-back from here -- abort the
         // communicator so that no rank waits for a message that will never come, and report
-        (void)R.CommAbort(cm);
-        return fail(c, PFM_ERR_COMM, std::string("RCCL (communicator aborted): ") + R.GetErrorString(r));
+        return abort_comm(PFM_ERR_COMM, std::string("RCCL: ") + R.GetErrorString(r));
       }
     rc = launch_halo_all(c->v, c->d_recv_all, c->d_recv_ptr, (int)c->peers.size(), c->n_recv_all, c->d_halo_recv, 1, st);
     if (rc)
@@ -1847,7 +1913,7 @@ extern "C"
           return hipfail(c, e, "join");
       }
     if (pair && rc == PFM_OK)
-      rc = launch_cart_apply_patches(c->cv, d_values[0], c->stream);
+      rc = launch_cart_apply_patches(c->cv, d_values[0], c->stream, c->v.status);
     if (phase == 1)
       return rc ? fail(c, rc, "assemble launch failed (interior tiles)") : PFM_OK;
     if (rc == PFM_OK && overlay_uu && c->scal_dirty)

@@ -124,7 +124,7 @@ namespace pfm
   // true: this assembly is the pair k_cart_uu3<RES> + k_cart_phi4<RES> and may run them on two streams (s, s_residual of
   // launch_assemble_cart) -- the caller forks / joins and applies the deferred patches (CartView::patch_*)
   bool cart_jacobian_pair(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, int phase);
-  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s);
+  int launch_cart_apply_patches(const CartView &cv, double *vals_uu, hipStream_t s, int *status);
   bool cart_matrix_supported(int dim);
   // 2-D boxes: row-owner Jacobian + residual of runs WITHOUT the stress split (pfm_cart2d.hip; PFM_ERR_UNSUPPORTED otherwise)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
@@ -147,13 +147,6 @@ namespace pfm
   // res_pde != nullptr: the kernel also writes the displacement rows of the residual (from its matrix rows, see the kernel)
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
                       const void *d_scal, double *res_pde, int lds_pad = 0);
-  // z-marching variant of launch_cart_uu3 (pfm_cart_uu4.hip): bitwise identical results, measured equal in time;
-  // selected by PFM_UU4=1 (A/B runs, tests/test_gpu_cart.py runs both)
-  int launch_cart_uu4(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal);
-  // round 3: the z-march with LDS-DMA plane prefetch and the residual from the rows (pfm_cart_uu5.hip)
-  int launch_cart_uu5(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal, double *res_pde);
   // node graph of a general mesh on the device (pfm_graph.hip)
   struct GraphScratch
   {

@@ -49,7 +49,8 @@ typedef enum pfm_status
   PFM_ERR_NONFINITE = 4,      /* non-finite value in an output (checked by pfm_check_finite only) */
   PFM_ERR_UNSUPPORTED = 5,    /* e.g. stress split in 3-D (reference is 2-D only, cracks.cc:1685-1690) */
   PFM_ERR_NOMEM = 6,
-  PFM_ERR_COMM = 7            /* an RCCL call failed; pfm_last_error() has the text */
+  PFM_ERR_COMM = 7,           /* an RCCL call failed; pfm_last_error() has the text */
+  PFM_ERR_INTERNAL = 8        /* an invariant of the library was violated (e.g. the deferred-patch list overflowed) */
 } pfm_status;
 
 enum
@@ -159,13 +160,18 @@ int pfm_halo_unpack_all(pfm_ctx *ctx, const double *d_buf_all);
  *   pfm_comm_create      ncclCommInitRank: collective over the n_ranks processes, one GPU each
  *   pfm_halo_exchange    pack (one launch) -> ncclGroupStart, ncclSend/ncclRecv per peer, ncclGroupEnd -> unpack (one
  *                        launch), all asynchronous on the context's stream, into buffers the context owns;
- *                        peer_ranks[k] = communicator rank of peer k of pfm_halo_register.  `comm` is an ncclComm_t:
- *                        one made by pfm_comm_create or the host's own.  Collective: every rank of the communicator
- *                        that is somebody's peer must call it. */
+ *                        peer_ranks[k] = communicator rank of peer k of pfm_halo_register.  `comm` is a handle made
+ *                        by pfm_comm_create, or by pfm_comm_wrap around the host's own ncclComm_t.  Collective: every
+ *                        rank of the communicator that is somebody's peer must call it.
+ * Error path: a failed RCCL call inside an exchange aborts the communicator (ncclCommAbort: peers error out instead of
+ * waiting for a message that never comes).  The HANDLE stays valid: pfm_comm_aborted() reports the state, every further
+ * exchange on it returns PFM_ERR_COMM, and pfm_comm_destroy() only frees the handle then (no double free). */
 #define PFM_COMM_ID_BYTES 128
 int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES]);
 int pfm_comm_create(void **comm, const uint8_t id[PFM_COMM_ID_BYTES], int n_ranks, int rank, int device);
+int pfm_comm_wrap(void **comm, void *nccl_comm /* the host's ncclComm_t; not destroyed by pfm_comm_destroy */);
 int pfm_comm_destroy(void *comm);
+int pfm_comm_aborted(const void *comm); /* 1 after a failed exchange aborted the communicator, else 0 */
 int pfm_halo_exchange(pfm_ctx *ctx, void *comm, const int *peer_ranks /* host, [n_peers] */);
 /* pfm_halo_exchange + pfm_assemble_device with the ghost import HIDDEN behind cell work: after pfm_state_set the exchange
  * runs on a second stream of the context while the tiles that read no ghost node are assembled; the rest follows when the

@@ -263,10 +263,11 @@ def test_cart_residual_with_old_timestep_phase_field(dim, n):
     assert linf_scaled(res_pde, r.residual_pde) < TOL and linf_scaled(res_tot, r.residual_total) < TOL
 
 
-def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
-    """pfm_cart_uu4.hip (z-marching (u,u) kernel, PFM_UU4=1) against the default k_cart_uu3: same summation order, so
-    every (u,u) value must be the same bit pattern -- on a box with several tiles, partial tiles, z-chunks, constraint
-    flags and both layouts.  The variant is chosen when the library is first used, hence two processes."""
+def test_jacobian_pair_sequential_and_residual_kernel_agree(tmp_path):
+    """The same 3-D assembly in its three launch modes: default (the (u,u) and the phase-field kernel next to each other on
+    two streams, residual from the matrix rows, deferred placeholder patches), PFM_JAC_SEQUENTIAL=1 (one after the other)
+    and PFM_RES_KERNEL=1 (quadrature residual kernel) -- on a box with several tiles, partial tiles, z-chunks, constraint
+    flags and both layouts.  The mode is chosen when the library is first used, hence one process each."""
     import os
     import subprocess
     import sys
@@ -287,28 +288,18 @@ def test_uu4_z_marching_variant_is_bitwise_identical(tmp_path):
         "        rhs.append(res)\n"
         "np.save(sys.argv[1], np.concatenate(out))\n"
         "np.save(sys.argv[2], np.concatenate(rhs))\n")
-    # default: k_cart_uu3 / k_cart_phi4 also write the residual (from their matrix rows); PFM_RES_KERNEL=1: the quadrature
-    # residual kernel; PFM_UU4=1 (+ PFM_RES_KERNEL=1, the z-marching kernel has no residual variant): k_cart_uu4
     val, rhs = {}, {}
-    for tag, env in (("rows", {}), ("rows_seq", {"PFM_JAC_SEQUENTIAL": "1"}), ("uu3", {"PFM_RES_KERNEL": "1"}),
-                     ("uu4", {"PFM_UU4": "1", "PFM_RES_KERNEL": "1"}), ("uu5", {"PFM_UU5": "1", "PFM_RES_KERNEL": "1"}),
-                     ("uu5rows", {"PFM_UU5": "1"})):
+    for tag, env in (("rows", {}), ("rows_seq", {"PFM_JAC_SEQUENTIAL": "1"}), ("quad", {"PFM_RES_KERNEL": "1"})):
         f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
-        e = {k: v for k, v in os.environ.items() if k not in ("PFM_UU4", "PFM_UU5", "PFM_RES_KERNEL", "PFM_JAC_SEQUENTIAL")}
+        e = {k: v for k, v in os.environ.items() if k not in ("PFM_RES_KERNEL", "PFM_JAC_SEQUENTIAL")}
         e.update(env)
         subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
         val[tag], rhs[tag] = np.load(f), np.load(g)
-    assert val["uu3"].shape == val["uu4"].shape == val["rows"].shape
-    assert np.array_equal(val["uu3"], val["uu4"]) and np.array_equal(rhs["uu3"], rhs["uu4"])
-    # default: the (u,u) and the phase-field kernel next to each other on two streams (deferred placeholder patches);
-    # PFM_JAC_SEQUENTIAL=1: one after the other -- the same kernels, the same bits
+    # side by side or one after the other: the same kernels, the same bits (run-to-run reproducibility)
     assert np.array_equal(val["rows"], val["rows_seq"]) and np.array_equal(rhs["rows"], rhs["rows_seq"])
-    # the residual variant of the (u,u) kernel writes the same matrix bits; its residual equals the quadrature one to round-off
-    assert np.array_equal(val["rows"], val["uu3"])
-    assert rhs["rows"].shape == rhs["uu3"].shape and linf_scaled(rhs["rows"], rhs["uu3"]) < TOL
-    # round 3: the z-march with LDS-DMA plane prefetch (pfm_cart_uu5.hip), without and with the residual from the rows
-    assert np.array_equal(val["uu3"], val["uu5"]) and np.array_equal(rhs["uu3"], rhs["uu5"])
-    assert np.array_equal(val["uu3"], val["uu5rows"]) and linf_scaled(rhs["uu5rows"], rhs["uu3"]) < TOL
+    # the quadrature residual against the residual from the rows: round-off apart; the matrix to round-off as well
+    assert val["rows"].shape == val["quad"].shape and linf_scaled(val["rows"], val["quad"]) < TOL
+    assert rhs["rows"].shape == rhs["quad"].shape and linf_scaled(rhs["rows"], rhs["quad"]) < TOL
 
 
 # ---- 2-D row-owner Jacobian (pfm_cart2d.hip): BASELINE config 2 with the matrix, tests/sneddon_2d_1.prm on a uniform mesh
@@ -349,41 +340,6 @@ def test_cart2d_random_constraints_and_placeholders(blocked, kappa_zero):
     v0, r0, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
     v1, r1, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
     assert all(np.array_equal(a, b) for a, b in zip(v0, v1)) and np.array_equal(r0, r1)
-
-
-def test_cart2d_first_generation_kernel_agrees(tmp_path):
-    """PFM_CART2D_OLD=1 keeps the row-owner kernel of round 2 (thread <-> node, direct quadrature) for A/B runs: both
-    generations against each other on boxes with partial blocks and constraints (round-off apart: the second generation
-    sums moments).  The variant is chosen when the library is first used, hence two processes."""
-    import os
-    import subprocess
-    import sys
-
-    script = tmp_path / "run2d.py"
-    script.write_text(
-        "import sys, numpy as np\n"
-        f"sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]\n"
-        "import test_gpu_cart as T\n"
-        "from gpu_util import make_context\n"
-        "out, rhs = [], []\n"
-        "for blocked in (True, False):\n"
-        "    for n in ((33, 20), (7, 15)):\n"
-        "        c = T.box_case(2, n, -10.0, 10.0, blocked)\n"
-        "        ctx = make_context(c)\n"
-        "        values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)\n"
-        "        out.extend(values)\n"
-        "        rhs.append(res)\n"
-        "np.save(sys.argv[1], np.concatenate(out))\n"
-        "np.save(sys.argv[2], np.concatenate(rhs))\n")
-    val, rhs = {}, {}
-    for tag, env in (("cells", {}), ("rows", {"PFM_CART2D_OLD": "1"})):
-        f, g = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy"
-        e = {k: v for k, v in os.environ.items() if k != "PFM_CART2D_OLD"}
-        e.update(env)
-        subprocess.run([sys.executable, str(script), str(f), str(g)], check=True, env=e, timeout=600)
-        val[tag], rhs[tag] = np.load(f), np.load(g)
-    assert val["cells"].shape == val["rows"].shape and not np.array_equal(val["cells"], val["rows"])
-    assert linf_scaled(val["cells"], val["rows"]) < TOL and linf_scaled(rhs["cells"], rhs["rows"]) < TOL
 
 
 def test_cart2d_split_runs_stay_on_the_general_family():

@@ -144,7 +144,7 @@ def test_rows_of_the_bench_mesh_match_the_oracle():
 def test_rows_of_the_config2_mesh_match_the_oracle():
     """BASELINE configs[1] at its real size: 2-D Sneddon, 1000^2 quads, residual-only (k_cart_residual2m: waves of 62
     x-consecutive nodes over chunks of node rows -> 17 wave columns x y-chunks), and the 2-D Jacobian rows of the same
-    nodes (k_cart2d_rows).  Sampled at the mesh edges, the wave-column seams (multiples of 62), the y-chunk seams and
+    blocks of 8 x 8 cells (k_cart2d_cells).  Sampled at the mesh edges, the wave-column seams (multiples of 62), the y-chunk seams and
     random interior nodes; oracle on the sub-mesh of the cells around them."""
     import torch
     import bench
