@@ -489,26 +489,35 @@ namespace pfm
       // register (sub-dword transfers to LDS would still occupy one dword per lane) and is stored at the end of the
       // step.  Wave 3: value offset (64-bit: 98 dwords) and neighbour mask of the 49 rows.
       unsigned pf = 0u; // flag byte in flight
-      auto dma_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+      bool pf_ok = false;
+      // node id of the lane's halo dword in plane kz (role < 3) -- SEPARATE from the requests: cart_local_id may look the id up
+      // in the lattice table (a load inside a branch, which the compiler waits for at the join with vmcnt(0)); with the
+      // transfers of the same step already in flight that wait made them synchronous (round 4: ids of the plane AND of
+      // the rows first, then all requests)
+      auto plane_node = [&](int kz, bool &ok, bool &inside, int &dw) __attribute__((always_inline)) -> unsigned {
+        int lq = lane;
+        asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
+        dw = 64 * role + lq;
+        const int hn = dw >> 1;
+        const int gi = i0 - 1 + hn % PH, gj = j0 - 1 + hn / PH;
+        inside = dw < 2 * NPH;
+        ok = role < 3 && inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
+        return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
+      };
+      auto dma_plane_at = [&](unsigned n, bool ok, bool inside, int dw, int buf) __attribute__((always_inline)) {
         if (role < 3)
           {
-            int lq = lane;
-            asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
-            const int dw = 64 * role + lq, hn = dw >> 1;
-            const int gi = i0 - 1 + hn % PH, gj = j0 - 1 + hn / PH;
-            const bool inside = dw < 2 * NPH;
-            const bool ok = inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
-            const unsigned n = ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
             const unsigned boff = 8u * n + 4u * (dw & 1);
             const double *const fld[6] = {v.u[0], v.u[1], v.u[2], v.phi, v.phi_old, v.phi_oldold};
-            pf = 0u;
+            // the flag byte: an unconditional load (n = 0 where there is no node), the validity is applied when it is stored
+            // (flags_put) -- loaded inside the branch below it would be waited for at the join, behind the transfers
+            pf = v.node_flags[n];
+            pf_ok = ok && (dw & 1) == 0;
             if (ok)
               {
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
                   dma_b32(fld[c], boff, reinterpret_cast<uint32_t *>(&s.U[buf][c][0]) + 64 * role);
-                if ((dw & 1) == 0)
-                  pf = v.node_flags[n];
               }
             else if (inside)
               {
@@ -518,20 +527,30 @@ namespace pfm
               }
           }
       };
+      auto dma_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+        bool ok, inside;
+        int dw;
+        const unsigned n = plane_node(kz, ok, inside, dw);
+        dma_plane_at(n, ok, inside, dw, buf);
+      };
       auto flags_put = [&](int kz) __attribute__((always_inline)) {
         const int dw = 64 * role + lane;
         if (role < 3 && (dw & 1) == 0 && dw < 2 * NPH)
-          s.flag[kz & 3][dw >> 1] = (unsigned char)pf;
+          s.flag[kz & 3][dw >> 1] = (unsigned char)(pf_ok ? pf : 0u);
       };
-      auto dma_rows = [&](int kz) __attribute__((always_inline)) {
+      auto rows_node = [&](int kz, bool &ok) __attribute__((always_inline)) -> unsigned {
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
+        const int gi = i0 + lq % PN, gj = j0 + lq / PN;
+        ok = role == 3 && lq < NPN && gi <= cv.o1[0] && gj <= cv.o1[1];
+        return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0xffffffffu;
+      };
+      auto dma_rows_at = [&](unsigned n, bool ok, int kz) __attribute__((always_inline)) {
         const int par = kz & 1;
         if (role == 3)
           {
             int lq = lane;
             asm volatile("" : "+v"(lq));
-            const int gi = i0 + lq % PN, gj = j0 + lq / PN;
-            const bool ok = lq < NPN && gi <= cv.o1[0] && gj <= cv.o1[1];
-            const unsigned n = ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0xffffffffu;
             if (ok)
               dma_b32(cv.nbr_mask, 4u * n, &s.deg[par][0]);
             else if (lq < NPN)
@@ -548,6 +567,11 @@ namespace pfm
                   dst[dw] = 0xffffffffu; // off = -1: not an owned node
               }
           }
+      };
+      auto dma_rows = [&](int kz) __attribute__((always_inline)) {
+        bool ok;
+        const unsigned n = rows_node(kz, ok);
+        dma_rows_at(n, ok, kz);
       };
 
       // every push accumulates: staged rows start at zero and the copy-out clears what it has streamed out
@@ -759,8 +783,13 @@ namespace pfm
           // next step's plane and row info: loads issued ahead of the copy-out stores, consumed after them
           if (ck + 1 < kB)
             {
-              dma_plane(ck + 2, lo); // slot lo (plane ck) is dead once the entries of layer ck are done
-              dma_rows(ck + 1);
+              // ids first (possible table look-ups and their waits), then every request of the step
+              bool okp, inp, okr;
+              int dwp;
+              const unsigned np_ = plane_node(ck + 2, okp, inp, dwp);
+              const unsigned nr_ = rows_node(ck + 1, okr);
+              dma_plane_at(np_, okp, inp, dwp, lo); // slot lo (plane ck) is dead once the entries of layer ck are done
+              dma_rows_at(nr_, okr, ck + 1);
             }
           stamp(10);
 

@@ -1,12 +1,19 @@
 // glue/cracks_gpu_assemble.cc — the deal.II / Trilinos side of the drop-in: what a maintainer of tjhei/cracks adds to
 // cracks.cc so that assemble_system() / assemble_nl_residual() run through include/pfm_assemble.h.
 //
-//   STATUS: UNTESTED AND NEVER COMPILED.  deal.II, Trilinos and p4est do not exist in the image this repository is
-//   built in (cracks.cc needs deal.II >= 9.5 with Trilinos + p4est, CMakeLists.txt:14-36), so this file is compiled
-//   only when PFM_WITH_DEALII is defined and nothing in tests/ builds it.  Everything it CALLS is compiled and tested:
-//   tests/cpp/abi_driver.cpp drives the same sequence (create -> bind -> comm -> state -> halo -> assemble) from C++
-//   on the GPU, with 1 rank everywhere and with 2 forked ranks wherever two GPUs are visible.  Statements about
-//   deal.II / Epetra behaviour that could not be checked here are marked "deal.II-knowledge".
+//   STATUS (round 4): COMPILED AND RUN AGAINST A MOCK, NEVER AGAINST deal.II.  deal.II, Trilinos and p4est do not exist in
+//   the image this repository is built in (cracks.cc needs deal.II >= 9.5 with Trilinos + p4est, CMakeLists.txt:14-36).
+//   tests/cpp/mock_dealii/ declares just the types this file touches (test scaffolding, not deal.II);
+//   tests/cpp/glue_driver.cpp builds a Problem from a mesh on disk and calls rebuild() + assemble(); tests/test_glue_mock.py
+//   compiles it on every CPU run and, on the GPU, compares every matrix entry and both residuals with the oracle for 2-D /
+//   3-D hanging-node meshes, the slit mesh and both dof layouts, with the mock's vertex numbering a random permutation of
+//   the mesh's (1 rank).  The library calls are additionally driven by tests/cpp/abi_driver.cpp (1 rank, and 2 forked
+//   ranks over RCCL wherever two GPUs are visible).
+//   What no test here can check is whether REAL deal.II / Epetra behave as this file assumes.  The three assumptions are
+//   isolated in one function each and marked "deal.II-knowledge -- verify on a real install":
+//     (A) global_dof_of():               the dof numbering of FESystem(FE_Q(1)^(dim+1)) without / with component_wise
+//     (B) local_column_of_global_dof():   block-local index <-> vertex rank of the 2x2 block matrices
+//     (C) gather_owned()/scatter_owned(): the owned part of a Trilinos vector is contiguous in ascending global index
 //
 // How to use: add  #include "glue/cracks_gpu_assemble.cc"  behind the class definition in cracks.cc, add the members of
 // PfmGlue<dim> (one object `pfm_glue`) to FracturePhaseFieldProblem<dim>, call pfm_glue.rebuild(*this) at the end of
@@ -87,6 +94,7 @@ namespace pfm_glue_detail
     int64_t nnz[4] = {0, 0, 0, 0};
     std::vector<double> h_vec[3], h_res[2];
     std::vector<uint8_t> flags;
+    bool state_complete = false; // all three vectors have been scattered into this context once
 
     ~PfmGlue()
     {
@@ -126,6 +134,7 @@ namespace pfm_glue_detail
     void rebuild(Problem &P)
     {
       release();
+      state_complete = false;
       const auto &dh = P.dof_handler;
       const auto &fe = dh.get_fe();
       const MPI_Comm mpi = P.mpi_com;
@@ -334,6 +343,9 @@ namespace pfm_glue_detail
     }
 
     // library column id (within block (r, c)'s column space) of a global dof
+    // deal.II-knowledge (B) -- verify on a real install: for every locally relevant vertex compare
+    //   cell->vertex_dof_index(v, comp) with the value this function inverts, e.g. in rebuild():
+    //   Assert(local_column_of_global_dof(P, 0, comp < dim ? 0 : 1, block-local index of that dof) == node * dim + comp (or node))
     template <class Problem>
     int32_t local_column_of_global_dof(const Problem &P, unsigned int /*r*/, unsigned int c, gidx g_in_block) const
     {
@@ -388,8 +400,11 @@ namespace pfm_glue_detail
 
     // ---------------------------------------------------------------------------------------------------------
     // body of assemble_system(bool residual_only), cracks.cc:2129-2475
+    // only_solution_changed: the line search (cracks.cc:2942-2957) and every Newton iteration after the first of a time
+    // step call assemble with old_solution / old_old_solution untouched; pass true there and only `solution` is copied
+    // and scattered again (pfm_state_set_solution: a third of the traffic)
     template <class Problem>
-    void assemble(Problem &P, const bool residual_only)
+    void assemble(Problem &P, const bool residual_only, const bool only_solution_changed = false)
     {
       // scalars
       pfm_params p{};
@@ -429,13 +444,18 @@ namespace pfm_glue_detail
       // row-map order = ascending global index = the library's owned order; deal.II-knowledge)
       const TrilinosWrappers::MPI::BlockVector *vec[3] = {&P.solution, &P.old_solution, &P.old_old_solution};
       const size_t nd = (size_t)n_owned * (dim + 1);
-      for (int k = 0; k < 3; ++k)
+      const bool sol_only = only_solution_changed && state_complete;
+      for (int k = 0; k < (sol_only ? 1 : 3); ++k)
         {
           gather_owned(*vec[k], h_vec[k]);
           AssertThrow(hipMemcpy(d_vec[k], h_vec[k].data(), sizeof(double) * nd, hipMemcpyHostToDevice) == hipSuccess, ExcMessage("H2D"));
         }
       // ghost import (cracks.cc:2147-2154) + cell work; every rank calls the exchange (it is collective among peers)
-      PFM_CALL(ctx, pfm_state_set(ctx, d_vec[0], d_vec[1], d_vec[2], /*on_device=*/1));
+      if (sol_only)
+        PFM_CALL(ctx, pfm_state_set_solution(ctx, d_vec[0], /*on_device=*/1));
+      else
+        PFM_CALL(ctx, pfm_state_set(ctx, d_vec[0], d_vec[1], d_vec[2], /*on_device=*/1));
+      state_complete = true;
       if (comm)
         PFM_CALL(ctx, pfm_halo_exchange(ctx, comm, peer_ranks.data()));
       PFM_CALL(ctx, pfm_assemble_device(ctx, residual_only ? 1 : 0, d_val, d_res[0], d_res[1]));
@@ -473,6 +493,11 @@ namespace pfm_glue_detail
     }
 
     // global dof of (local node, component)
+    // deal.II-knowledge (A) -- verify on a real install: loop over the cells, for every vertex v and component comp
+    //   Assert(global_dof_of(P, node_of_phi_dof.at(cell->vertex_dof_index(v, dim)), comp) == cell->vertex_dof_index(v, comp)).
+    // It holds if (i) the dim + 1 dofs of a vertex are numbered consecutively by DoFHandler::distribute_dofs for an
+    // FESystem of dim + 1 Q1 elements, and (ii) DoFRenumbering::component_wise with the blocks {u..u, phi}
+    // (cracks.cc:1587-1590) keeps the vertex order within each block.
     template <class Problem>
     gidx global_dof_of(const Problem &P, int32_t n, unsigned int comp) const
     {
@@ -485,6 +510,8 @@ namespace pfm_glue_detail
     }
 
     // owned dofs of a block vector -> the context's layout
+    // deal.II-knowledge (C) -- verify on a real install: for i in [0, locally_owned_size)
+    //   Assert(v.block(b).locally_owned_elements().nth_index_in_set(i) is ascending and *(v.block(b).begin() + i) == v.block(b)[that index])
     void gather_owned(const TrilinosWrappers::MPI::BlockVector &v, std::vector<double> &out) const
     {
       if (blocked)

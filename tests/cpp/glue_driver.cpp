@@ -186,6 +186,7 @@ static int run(const std::string &dir, std::istringstream &meta)
     write_bin(dir + "/" + name, x.data(), x.size());
   };
   glue.assemble(P, /*residual_only=*/true);
+  glue.assemble(P, /*residual_only=*/true, /*only_solution_changed=*/true); // the line-search form: same state, same result
   dump(P.system_pde_residual, "out_res_pde_ro.bin");
   dump(P.system_total_residual, "out_res_tot_ro.bin");
   glue.assemble(P, /*residual_only=*/false);

@@ -1,0 +1,181 @@
+"""glue/cracks_gpu_assemble.cc (the deal.II / Trilinos side of the drop-in) through a compiler and on the
+GPU.  deal.II does not exist in this image; tests/cpp/mock_dealii/ declares just the types the glue touches (TEST
+SCAFFOLDING for our own file -- not deal.II, not the reference compiled) and tests/cpp/glue_driver.cpp builds a
+`Problem` with the ~30 members the glue reads from a mesh this test writes to disk, calls PfmGlue::rebuild() and
+PfmGlue::assemble(residual_only) and hands back what the glue left in the "Trilinos" objects.
+
+The vertex numbering of the mock is a random permutation of the mesh's, so that every index map of the glue (phase-field
+dof -> local node, Epetra column -> library column, owned vectors in row-map order) is exercised; the comparison is with the
+CPU oracle, every matrix entry and both residuals, at the tolerance of the other parity tests."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cases
+import oracle_api as O
+from cracks_amd import build
+from cracks_amd import mesh as M
+from gpu_util import linf_scaled
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "glue_driver.cpp")
+GLUE = os.path.join(ROOT, "glue", "cracks_gpu_assemble.cc")
+MOCK = os.path.join(ROOT, "tests", "cpp", "mock_dealii")
+EXE = os.path.join(ROOT, "tests", "cpp", "glue_driver")
+TOL = 1e-12
+
+
+def build_glue_driver(force=False):
+    lib = build.build_native()
+    deps = [SRC, GLUE, lib, os.path.join(MOCK, "mock_dealii.h")]
+    if not force and os.path.exists(EXE) and os.path.getmtime(EXE) > max(os.path.getmtime(d) for d in deps):
+        return EXE
+    libdir = os.path.dirname(lib)
+    cmd = [build.hipcc(), "-std=c++17", "-O1", "-Wall", "-Wno-unused-function", SRC, "-I" + MOCK, "-I" + os.path.join(ROOT, "include"),
+           "-L" + libdir, "-lpfm_hip", "-Wl,-rpath," + libdir, "-o", EXE]
+    subprocess.check_call(cmd)
+    return EXE
+
+
+def test_glue_compiles_against_the_mock_headers():
+    """The glue has been through a compiler: every type error and typo in it fails here (CPU, no GPU needed)."""
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    exe = build_glue_driver(force=True)
+    assert os.path.exists(exe)
+    text = open(GLUE).read()
+    assert "PFM_WITH_DEALII" in text and "pfm_internal.h" not in text
+
+
+def _mock_dof(layout, rank, comp):
+    """The numbering the glue assumes of deal.II (glue_driver.cpp: dof_of)."""
+    rank = np.asarray(rank)
+    comp = np.asarray(comp)
+    if not layout.blocked:
+        return (layout.dim + 1) * rank + comp
+    return np.where(comp < layout.dim, layout.dim * rank + comp, layout.n_u + rank)
+
+
+def _write_problem(c, d, seed):
+    mesh, lay = c.mesh, c.layout
+    dim, N = mesh.dim, mesh.n_nodes
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(N).astype(np.int64)  # node -> vertex rank of the mock
+    node_of_rank = np.argsort(perm)
+    # dof map: layout dof -> mock dof
+    node, comp = lay.node_comp_of_dof()
+    to_mock = _mock_dof(lay, perm[node], comp).astype(np.int64)
+    perm[mesh.cells].astype(np.int32).tofile(os.path.join(d, "cells.bin"))
+    np.ascontiguousarray(mesh.coords[node_of_rank]).astype(np.float64).tofile(os.path.join(d, "coords.bin"))
+    # closed hanging-node lines at node level, from the phase-field lines of constraints_hanging_nodes
+    hl = c.ch.lines()
+    hn, hp, hw, ptr = [], [], [], [0]
+    for n in range(N):
+        g = int(lay.dof(n, dim))
+        if g in hl:
+            hn.append(perm[n])
+            for col, w in hl[g]:
+                hp.append(perm[node[col]])
+                hw.append(w)
+            ptr.append(len(hp))
+    if hn:
+        np.array(hn, np.int32).tofile(os.path.join(d, "hn_nodes.bin"))
+        np.array(hp, np.int32).tofile(os.path.join(d, "hn_parents.bin"))
+        np.array(hw, np.float64).tofile(os.path.join(d, "hn_w.bin"))
+        np.array(ptr, np.int64).tofile(os.path.join(d, "hn_ptr.bin"))
+    # homogeneous lines of constraints_update (not the hanging-node lines), one flag byte per vertex rank
+    fl = np.zeros(N, np.uint8)
+    upd = c.cu.flag.astype(bool) & ~c.ch.flag.astype(bool)
+    for g in np.nonzero(upd)[0]:
+        fl[perm[node[g]]] |= np.uint8(1 << comp[g])
+    fl.tofile(os.path.join(d, "con_update.bin"))
+    for name, x in (("sol", c.sol), ("old", c.old), ("oldold", c.oldold)):
+        y = np.empty_like(x)
+        y[to_mock] = x
+        y.tofile(os.path.join(d, name + ".bin"))
+    # the pattern in the mock's numbering, per block, columns ascending (a filled Epetra matrix)
+    rp, ci = M.dof_sparsity(mesh, lay)
+    rows = np.repeat(np.arange(lay.n_dofs), np.diff(rp))
+    P = sp.csr_matrix((np.ones(ci.size), (to_mock[rows], to_mock[ci])), shape=(lay.n_dofs,) * 2)
+    P.sort_indices()
+    blocks = {}
+    if lay.blocked:
+        nu = lay.n_u
+        for r, (r0, r1) in enumerate(((0, nu), (nu, lay.n_dofs))):
+            for cc, (c0, c1) in enumerate(((0, nu), (nu, lay.n_dofs))):
+                B = P[r0:r1, c0:c1].tocsr()
+                B.sort_indices()
+                blocks[2 * r + cc] = B
+    else:
+        blocks[0] = P
+    for b, B in blocks.items():
+        B.indptr.astype(np.int32).tofile(os.path.join(d, f"rowptr{b}.bin"))
+        B.indices.astype(np.int32).tofile(os.path.join(d, f"colind{b}.bin"))
+    p = c.params
+    meta = [dim, int(lay.blocked), N, mesh.n_cells, len(hn), int(p.outer_solver)]  # 0 = active set, 1 = simple monolithic (include/pfm_params.h)
+    vals = [p.lambda_, p.mu, p.G_c, p.alpha_eps, p.constant_k, p.pressure, p.alpha_biot, p.gamma_penal, p.timestep, p.time,
+            p.old_timestep, p.old_old_timestep, p.decompose_stress_rhs, p.decompose_stress_matrix]
+    with open(os.path.join(d, "meta.txt"), "w") as f:
+        f.write(" ".join(str(x) for x in meta) + "\n" + " ".join(repr(float(x)) for x in vals) + "\n")
+        f.write(f"{int(p.timestep_number)} {int(p.use_old_timestep_pf)}\n")
+    return to_mock, blocks
+
+
+def _read_matrix(d, lay, blocks):
+    mats = {b: sp.csr_matrix((np.fromfile(os.path.join(d, f"out_val{b}.bin")), B.indices, B.indptr), shape=B.shape) for b, B in blocks.items()}
+    if not lay.blocked:
+        return mats[0]
+    return sp.bmat([[mats[0], mats[1]], [mats[2], mats[3]]], format="csr")
+
+
+CASES = [
+    ("sneddon_2d_hanging_blocked", lambda: cases.perturbed(cases.kat_sneddon_2d())),
+    ("sneddon_3d_blocked", lambda: cases.perturbed(cases.kat_sneddon_3d(5))),
+    ("miehe_slit_interleaved", lambda: cases.perturbed(cases.kat_miehe_shear_1())),
+    ("hetero_3d_hanging_blocked", None),  # built below: homogeneous material on the 3-D mesh with hanging nodes
+]
+
+
+def _case(name, maker):
+    if maker is not None:
+        return maker()
+    c = cases.perturbed(cases.kat_hetero_3d())
+    c.cell_lambda = c.cell_mu = None  # the driver's Problem is not a multiple_het run
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,maker", CASES, ids=[c[0] for c in CASES])
+def test_glue_rebuild_and_assemble_match_the_oracle(name, maker, tmp_path):
+    exe = build_glue_driver()
+    c = _case(name, maker)
+    d = str(tmp_path)
+    to_mock, blocks = _write_problem(c, d, seed=7)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, d], capture_output=True, text=True, timeout=600, env=env)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "glue_driver: OK" in r.stdout, r.stdout + r.stderr
+    mesh, lay = c.mesh, c.layout
+    rp, ci = M.dof_sparsity(mesh, lay)
+    # residual-only call
+    ro = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, True, rp, ci)
+    assert ro.err == 0
+    res_pde = np.fromfile(os.path.join(d, "out_res_pde_ro.bin"))[to_mock]
+    res_tot = np.fromfile(os.path.join(d, "out_res_tot_ro.bin"))[to_mock]
+    assert linf_scaled(res_pde, ro.residual_pde) < TOL and linf_scaled(res_tot, ro.residual_total) < TOL
+    # full call: every matrix entry (constrained rows included) and the residual
+    rf = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, False, rp, ci)
+    assert rf.err == 0
+    A_ref = sp.csr_matrix((rf.values, ci, rp), shape=(lay.n_dofs,) * 2)
+    A_mock = _read_matrix(d, lay, blocks).tocsr()
+    assert np.isfinite(A_mock.data).all() and np.abs(A_mock.data).max() < 1e70  # every value was overwritten (-7e77 marker)
+    A = A_mock[to_mock][:, to_mock].tocsr()  # back to the layout's numbering
+    A.sort_indices()
+    A_ref.sort_indices()
+    assert (A.indptr == A_ref.indptr).all() and (A.indices == A_ref.indices).all()
+    assert linf_scaled(A.data, A_ref.data) < TOL
+    assert linf_scaled(np.fromfile(os.path.join(d, "out_res_pde.bin"))[to_mock], rf.residual_pde) < TOL
