@@ -19,7 +19,7 @@ rank ``r = ix + p0*(iy + p1*iz)``.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import math
 
@@ -254,8 +254,45 @@ def morton_cell_ranks(mesh: Mesh, world: int) -> np.ndarray:
     return rank
 
 
-def partition_general(mesh: Mesh, world: int, cell_rank: Optional[np.ndarray] = None) -> List[LocalProblem]:
+def hanging_closure_shipments(mesh: Mesh, cell_rank: np.ndarray, owner: np.ndarray) -> Dict[int, np.ndarray]:
+    """The cells each rank must RECEIVE so that owner-computes is complete on a host whose ghost layer is deal.II's.
+
+    deal.II's ghost layer holds the cells that share a vertex with a locally owned cell.  A cell K that reaches an owned
+    row only through a HANGING vertex -- ``distribute_local_to_global`` moves K's contributions at the hanging vertex to
+    its parents' rows (cracks.cc:2440-2447) -- need not be in it: K has the hanging vertex and one end of the coarse edge
+    as vertices, the owned parent may be the other end.  The reference repairs this after the fact with
+    ``compress(add)`` (cracks.cc:2470-2475).  Here the OWNER of such a cell ships it instead: rank s = cell_rank[K]
+    looks at the constraint lines of K's hanging vertices (locally relevant on s) and sends K -- its vertices, their
+    coordinates and constraint lines -- to every rank r != s that owns one of the parents (glue/cracks_gpu_assemble.cc:
+    ship_hanging_closure_cells; one some_to_some per setup_system).  The receiver adds the cells it does not have yet to
+    its local mesh, their vertices become ghost nodes like any other.  Returns {receiver rank: global cell ids}; the lists
+    are what the owners send, duplicates of cells the receiver already holds included."""
+    import scipy.sparse as sp
+
+    N, nc_cells, nv = mesh.n_nodes, mesh.n_cells, mesh.nv
+    out: Dict[int, List[int]] = {}
+    if not mesh.hn_nodes.size:
+        return {}
+    C0 = sp.csr_matrix((np.ones(nc_cells * nv, np.int32), (np.repeat(np.arange(nc_cells), nv), mesh.cells.ravel())), shape=(nc_cells, N))
+    H = sp.csr_matrix((np.ones(mesh.hn_parents.size, np.int32), (np.repeat(mesh.hn_nodes, np.diff(mesh.hn_ptr)), mesh.hn_parents)),
+                      shape=(N, N))
+    CP = (C0 @ H).tocsr()  # cell -> parents of its hanging vertices
+    for k in range(nc_cells):
+        par = CP.indices[CP.indptr[k]:CP.indptr[k + 1]]
+        for r in np.unique(owner[par]):
+            if int(r) != int(cell_rank[k]):
+                out.setdefault(int(r), []).append(k)
+    return {r: np.asarray(sorted(set(v)), np.int64) for r, v in out.items()}
+
+
+def partition_general(mesh: Mesh, world: int, cell_rank: Optional[np.ndarray] = None, ghost_layer: str = "closure") -> List[LocalProblem]:
     """Owner-computes partition of an arbitrary Q1 mesh (hanging nodes allowed) into ``world`` rank-local problems.
+
+    ``ghost_layer``: which cells a rank holds besides its own --
+      "closure" (default): exactly the cells that contribute to an owned row (below);
+      "dealii": the cells sharing a vertex with a locally owned cell, i.e. what a deal.II / p4est host has -- NOT closed
+        under hanging nodes (``hanging_closure_shipments``): a model of the hole, for tests;
+      "dealii+shipped": that layer plus the cells their owners ship (what glue/cracks_gpu_assemble.cc hands to the library).
 
     * a node belongs to the lowest rank owning a cell that has it as a vertex (deal.II's rule for dofs);
     * a rank's local cells are all cells that contribute to a row it owns: cells with an owned vertex, and cells
@@ -282,10 +319,23 @@ def partition_general(mesh: Mesh, world: int, cell_rank: Optional[np.ndarray] = 
     assert (owner < world).all(), "node without a cell"
     hn_index = np.full(N, -1, np.int64)
     hn_index[mesh.hn_nodes] = np.arange(mesh.hn_nodes.size)
+    if ghost_layer not in ("closure", "dealii", "dealii+shipped"):
+        raise ValueError(ghost_layer)
+    shipped = hanging_closure_shipments(mesh, cell_rank, owner) if ghost_layer == "dealii+shipped" else {}
+    C0 = sp.csr_matrix((np.ones(nc_cells * nv, np.int32), (np.repeat(np.arange(nc_cells), nv), mesh.cells.ravel())), shape=(nc_cells, N))
     parts = []
     for r in range(world):
         owned_mask = owner == r
-        lc = np.nonzero(C @ owned_mask.astype(np.int32) > 0)[0]
+        if ghost_layer == "closure":
+            lc = np.nonzero(C @ owned_mask.astype(np.int32) > 0)[0]
+        else:
+            mine = cell_rank == r
+            vmine = np.zeros(N, np.int32)
+            vmine[mesh.cells[mine].ravel()] = 1
+            keep = (C0 @ vmine > 0) | mine
+            if r in shipped:
+                keep[shipped[r]] = True
+            lc = np.nonzero(keep)[0]
         reach = np.zeros(N, bool)
         sub = C[lc]
         reach[sub.indices] = True

@@ -131,8 +131,10 @@ def test_owned_rows_match_single_rank(dim, n, world, path):
                     assert max(abs(got[k] - want[k]) for k in want) < 1e-12 * scale
 
 
-@pytest.mark.parametrize("kind,world", [("slit2d", 4), ("slit2d", 3), ("box3d", 2)])
-def test_general_partition_owned_rows_match_single_rank(kind, world):
+@pytest.mark.parametrize("kind,world,ghost_layer", [("slit2d", 4, "closure"), ("slit2d", 3, "closure"), ("box3d", 2, "closure"),
+                                                   ("slit2d", 4, "dealii+shipped"), ("slit2d", 2, "dealii+shipped"),
+                                                   ("box3d", 3, "dealii+shipped"), ("box3d", 4, "dealii+shipped")])
+def test_general_partition_owned_rows_match_single_rank(kind, world, ghost_layer):
     """BASELINE config 'Miehe shear with AMR on 4 GPUs': general partition (hanging nodes, slit), general kernel
     family, stress split active in 2-D; every rank's context on cuda:0, ghost import through the HIP pack/unpack."""
     import torch
@@ -180,7 +182,9 @@ def test_general_partition_owned_rows_match_single_rank(kind, world):
     ref_res = ref.system_pde_residual.cpu().numpy()
     ref_pat = [ref.ctx.pattern(b) for b in range(4)]
 
-    lps = P.partition_general(g, world)
+    # "dealii+shipped": the cell set a deal.II host hands over (its one-cell ghost layer + the cells that reach an owned
+    # row through a hanging vertex, shipped by their owners: partition.hanging_closure_shipments, the glue)
+    lps = P.partition_general(g, world, ghost_layer=ghost_layer)
     asms = []
     for lp in lps:
         a = Assembler(lp.mesh, blocked=True, n_owned_nodes=lp.n_owned)

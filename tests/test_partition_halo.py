@@ -164,6 +164,36 @@ def test_general_partition_structure_and_owned_rows(kind, world):
         _owned_rows_match(lp, g, f, base.params, dirichlet)
 
 
+@pytest.mark.parametrize("kind,world", [("slit2d", 2), ("slit2d", 3), ("slit2d", 4), ("box3d", 3), ("box3d", 4)])
+def test_dealii_ghost_layer_is_not_closed_under_hanging_nodes_and_shipping_closes_it(kind, world):
+    """cracks.cc:2470-2475: the reference repairs rows that received contributions on another rank with compress(add).
+    Owner-computes has no such step, so every cell that reaches an owned row -- also through a hanging vertex whose parent
+    is owned -- must be local.  deal.II's one-cell ghost layer (cells sharing a vertex with an owned cell) does not
+    guarantee that: on these partitions some rank misses such cells and its rows come out wrong; with the cells their
+    owners ship (partition.hanging_closure_shipments, what the glue does) every owned row equals the single-rank row."""
+    g = amr_mesh(kind)
+    dim = g.dim
+    cr = P.morton_cell_ranks(g, world)
+    closed = P.partition_general(g, world, cr)
+    layer = P.partition_general(g, world, cr, ghost_layer="dealii")
+    shipped = P.partition_general(g, world, cr, ghost_layer="dealii+shipped")
+    missing = [set(a.global_cells) - set(b.global_cells) for a, b in zip(closed, layer)]
+    assert any(missing), "this partition does not exercise the hole"
+    f = _amr_fields(g, dim)
+    base = cases.kat_sneddon_3d(4) if dim == 3 else cases.kat_miehe_shear_1()
+    dirichlet = M.sneddon_dirichlet_dofs if dim == 3 else M.miehe_shear_dirichlet_dofs
+    # the hole is real: a rank that misses a cell assembles a wrong owned row (or lacks a column of it)
+    bad = [r for r in range(world) if missing[r]]
+    with pytest.raises(AssertionError):
+        _owned_rows_match(layer[bad[0]], g, f, base.params, dirichlet)
+    for r, lp in enumerate(shipped):
+        assert set(closed[r].global_cells) <= set(lp.global_cells)
+        assert lp.n_owned == closed[r].n_owned and (lp.global_ids[:lp.n_owned] == closed[r].global_ids[:lp.n_owned]).all()
+        ghosts = set(range(lp.n_owned, lp.mesh.n_nodes))
+        assert set(int(k) for k in lp.recv_nodes) == ghosts
+        _owned_rows_match(lp, g, f, base.params, dirichlet)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -172,7 +202,7 @@ def _free_port():
     return port
 
 
-def _worker_amr(rank, world, port, kind, q):
+def _worker_amr(rank, world, port, kind, q, ghost_layer="closure"):
     """Ghost import over gloo on a general partition (hanging nodes), then the owner-computes check."""
     import torch
     import torch.distributed as dist
@@ -185,7 +215,7 @@ def _worker_amr(rank, world, port, kind, q):
     try:
         g = amr_mesh(kind)
         dim = g.dim
-        lp = P.partition_general(g, world)[rank]
+        lp = P.partition_general(g, world, ghost_layer=ghost_layer)[rank]
         rec = dim + 3
         f = _amr_fields(g, dim)
         state = np.full((lp.mesh.n_nodes, rec), np.nan)
@@ -299,13 +329,14 @@ def test_world2_gloo_halo_and_owner_computes(dim, n):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
-def test_world2_gloo_general_partition_with_hanging_nodes():
+@pytest.mark.parametrize("ghost_layer", ["closure", "dealii+shipped"])
+def test_world2_gloo_general_partition_with_hanging_nodes(ghost_layer):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_amr, args=(r, 2, port, "slit2d", q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_amr, args=(r, 2, port, "slit2d", q, ghost_layer)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
