@@ -469,10 +469,25 @@ def main():
     k_ms, k_n = asm.ctx.kernel_time_ms()
     asm.ctx.timing_enable(False)
 
-    tt = torch.tensor([elapsed, k_ms, k_med], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+    # the ghost import alone (cracks.cc:2147-2154 as pack -> RCCL group -> unpack): events around halo.exchange, median of 20
+    exchange_ms = 0.0
+    if world > 1 and halo is not None:
+        xs = []
+        for _ in range(3):
+            halo.exchange(asm.ctx)
+        fence()
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            halo.exchange(asm.ctx)
+            e1.record()
+            e1.synchronize()
+            xs.append(e0.elapsed_time(e1))
+        exchange_ms = float(np.median(xs))
+    tt = torch.tensor([elapsed, k_ms, k_med, exchange_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, k_ms, k_med = float(tt[0]), float(tt[1]), float(tt[2])
+    elapsed, k_ms, k_med, exchange_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
     checksum = None
     if args.checksum:
         # sums over the owned rows: every global row is owned by exactly one rank
@@ -490,6 +505,53 @@ def main():
     n_cells_global = int(np.prod(ncell))
     n_dofs = n_nodes_global * (dim + 1)
     ms_per_step = 1e3 * elapsed / args.steps
+
+    # The headline cut is z-slabs (2 peers, whole x-y tiles); a deal.II host hands over p4est's Morton sub-cubes (up to 7
+    # peers, partial tiles).  The same steps on the near-cubic grid, in the same run, so that the SCALE record shows both.
+    cubic = None
+    p_cubic = P.factor_ranks(world, dim)
+    if world > 1 and dim == 3 and tuple(p_cubic) != tuple(p) and not args.no_extras and not residual_only:
+        asm.ctx.close()
+        del asm
+        if halo is not None:
+            halo.close()
+        torch.cuda.empty_cache()
+        lp2 = P.build_local_problem(dim, ncell, p_cubic, rank)
+        u2, phi2, po2, poo2, flags2 = synthetic_state(lp2.mesh, lp2.global_ids, h, dim)
+        halo2 = HaloExchange(dim, lp2.peers, lp2.send_ptr, lp2.send_nodes, lp2.recv_ptr, lp2.recv_nodes, dev)
+        asm2 = Assembler(lp2.mesh, blocked=True, device=local_rank, n_owned_nodes=lp2.n_owned, halo=halo2)
+        asm2.set_params(sneddon_params(h, dim))
+        asm2.set_constraints(flags2)
+        no2 = lp2.n_owned
+
+        def pack2(uu, pp):
+            v = np.empty(no2 * (dim + 1))
+            v[:no2 * dim] = uu[:no2].reshape(-1)
+            v[no2 * dim:] = pp[:no2]
+            return v
+        asm2.set_vectors(pack2(u2, phi2), pack2(np.zeros_like(u2), po2), pack2(np.zeros_like(u2), poo2))
+        for _ in range(args.warmup):
+            asm2.assemble_system(False)
+        asm2.synchronize()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            asm2.assemble_system(False)
+        fence()
+        el2 = time.perf_counter() - t2
+        xs = []
+        for _ in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            halo2.exchange(asm2.ctx)
+            e1.record()
+            e1.synchronize()
+            xs.append(e0.elapsed_time(e1))
+        t3 = torch.tensor([el2, float(np.median(xs)), float(len(lp2.peers))], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        cubic = {"partition": "x".join(str(k) for k in p_cubic), "ms_per_step": 1e3 * float(t3[0]) / args.steps,
+                 "value": n_dofs / (float(t3[0]) / args.steps), "exchange_ms": float(t3[1]), "max_peers": int(t3[2])}
+        asm = asm2
 
     if rank == 0:
         abytes = algorithmic_bytes_per_cell(dim, residual_only) * lp.mesh.n_cells  # this rank's launch
@@ -521,7 +583,7 @@ def main():
                     (" -- SMOKE RUN: all ranks on one GPU, gloo, not a measurement" if smoke_gloo else ""),
             "config": {"workload": f"Sneddon {dim}D, {n}^{dim} = {n_cells_global} Q1 cells, {n_dofs} DoFs, "
                                    f"{'residual-only' if residual_only else 'full Jacobian+residual, 2x2 block CSR (%d nnz/row-node-comp)' % (4 * 3 ** dim)}",
-                       "partition": "x".join(str(k) for k in p), "kernel_path": asm.ctx.kernel_path,
+                       "partition": "x".join(str(k) for k in p), "peers": len(lp.peers), "kernel_path": asm.ctx.kernel_path,
                        "state_scatter": "solution_only" if residual_only else "all three vectors, every step",
                        "setup_s": round(t_setup, 2),  # mesh + synthetic state in numpy + context
                        # pfm_ctx_create alone: what a setup_system() after refine_mesh costs (cracks.cc:4148)
@@ -534,6 +596,10 @@ def main():
                          "kernel_ms": k_ms, "kernel_ms_median": k_med, "launches": k_n,
                          "algorithmic_bytes_per_cell": algorithmic_bytes_per_cell(dim, residual_only)},
         }
+        if world > 1:
+            out["exchange_ms"] = exchange_ms  # the ghost import alone, max over ranks of the per-rank median
+        if cubic is not None:
+            out["cubic_partition"] = cubic
         if checksum is not None:
             out["checksum"] = checksum
         if world == 1 and not smoke_gloo and not args.no_extras and dim == 3 and not residual_only and args.path == "auto":

@@ -46,6 +46,22 @@ def test_cpp_host_create_halo_assemble(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [4, 8])
+def test_cpp_host_more_ranks_over_rccl(ranks):
+    """The ring exchange of the C++ host with 4 and 8 forked ranks (one GPU each) wherever the box has them."""
+    import torch
+
+    if torch.cuda.device_count() < ranks:
+        pytest.skip(f"needs >= {ranks} GPUs")
+    exe = build_driver()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "13", "9", "10", "--ranks", str(ranks)], capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"abi_driver: OK ({ranks} ranks)" in r.stdout
+
+
+@pytest.mark.gpu
 def test_cpp_host_two_ranks_over_rccl():
     """Two forked ranks, one GPU each, RCCL id over a pipe, ring exchange of the ghost planes through
     pfm_comm_create / pfm_halo_exchange: the first box with >= 2 GPUs that runs `pytest -m gpu` exercises the in-library

@@ -267,6 +267,13 @@ def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra
     many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                 "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world)] + common)
     assert many["n_gpus"] == world and one["n_gpus"] == 1
+    # what the driver's SCALE record needs beside the value: the cut, the measured ghost import, and -- where the headline
+    # cut is z-slabs -- the same steps on the near-cubic grid a p4est host would hand over
+    assert many["config"]["partition"] and many["config"]["peers"] >= 1 and many["exchange_ms"] > 0.0
+    if world == 2 and not extra:
+        assert many["config"]["partition"] == "1x1x2"
+        cp = many["cubic_partition"]
+        assert cp["partition"] == "2x1x1" and cp["ms_per_step"] > 0 and cp["exchange_ms"] > 0 and cp["max_peers"] == 1
     a, b = np.array(one["checksum"]), np.array(many["checksum"])
     assert a.shape == b.shape and np.abs(a).max() > 0
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)  # each pair is (sum, sum of absolute values)
@@ -318,6 +325,29 @@ def test_bench_two_gpus_over_rccl():
     two = _bench_json([sys.executable, "bench.py", "--gpus", "2"] + common, env)
     assert two["n_gpus"] == 2
     a, b = np.array(one["checksum"]), np.array(two["checksum"])
+    scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
+    assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
+
+
+@pytest.mark.parametrize("world,grid", [(4, "2,2,1"), (8, "2,2,2"), (8, "1,1,8")])
+def test_bench_more_gpus_over_rccl_subcubes(world, grid):
+    """4 and 8 ranks over real RCCL with p4est-like sub-cube partitions (up to 7 peers per rank: faces, edges, corners in
+    the exchange lists) and with the z-slabs of the headline run; partition-independent sums against the 1-rank ones."""
+    import os
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs >= {world} GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("PFM_BENCH_SMOKE_GLOO", None)
+    common = ["--n", "40", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--checksum"]
+    one = _bench_json([sys.executable, "bench.py", "--gpus", "1"] + common, env)
+    many = _bench_json([sys.executable, "bench.py", "--gpus", str(world)] + common, dict(env, PFM_BENCH_GRID=grid))
+    assert many["n_gpus"] == world and many["config"]["partition"] == grid.replace(",", "x") and many["exchange_ms"] > 0.0
+    a, b = np.array(one["checksum"]), np.array(many["checksum"])
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
     assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
 
