@@ -189,6 +189,12 @@ class Context:
                                                  C.c_void_p(res_pde_ptr), C.c_void_p(res_tot_ptr)),
                     "pfm_assemble_device")
 
+    def assemble_nl_residual_device(self, sol_ptr: int, res_pde_ptr: int, res_tot_ptr: int):
+        """``pfm_assemble_nl_residual_device``: solution := sol, then both residuals (the line-search call, cracks.cc:2942-2957);
+        single-rank contexts only."""
+        self._check(self.lib.pfm_assemble_nl_residual_device(self._h, C.c_void_p(sol_ptr), C.c_void_p(res_pde_ptr), C.c_void_p(res_tot_ptr)),
+                    "pfm_assemble_nl_residual_device")
+
     def assemble_overlapped(self, comm_handle: int, peer_ranks, residual_only: bool, value_ptrs: Sequence[int], res_pde_ptr: int,
                             res_tot_ptr: int):
         """``pfm_assemble_overlapped``: ghost import on the context's side stream next to the interior tiles."""
@@ -337,6 +343,11 @@ class Assembler:
         since the last call (the line search of cracks.cc:2942-2957 and the Newton iterations within a time step):
         old_solution / old_old_solution are not scattered again."""
         self.ctx.set_stream(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        if solution_only and residual_only and self.halo is None:
+            # one library call; on a single-rank box the residual kernel reads `solution` itself (no scatter launch)
+            self.ctx.assemble_nl_residual_device(self.solution.data_ptr(), self.system_pde_residual.data_ptr(),
+                                                 self.system_total_residual.data_ptr())
+            return
         if solution_only:
             self.ctx.state_set_solution_device(self.solution.data_ptr())
         else:

@@ -26,7 +26,7 @@ EXPORTS = [
     "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_wrap", "pfm_comm_destroy", "pfm_comm_aborted", "pfm_halo_exchange", "pfm_assemble_overlapped",
     "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
-    "pfm_assemble_device",
+    "pfm_assemble_device", "pfm_assemble_nl_residual_device",
     "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path", "pfm_ctx_force_phase",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms", "pfm_kernel_times_ms",
     # include/pfm_newton.h
@@ -118,6 +118,7 @@ def load():
     lib.pfm_halo_pack_all.argtypes = [vp, vp]
     lib.pfm_halo_unpack_all.argtypes = [vp, vp]
     lib.pfm_assemble_device.argtypes = [vp, i32, vp, vp, vp]
+    lib.pfm_assemble_nl_residual_device.argtypes = [vp, vp, vp, vp]
     lib.pfm_sync_status.argtypes = [vp]
     lib.pfm_assemble.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     lib.pfm_ctx_kernel_path.argtypes = [vp]

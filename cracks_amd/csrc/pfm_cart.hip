@@ -152,9 +152,23 @@ namespace pfm
         if (node_in && j >= 0 && j < cv.NY)
           {
             const int n = cart_local_id3(cv, i, j, 0);
-            val[0] = v.u[0][n];
-            val[1] = v.u[1][n];
-            val[2] = v.phi[n];
+            if (v.fused_solution) // pfm_assemble_nl_residual_device on a single-rank box (see k_cart_residual3)
+              {
+                const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
+                const double *su = v.fused_solution + (il ? 3LL * n : 2LL * n);
+                val[0] = su[0];
+                val[1] = su[1];
+                val[2] = il ? su[2] : v.fused_solution[2LL * v.n_owned + n];
+                v.u[0][n] = val[0];
+                v.u[1][n] = val[1];
+                v.phi[n] = val[2];
+              }
+            else
+              {
+                val[0] = v.u[0][n];
+                val[1] = v.u[1][n];
+                val[2] = v.phi[n];
+              }
             const double po = v.phi_old[n], poo = v.phi_oldold[n];
             if constexpr (LIN)
               val[3] = S.use_old ? po : poo + S.tfac * (po - poo);
@@ -419,10 +433,31 @@ namespace pfm
             if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
               {
                 const int n = cart_local_id3(cv, gi, gj, kz);
-                val[0] = v.u[0][n];
-                val[1] = v.u[1][n];
-                val[2] = v.u[2][n];
-                val[3] = v.phi[n];
+                if (v.fused_solution) // kernel argument: uniform branch.  Single rank: every node is an owned node
+                  {
+                    const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
+                    const double *su = v.fused_solution + (il ? 4LL * n : 3LL * n);
+                    val[0] = su[0];
+                    val[1] = su[1];
+                    val[2] = su[2];
+                    val[3] = il ? su[3] : v.fused_solution[3LL * v.n_owned + n];
+                    // the node state is what pfm_state_set_solution would have left: every node is written once, by the
+                    // tile and z-chunk that own it
+                    if (hx >= 1 && hx <= RNX && hy >= 1 && hy <= RNY && kz >= kA && kz < kB)
+                      {
+                        v.u[0][n] = val[0];
+                        v.u[1][n] = val[1];
+                        v.u[2][n] = val[2];
+                        v.phi[n] = val[3];
+                      }
+                  }
+                else
+                  {
+                    val[0] = v.u[0][n];
+                    val[1] = v.u[1][n];
+                    val[2] = v.u[2][n];
+                    val[3] = v.phi[n];
+                  }
                 val[4] = v.phi_old[n];
                 val[5] = v.phi_oldold[n];
                 if constexpr (LIN)

@@ -1338,6 +1338,32 @@ extern "C"
 
   int pfm_state_set_solution(pfm_ctx *c, const double *sol, int on_device) { return state_set_impl(c, sol, nullptr, nullptr, on_device); }
 
+  static int assemble_impl(pfm_ctx *c, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot, int phase);
+
+  // assemble_nl_residual() of the line search (cracks.cc:2942-2957, 2507-2512): solution := d_solution, then the residuals.
+  // On a single-rank box (2-D or 3-D lattice) the residual kernel reads d_solution itself (DevView::fused_solution); everywhere else this
+  // is pfm_state_set_solution + pfm_assemble_device(residual_only).  Ranks with peers must import ghosts in between: they
+  // call the two entry points themselves.
+  int pfm_assemble_nl_residual_device(pfm_ctx *c, const double *d_solution, double *d_res_pde, double *d_res_tot)
+  {
+    if (!c || (!d_solution && c->n_owned_dofs() != 0))
+      return PFM_ERR_BAD_ARG;
+    if (!c->peers.empty())
+      return fail(c, PFM_ERR_BAD_ARG, "pfm_assemble_nl_residual_device: a rank with peers imports ghosts between the scatter and the assembly");
+    const bool split = c->have_params && c->prm.decompose_stress_matrix > 0 && c->prm.timestep_number > 0;
+    const bool fuse = c->kernel_path == 1 && !split && c->v.n_owned == c->v.n_nodes && c->v.n_owned > 0 &&
+                      getenv("PFM_NO_FUSED_SCATTER") == nullptr;
+    if (!fuse)
+      {
+        const int rc = state_set_impl(c, d_solution, nullptr, nullptr, 1);
+        return rc ? rc : assemble_impl(c, 1, nullptr, d_res_pde, d_res_tot, 0);
+      }
+    c->v.fused_solution = d_solution;
+    const int rc = assemble_impl(c, 1, nullptr, d_res_pde, d_res_tot, 0);
+    c->v.fused_solution = nullptr;
+    return rc;
+  }
+
   static int ensure_halo_buffers(pfm_ctx *c);
 
   int pfm_halo_register(pfm_ctx *c, int n_peers, const int64_t *send_ptr, const int32_t *send_nodes,

@@ -36,6 +36,10 @@ namespace pfm
     double *u[3];
     double *phi, *phi_old, *phi_oldold;
     int *status; // device error word (pfm_status)
+    // pfm_assemble_nl_residual_device on a single-rank 3-D box: the residual kernel reads `solution` (owned dofs, the
+    // context's layout) itself while it fills its nodal planes and writes the node state on the way -- the separate scatter
+    // launch of pfm_state_set_solution (0.1 ms at 216^3) disappears.  nullptr everywhere else.
+    const double *fused_solution;
   };
 
   // Uniform Cartesian box (fast path): lattice of (NX,NY,NZ) nodes, owned nodes form the

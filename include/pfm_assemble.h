@@ -193,6 +193,12 @@ int pfm_assemble_overlapped(pfm_ctx *ctx, void *comm, const int *peer_ranks, int
  * cracks.cc:2470-2475) is needed. */
 int pfm_assemble_device(pfm_ctx *ctx, int residual_only, double *const *d_values /* [n_blocks] */,
                         double *d_residual_pde, double *d_residual_total);
+/* assemble_nl_residual() after `solution` alone changed -- the call of the line search (cracks.cc:2942-2957: solution +=
+ * delta; assemble_nl_residual(), up to max_no_line_search_steps times per Newton step; cracks.cc:2507-2512):
+ * = pfm_state_set_solution(d_solution, on_device = 1) + pfm_assemble_device(residual_only = 1) in one call.  On a
+ * single-rank 3-D box the residual kernel reads d_solution itself and the scatter launch disappears.  Ranks with halo
+ * peers import ghosts between the two steps and keep calling them separately (PFM_ERR_BAD_ARG here). */
+int pfm_assemble_nl_residual_device(pfm_ctx *ctx, const double *d_solution, double *d_residual_pde, double *d_residual_total);
 /* Blocks until the stream is idle and returns the deferred status of the launches since
  * the last call (PFM_ERR_NOT_ORTHOGONAL, PFM_ERR_HIP, ...). */
 int pfm_sync_status(pfm_ctx *ctx);

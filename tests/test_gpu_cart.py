@@ -433,3 +433,41 @@ def test_state_set_solution_only_keeps_the_old_fields():
     _, r2, t2 = ref.assemble_host(sol2, c.old, c.oldold, True)
     assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
     assert not np.array_equal(r1, r0)
+
+
+@pytest.mark.parametrize("dim,n", [(3, (11, 9, 20)), (2, (70, 33))])
+@pytest.mark.parametrize("blocked", [True, False])
+def test_assemble_nl_residual_device_reads_the_solution_itself(dim, n, blocked):
+    """pfm_assemble_nl_residual_device (cracks.cc:2942-2957, 2507-2512: solution += delta; assemble_nl_residual()): on a
+    single-rank box the residual kernel reads `solution` itself instead of a scatter launch in front of it.  Same bits as
+    pfm_state_set_solution + pfm_assemble_device, and the node state is left as the scatter would have left it: a
+    full assembly that follows WITHOUT another scatter matches the oracle at the new solution."""
+    import torch
+
+    c = box_case(dim, n, -10.0, 10.0, blocked)
+    ctx = make_context(c)
+    ctx.assemble_host(c.sol, c.old, c.oldold, True)  # all three vectors once
+    rng = np.random.default_rng(5)
+    sol2 = c.sol + 1e-3 * rng.standard_normal(c.sol.shape)
+    nd = c.layout.n_dofs
+    d_sol = torch.from_numpy(np.ascontiguousarray(sol2)).cuda()
+    bufs = [torch.empty(nd, dtype=torch.float64, device="cuda") for _ in range(2)]
+    ctx.assemble_nl_residual_device(d_sol.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr())
+    ctx.sync_status()
+    r1, t1 = bufs[0].cpu().numpy(), bufs[1].cpu().numpy()
+    ref = make_context(c)
+    _, r2, t2 = ref.assemble_host(sol2, c.old, c.oldold, True)
+    assert np.array_equal(r1, r2) and np.array_equal(t1, t2)
+    # the state: a Jacobian assembled now (no scatter in between) belongs to sol2
+    ctx.set_stream(0)
+    nb = ctx.n_blocks
+    vals = [torch.empty(ctx.pattern_size(b)[1], dtype=torch.float64, device="cuda") for b in range(nb)]
+    ctx.assemble_device(False, [v.data_ptr() for v in vals], bufs[0].data_ptr(), bufs[1].data_ptr())
+    ctx.sync_status()
+    c2 = c
+    c2.sol = sol2
+    r, rp, ci = oracle(c2, False)
+    A_ref = sp.csr_matrix((r.values, ci, rp), shape=(nd,) * 2)
+    A = blocks_to_global(ctx, c.layout, [v.cpu().numpy() for v in vals])
+    A.sort_indices()
+    assert linf_scaled(A.data, A_ref.data) < TOL and linf_scaled(bufs[0].cpu().numpy(), r.residual_pde) < TOL
