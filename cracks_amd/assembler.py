@@ -251,6 +251,12 @@ class Context:
     def force_path(self, path: int):
         self._check(self.lib.pfm_ctx_force_path(self._h, path), "pfm_ctx_force_path")
 
+    def overlay_info(self):
+        """(rows written by the patch kernel of the cartesian overlay, cells left to the general family)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.pfm_ctx_overlay_info(self._h, C.byref(a), C.byref(b)), "pfm_ctx_overlay_info")
+        return int(a.value), int(b.value)
+
     def force_phase(self, phase: int):
         """measurement: 1 / 2 = only the first / second half of the overlapped assembly, 0 = all."""
         self._check(self.lib.pfm_ctx_force_phase(self._h, phase), "pfm_ctx_force_phase")

@@ -27,7 +27,7 @@ EXPORTS = [
     "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
     "pfm_assemble_device", "pfm_assemble_nl_residual_device",
-    "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path", "pfm_ctx_force_phase",
+    "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path", "pfm_ctx_overlay_info", "pfm_ctx_force_phase",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms", "pfm_kernel_times_ms",
     # include/pfm_newton.h
     "pfm_diag_mass_device", "pfm_active_set_device", "pfm_get_constraints", "pfm_functionals",
@@ -123,6 +123,7 @@ def load():
     lib.pfm_assemble.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     lib.pfm_ctx_kernel_path.argtypes = [vp]
     lib.pfm_ctx_force_path.argtypes = [vp, i32]
+    lib.pfm_ctx_overlay_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.pfm_timing_enable.argtypes = [vp, i32]
     lib.pfm_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.pfm_kernel_times_ms.argtypes = [vp, vp, i32, C.POINTER(C.c_int)]

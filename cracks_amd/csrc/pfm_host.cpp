@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <exception>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -629,6 +630,242 @@ int64_t pfm_ctx::block_nnz(int b) const
 namespace
 {
   // PFM_CTX_TIMING=1: wall time of the phases of pfm_ctx_create on stderr (tuning only)
+
+  // ---- cartesian overlay of a general 2-D mesh (DevView::row_patch ..., pfm_kernels.hip: PATCH) -------------------------
+  // Every cell that is an axis-parallel rectangle belongs to the lattice of its size (a refinement level); a node is REGULAR
+  // when it is owned, neither hanging nor a parent, has exactly four incident cells, all of one level, and none of the nine
+  // lattice nodes around it is hanging -- its row is then the plain 9-point row of that level, completed by one workgroup
+  // of the patch kernel.  Blocks of 8 x 8 cells (7 x 7 nodes owned per block) tile each level; the general family keeps
+  // the cells that touch any other row (reduced colour lists), and skips the regular rows.
+  void build_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, const std::vector<int32_t> &hn_index, const std::vector<int32_t> &order,
+                       const std::vector<uint8_t> &ring)
+  {
+    DevView &v = c->v;
+    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    const int64_t NC = m->n_cells;
+    if (m->dim != 2 || NC == 0 || getenv("PFM_NO_PATCH"))
+      return;
+    const double *X = m->coords;
+    double xmin = X[0], ymin = X[1], xmax = X[0], ymax = X[1];
+    for (int32_t n = 0; n < N; ++n)
+      {
+        xmin = std::min(xmin, X[2 * n]);
+        xmax = std::max(xmax, X[2 * n]);
+        ymin = std::min(ymin, X[2 * n + 1]);
+        ymax = std::max(ymax, X[2 * n + 1]);
+      }
+    const double tol = 1e-9 * std::max(xmax - xmin, ymax - ymin);
+    // level of a cell (by its size), lattice position of its lower-left vertex
+    struct Level
+    {
+      double hx, hy;
+      long long ix0, iy0, ix1, iy1; // cell index range
+    };
+    std::vector<Level> levels;
+    std::vector<int8_t> cell_level((size_t)NC, -1);
+    std::vector<long long> cix((size_t)NC), ciy((size_t)NC);
+    for (int64_t k = 0; k < NC; ++k)
+      {
+        const int32_t *cn = m->cell_nodes + 4 * k;
+        const double x0 = X[2 * cn[0]], y0 = X[2 * cn[0] + 1], x1 = X[2 * cn[1]], y1 = X[2 * cn[1] + 1];
+        const double x2 = X[2 * cn[2]], y2 = X[2 * cn[2] + 1], x3 = X[2 * cn[3]], y3 = X[2 * cn[3] + 1];
+        const double hx = x1 - x0, hy = y2 - y0;
+        if (!(hx > tol && hy > tol) || std::fabs(y1 - y0) > tol || std::fabs(x2 - x0) > tol || std::fabs(x3 - x1) > tol || std::fabs(y3 - y2) > tol)
+          continue; // not an axis-parallel rectangle in deal.II's vertex order: stays with the general family
+        int L = -1;
+        for (size_t l = 0; l < levels.size(); ++l)
+          if (std::fabs(levels[l].hx - hx) <= 1e-9 * hx && std::fabs(levels[l].hy - hy) <= 1e-9 * hy)
+            L = (int)l;
+        if (L < 0)
+          {
+            if (levels.size() >= 100)
+              continue;
+            levels.push_back(Level{hx, hy, LLONG_MAX, LLONG_MAX, LLONG_MIN, LLONG_MIN});
+            L = (int)levels.size() - 1;
+          }
+        const double fx = (x0 - xmin) / levels[L].hx, fy = (y0 - ymin) / levels[L].hy;
+        const long long ix = std::llround(fx), iy = std::llround(fy);
+        if (std::fabs(fx - (double)ix) > 1e-6 || std::fabs(fy - (double)iy) > 1e-6)
+          continue; // off the level's lattice
+        cell_level[k] = (int8_t)L;
+        cix[k] = ix;
+        ciy[k] = iy;
+        Level &lv = levels[L];
+        lv.ix0 = std::min(lv.ix0, ix);
+        lv.iy0 = std::min(lv.iy0, iy);
+        lv.ix1 = std::max(lv.ix1, ix);
+        lv.iy1 = std::max(lv.iy1, iy);
+      }
+    if (levels.empty())
+      return;
+    // incident cells per node: count, common level, the 4 cells by the vertex the node is of them
+    std::vector<uint8_t> n_inc((size_t)N, 0), is_parent((size_t)N, 0);
+    std::vector<int8_t> node_level((size_t)N, -2); // -2 none yet, -1 mixed / off-lattice
+    std::vector<int32_t> inc((size_t)N * 4, -1);   // inc[4 n + a]: the cell of which n is vertex a
+    for (int64_t k = 0; k < NC; ++k)
+      for (int a = 0; a < 4; ++a)
+        {
+          const int32_t n = m->cell_nodes[4 * k + a];
+          if (n_inc[n] < 255)
+            ++n_inc[n];
+          const int8_t L = cell_level[k];
+          node_level[n] = (node_level[n] == -2) ? L : (node_level[n] == L ? L : (int8_t)-1);
+          inc[(size_t)n * 4 + a] = (inc[(size_t)n * 4 + a] == -1) ? (int32_t)k : -2; // -2: two cells claim the same corner
+        }
+    if (m->n_hanging > 0)
+      for (int64_t j = 0; j < m->hn_ptr[m->n_hanging]; ++j)
+        is_parent[m->hn_parents[j]] = 1;
+    // two nodes at one lattice position (the lips of a slit, meshes/unit_slit.inp): neither they nor their neighbours are regular
+    std::vector<uint8_t> dup((size_t)N, 0);
+    for (size_t L = 0; L < levels.size(); ++L)
+      {
+        const Level &lv = levels[L];
+        if (lv.ix0 > lv.ix1)
+          continue;
+        const long long W = lv.ix1 - lv.ix0 + 2, Hh = lv.iy1 - lv.iy0 + 2;
+        if ((double)W * (double)Hh > 4.0e8)
+          continue;
+        std::vector<int32_t> node_at((size_t)(W * Hh), -1);
+        for (int64_t k = 0; k < NC; ++k)
+          if (cell_level[k] == (int8_t)L)
+            for (int a = 0; a < 4; ++a)
+              {
+                const int32_t n = m->cell_nodes[4 * k + a];
+                int32_t &slot = node_at[(size_t)((ciy[k] - lv.iy0 + (a >> 1)) * W + (cix[k] - lv.ix0 + (a & 1)))];
+                if (slot == -1)
+                  slot = n;
+                else if (slot != n)
+                  dup[n] = dup[slot] = 1;
+              }
+      }
+    auto hanging = [&](int32_t n) { return (!hn_index.empty() && hn_index[n] >= 0) || dup[n] != 0; };
+    std::vector<uint8_t> regular((size_t)N, 0);
+    int64_t n_regular = 0;
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        if (n_inc[n] != 4 || node_level[n] < 0 || hanging(n) || is_parent[n])
+          continue;
+        bool ok = true;
+        for (int a = 0; a < 4 && ok; ++a)
+          {
+            const int32_t k = inc[(size_t)n * 4 + a];
+            ok = k >= 0;
+            if (ok)
+              for (int b = 0; b < 4; ++b)
+                ok = ok && !hanging(m->cell_nodes[4 * k + b]);
+          }
+        // the four cells really are the 2 x 2 cells around n on the level's lattice
+        if (ok)
+          {
+            const int32_t k3 = inc[(size_t)n * 4 + 3], k2 = inc[(size_t)n * 4 + 2], k1 = inc[(size_t)n * 4 + 1], k0 = inc[(size_t)n * 4 + 0];
+            ok = cix[k2] == cix[k3] + 1 && ciy[k2] == ciy[k3] && cix[k1] == cix[k3] && ciy[k1] == ciy[k3] + 1 && cix[k0] == cix[k3] + 1 &&
+                 ciy[k0] == ciy[k3] + 1;
+          }
+        if (ok && c->h_nadj_ptr.size() == (size_t)NO + 1)
+          ok = c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n] == 9;
+        if (ok)
+          {
+            regular[n] = 1;
+            ++n_regular;
+          }
+      }
+    if (n_regular == 0)
+      return;
+    // blocks: block (bx, by) of a level owns the lattice nodes [7 bx, 7 bx + 6] x [7 by, 7 by + 6] and holds the cells
+    // [7 bx - 1, 7 bx + 6] x [7 by - 1, 7 by + 6]; node (i, j) of the lattice = upper-right vertex of cell (i - 1, j - 1)
+    std::vector<int32_t> blk_cells, blk_nodes;
+    for (size_t L = 0; L < levels.size(); ++L)
+      {
+        const Level &lv = levels[L];
+        if (lv.ix0 > lv.ix1)
+          continue;
+        const long long W = lv.ix1 - lv.ix0 + 1, Hh = lv.iy1 - lv.iy0 + 1;
+        if ((double)W * (double)Hh > 4.0e8)
+          continue; // a level whose bounding box is mostly empty: not worth a dense table
+        std::vector<int32_t> at((size_t)(W * Hh), -1);
+        for (int64_t k = 0; k < NC; ++k)
+          if (cell_level[k] == (int8_t)L)
+            at[(size_t)((ciy[k] - lv.iy0) * W + (cix[k] - lv.ix0))] = (int32_t)k;
+        auto cell_at = [&](long long i, long long j) -> int32_t {
+          return (i < lv.ix0 || i > lv.ix1 || j < lv.iy0 || j > lv.iy1) ? -1 : at[(size_t)((j - lv.iy0) * W + (i - lv.ix0))];
+        };
+        auto floordiv = [](long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        const long long bx0 = floordiv(lv.ix0, 7), bx1 = floordiv(lv.ix1 + 1, 7), by0 = floordiv(lv.iy0, 7), by1 = floordiv(lv.iy1 + 1, 7);
+        for (long long by = by0; by <= by1; ++by)
+          for (long long bx = bx0; bx <= bx1; ++bx)
+            {
+              int32_t cells[64], nodes[81];
+              bool any = false;
+              for (int q = 0; q < 81; ++q)
+                nodes[q] = -1;
+              for (int cy = 0; cy < 8; ++cy)
+                for (int cx = 0; cx < 8; ++cx)
+                  {
+                    const int32_t k = cell_at(7 * bx - 1 + cx, 7 * by - 1 + cy);
+                    cells[cy * 8 + cx] = k;
+                    if (k >= 0)
+                      for (int a = 0; a < 4; ++a)
+                        nodes[(cx + (a & 1)) + 9 * (cy + (a >> 1))] = m->cell_nodes[4 * k + a];
+                  }
+              for (int hy = 1; hy <= 7; ++hy)
+                for (int hx = 1; hx <= 7; ++hx)
+                  {
+                    const int32_t n = nodes[hx + 9 * hy];
+                    any = any || (n >= 0 && n < NO && regular[n] && node_level[n] == (int8_t)L);
+                  }
+              if (!any)
+                continue;
+              // a regular node of ANOTHER level may sit at a position of this block (coinciding lattices): it is not ours
+              for (int hy = 1; hy <= 7; ++hy)
+                for (int hx = 1; hx <= 7; ++hx)
+                  {
+                    const int32_t n = nodes[hx + 9 * hy];
+                    if (n >= 0 && n < NO && regular[n] && node_level[n] != (int8_t)L)
+                      nodes[hx + 9 * hy] = -1;
+                  }
+              blk_cells.insert(blk_cells.end(), cells, cells + 64);
+              blk_nodes.insert(blk_nodes.end(), nodes, nodes + 81);
+            }
+      }
+    const int n_blocks = (int)(blk_cells.size() / 64);
+    if (n_blocks == 0)
+      return;
+    // reduced lists of the general family: the cells that touch a row the patches do not write
+    std::vector<uint8_t> need((size_t)NC, 0);
+    for (int64_t k = 0; k < NC; ++k)
+      for (int a = 0; a < 4; ++a)
+        {
+          const int32_t n = m->cell_nodes[4 * k + a];
+          if (hanging(n) || (n < NO && !regular[n]))
+            need[k] = 1;
+        }
+    std::vector<int32_t> order_red;
+    std::vector<uint8_t> ring_red;
+    c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
+    for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
+      {
+        c->color_ptr_reduced[cl] = (long long)order_red.size();
+        for (long long i = c->color_ptr[cl]; i < c->color_ptr[cl + 1]; ++i)
+          if (need[order[(size_t)i]])
+            order_red.push_back(order[(size_t)i]);
+      }
+    c->color_ptr_reduced.back() = (long long)order_red.size();
+    (void)ring;
+    (void)ring_red;
+    c->n_general_cells = (int64_t)order_red.size();
+    if (order_red.empty())
+      order_red.push_back(0);
+    v.row_patch = dev_upload(c, regular.data(), regular.size());
+    v.patch_cells = dev_upload(c, blk_cells.data(), blk_cells.size());
+    v.patch_nodes = dev_upload(c, blk_nodes.data(), blk_nodes.size());
+    c->d_node_slots = dev_alloc<unsigned long long>(c, (size_t)std::max<int32_t>(NO, 1));
+    v.node_slots = c->d_node_slots;
+    c->d_color_cells_reduced = dev_upload(c, order_red.data(), order_red.size());
+    c->n_patch_blocks = n_blocks;
+    c->n_patch_rows = n_regular;
+    c->patch_slots_valid = false;
+  }
+
   struct PhaseClock
   {
     const bool on = getenv("PFM_CTX_TIMING") != nullptr;
@@ -932,6 +1169,8 @@ extern "C"
         v.color_cells = dev_upload(c, order.data(), order.size());
         v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
         clk.mark("colour classes");
+        build_patches2d(c, m, hn_index, order, ring);
+        clk.mark("cartesian overlay (2-D)");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
           {
@@ -1006,7 +1245,7 @@ extern "C"
       {
         return hipfail(c, f.e, f.what);
       }
-    c->kernel_path = c->cart_ok ? 1 : 0;
+    c->kernel_path = c->cart_ok ? 1 : (c->n_patch_blocks > 0 ? 3 : 0); // 3: general family + cartesian overlay (2-D)
     return PFM_OK;
   }
 
@@ -1253,6 +1492,7 @@ extern "C"
                 if (!c->h_nadj.empty() &&
                     hipMemcpy(const_cast<int32_t *>(c->v.nadj), c->h_nadj.data(), c->h_nadj.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
                   throw HipFail{hipGetLastError(), "hipMemcpy nadj"};
+                c->patch_slots_valid = false; // the regular rows' slots follow the bound order
                 if (launch_build_cslot(c->v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
                   throw HipFail{hipGetLastError(), "cslot kernel"};
               }
@@ -1743,6 +1983,30 @@ extern "C"
     return halo_exchange_on(c, comm, peer_ranks, c->stream);
   }
 
+  // cartesian overlay: the slots of the regular rows follow the order of the node-graph rows (pfm_pattern_bind may change it)
+  static int ensure_patch_ready(pfm_ctx *c)
+  {
+    if (c->n_patch_blocks == 0 || c->patch_slots_valid)
+      return PFM_OK;
+    try
+      {
+        ensure_general_tables(c); // v.nadj (lattice contexts build it on first use)
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
+      }
+    catch (const std::bad_alloc &)
+      {
+        return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+      }
+    const int rc = launch_patch_slots(c->v, c->d_node_slots, c->n_patch_blocks, c->stream);
+    if (rc)
+      return fail(c, rc, "patch slots");
+    c->patch_slots_valid = true;
+    return PFM_OK;
+  }
+
   // phase 2 of pfm_assemble_overlapped launches only the tiles that read ghost nodes: their indices, once per context
   static int ensure_overlap_lists(pfm_ctx *c)
   {
@@ -1803,6 +2067,15 @@ extern "C"
           }
       }
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
+    // cartesian overlay of a general 2-D mesh (AMR meshes; stress-split runs on a lattice): patch kernel for the regular rows,
+    // the general family for the rest (PFM_NO_PATCH=1 at context creation: general family alone)
+    const bool patches = !cart && c->v.dim == 2 && c->n_patch_blocks > 0 && c->kernel_path != 0 && phase != 1;
+    if (patches)
+      {
+        const int rcp = ensure_patch_ready(c);
+        if (rcp)
+          return rcp;
+      }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing && phase == 2)
       ev1 = c->ev_pool[c->ev_used - 1].second; // opened by phase 1
@@ -1919,9 +2192,29 @@ extern "C"
     pfm::CartView cv_launch = c->cv;
     if (!pair)
       cv_launch.patch_idx = nullptr, cv_launch.patch_val = nullptr, cv_launch.patch_count = nullptr, cv_launch.patch_cap = 0;
-    int rc = cart ? launch_assemble_cart(c->v, cv_launch, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, pair || fork ? s_res : c->stream, c->d_scal, phase)
-                  : launch_assemble_general(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr,
-                                            fork_general ? c->side_stream : nullptr);
+    int rc;
+    if (cart)
+      rc = launch_assemble_cart(c->v, cv_launch, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, pair || fork ? s_res : c->stream, c->d_scal, phase);
+    else if (patches)
+      {
+        // the general family over the cells that touch a non-regular row (it skips the regular ones: DevView::row_patch),
+        // then the patch kernel: every regular row is written once, with plain stores
+        pfm::DevView vg = c->v;
+        vg.color_cells = c->d_color_cells_reduced;
+        rc = c->n_general_cells > 0 ? launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream,
+                                                              c->color_ptr_reduced, fork_general ? c->side_stream : nullptr)
+                                    : PFM_OK;
+        if (rc == PFM_OK)
+          rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks,
+                                       fork_general ? c->side_stream : c->stream);
+      }
+    else
+      {
+        pfm::DevView vg = c->v;
+        vg.row_patch = nullptr; // no overlay in this assembly: the general family writes every row
+        rc = launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr,
+                                     fork_general ? c->side_stream : nullptr);
+      }
     if (fork_general)
       {
         e = hipEventRecord(c->ev_join, c->side_stream);
@@ -2173,9 +2466,25 @@ extern "C"
 
   int pfm_ctx_force_path(pfm_ctx *c, int path)
   {
+    if (path == 3 && c && !c->cart_ok && c->n_patch_blocks > 0)
+      {
+        c->kernel_path = 3;
+        return PFM_OK;
+      }
     if (!c || path < 0 || path > 2 || (path >= 1 && !c->cart_ok) || (path == 2 && c->v.dim != 3))
       return PFM_ERR_UNSUPPORTED;
     c->kernel_path = path;
+    return PFM_OK;
+  }
+
+  int pfm_ctx_overlay_info(const pfm_ctx *c, int64_t *n_patch_rows, int64_t *n_general_cells)
+  {
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    if (n_patch_rows)
+      *n_patch_rows = c->n_patch_blocks > 0 ? c->n_patch_rows : 0;
+    if (n_general_cells)
+      *n_general_cells = c->n_patch_blocks > 0 ? c->n_general_cells : c->v.n_cells;
     return PFM_OK;
   }
 

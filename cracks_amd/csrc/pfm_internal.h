@@ -40,6 +40,14 @@ namespace pfm
     // context's layout) itself while it fills its nodal planes and writes the node state on the way -- the separate scatter
     // launch of pfm_state_set_solution (0.1 ms at 216^3) disappears.  nullptr everywhere else.
     const double *fused_solution;
+    // ---- cartesian overlay of a general 2-D mesh (round 4, pfm_kernels.hip: PATCH): rows of "regular" nodes -- not hanging,
+    // not a parent, exactly four incident cells of one refinement level, a plain 9-neighbour row -- are completed inside one
+    // workgroup per 8 x 8 block of that level's lattice and written once; the colour classes / the atomic class only run
+    // over the cells that touch another row and skip the regular ones.  nullptr: no overlay.
+    const uint8_t *row_patch;            // [n_nodes] 1 = the row is written by the patch kernel
+    const int32_t *patch_cells;          // [n_patch_blocks][64] cell id of lattice position (cx, cy) of the block, -1 = none
+    const int32_t *patch_nodes;          // [n_patch_blocks][81] node id of the block's 9 x 9 nodes, -1 = none
+    const unsigned long long *node_slots; // [n_owned] regular rows: CSR slot of lattice offset o in bits 4 o .. 4 o + 3
   };
 
   // Uniform Cartesian box (fast path): lattice of (NX,NY,NZ) nodes, owned nodes form the
@@ -171,6 +179,11 @@ namespace pfm
   int launch_assemble_general(const DevView &v, const pfm_params &p, int residual_only,
                               double *const *d_values, double *d_res_pde, double *d_res_tot,
                               hipStream_t s, const std::vector<long long> &color_ptr, hipStream_t s_atomic = nullptr);
+  // the patch kernel of the cartesian overlay (2-D): one workgroup per block of DevView::patch_cells
+  int launch_assemble_patches(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *d_res_pde,
+                              double *d_res_tot, int n_blocks, hipStream_t s);
+  // fills DevView::node_slots from the current order of the node-graph rows (context creation, pfm_pattern_bind)
+  int launch_patch_slots(const DevView &v, unsigned long long *d_slots, int n_blocks, hipStream_t s);
 } // namespace pfm
 
 struct pfm_ctx
@@ -217,6 +230,14 @@ struct pfm_ctx
   pfm::LatticeHost lat;          // host lattice tables (cartesian path only)
   bool pattern_bound[4] = {false, false, false, false};
   bool scal_dirty = true; // d_scal does not hold the tables of the current parameters yet
+  // cartesian overlay of a general 2-D mesh (DevView::row_patch ...): blocks, the reduced cell lists of the general family
+  int n_patch_blocks = 0;
+  int64_t n_patch_rows = 0, n_general_cells = 0;
+  unsigned long long *d_node_slots = nullptr;
+  bool patch_slots_valid = false;
+  int32_t *d_color_cells_reduced = nullptr; // colour-sorted cells that touch a row the patches do not write
+  std::vector<long long> color_ptr_reduced;
+  uint8_t *d_cell_ring_reduced = nullptr;
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;
   double *d_partial = nullptr;

@@ -197,11 +197,19 @@ namespace pfm
     // row accumulators of a hex vertex need 374 registers -- one wave per SIMD plus accumulation-register moves; two
     // launches with 54 accumulators each run at two waves per SIMD).  The residual and the constrained diagonals are
     // written by the launch with BH < 0 or BH == 1 (the upper half has the registers to spare).
-    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1, bool RING = false /* DevView::cell_ring is set */>
+    // PATCH (2-D, round 4): the workgroup is an 8 x 8 block of one refinement level's lattice (DevView::patch_cells); the
+    // rows of the block's regular nodes are completed in LDS -- the four vertex lanes of the cells push in four barrier-
+    // separated phases (phase = vertex index: a node receives exactly one cell per phase, the order of the adds is fixed) --
+    // masked and written ONCE: no colour classes, no read-modify-write of global memory, no atomics.  Same q-loop, same
+    // formulas as every other instantiation.
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1, bool RING = false /* DevView::cell_ring is set */, bool PATCH = false>
     __global__ __launch_bounds__(256, (dim == 3 && FULL) ? 2 : 1) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
                                                               double *res_pde, double *res_tot,
                                                               int residual_only, long long class_begin, long long class_size)
     {
+      static_assert(!PATCH || (dim == 2 && !ATOMIC && BH < 0 && !RING), "the patch form exists in 2-D");
+      constexpr int PRW = 81 + 3 + 3; // staged row of a node: 3 row components x 9 offsets x 3 column components, residual, placeholders
+      __shared__ double s_row[PATCH ? 49 * PRW : 1];
       constexpr int nv = 1 << dim, nc = dim + 1, nq = (dim == 2 ? 9 : 27), dpc = nv * nc;
       constexpr int B0 = BH < 0 ? 0 : BH * (nv / 2), NBL = BH < 0 ? nv : nv / 2; // trial vertices [B0, B0 + NBL)
       static_assert(BH < 0 || (FULL && !SPLIT), "the split of the trial vertices exists for the unsplit Jacobian only");
@@ -215,8 +223,18 @@ namespace pfm
       const int a = tid % nv, cl0 = tid / nv;
       const int cl = cl0;
       const long long at = (long long)blockIdx.x * CPB + cl;
-      const bool active = at < class_size;
-      const long long cell = active ? v.color_cells[class_begin + at] : 0;
+      bool active = at < class_size;
+      long long cell = 0;
+      if constexpr (PATCH)
+        {
+          const int pc = v.patch_cells[(long long)blockIdx.x * CPB + cl];
+          active = pc >= 0;
+          cell = active ? pc : 0;
+          for (int i = tid; i < 49 * PRW; i += 256)
+            s_row[i] = 0.0;
+        }
+      else
+        cell = active ? v.color_cells[class_begin + at] : 0;
       int A = 0;
       if (active)
         {
@@ -232,8 +250,8 @@ namespace pfm
           s_p[2][a][cl] = v.phi_oldold[A];
         }
       __syncthreads();
-      if (!active)
-        return;
+      if (!PATCH && !active)
+        return; // (the lanes of an absent cell of a patch block stay for the barriers of the epilogue)
 
       double lam = prm.lambda, mu = prm.mu;
       if (v.cell_lambda)
@@ -298,8 +316,9 @@ namespace pfm
         }
       bool ortho_ok = true;
 
+      const int nq_run = active ? nq : 0;
 #pragma unroll 1
-      for (int q = 0; q < nq; ++q)
+      for (int q = 0; q < nq_run; ++q)
         {
           int cl = cl0;
           asm volatile("" : "+v"(cl)); // the cell's nodal data are re-read from LDS per q-point, not pinned in registers
@@ -656,13 +675,117 @@ namespace pfm
       if (!ortho_ok)
         atomicMax(v.status, (int)PFM_ERR_NOT_ORTHOGONAL);
 
+      if constexpr (PATCH)
+        {
+          // =============================== rows of the block's regular nodes, completed in LDS
+          const int cx = cl0 % 8, cy = cl0 / 8, ax = a & 1, ay = a >> 1;
+          const int nx = cx + ax, ny = cy + ay; // position of the lane's vertex among the block's 9 x 9 nodes
+          const bool mine = active && nx >= 1 && nx <= 7 && ny >= 1 && ny <= 7;
+          double *row = s_row + ((nx - 1) + 7 * (ny - 1)) * PRW;
+          // |K_ii| of this cell, or the mean |diagonal| of its element matrix (deal.II's placeholder rule)
+          double diag[nc] = {0.0, 0.0, 0.0};
+          if constexpr (FULL)
+            {
+#pragma unroll
+              for (int b = 0; b < nv; ++b)
+                if (b == a)
+                  {
+                    diag[0] = fabs(Kuu[b][0][0]);
+                    diag[1] = fabs(Kuu[b][1][1]);
+                    diag[2] = fabs(Kpp[b]);
+                  }
+            }
+          double dsum = diag[0] + diag[1] + diag[2];
+#pragma unroll
+          for (int m = 1; m < nv; m <<= 1)
+            dsum += __shfl_xor(dsum, m, nv);
+          const double avg = dsum / (double)dpc;
+#pragma unroll 1
+          for (int phase = 0; phase < nv; ++phase)
+            {
+              if (mine && a == phase)
+                {
+                  if constexpr (FULL)
+                    {
+#pragma unroll
+                      for (int b = 0; b < nv; ++b)
+                        {
+                          const int o = ((b & 1) - ax + 1) + 3 * ((b >> 1) - ay + 1); // lattice offset of the trial vertex
+#pragma unroll
+                          for (int c = 0; c < dim; ++c)
+#pragma unroll
+                            for (int d = 0; d < dim; ++d)
+                              row[(c * 9 + o) * 3 + d] += Kuu[b][c][d];
+#pragma unroll
+                          for (int d = 0; d < dim; ++d)
+                            row[(dim * 9 + o) * 3 + d] += Kpu[b][d];
+                          row[(dim * 9 + o) * 3 + dim] += Kpp[b];
+                        }
+#pragma unroll
+                      for (int c = 0; c < nc; ++c)
+                        row[84 + c] += diag[c] != 0.0 ? diag[c] : avg;
+                    }
+#pragma unroll
+                  for (int c = 0; c < nc; ++c)
+                    row[81 + c] += R[c];
+                }
+              __syncthreads();
+            }
+          const int32_t *bn = v.patch_nodes + (long long)blockIdx.x * 81;
+          const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
+          if constexpr (FULL)
+            {
+              const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
+              for (int e = tid; e < 49 * 81; e += 256)
+                {
+                  const int nl = e / 81, r = e - nl * 81;
+                  const int hx = nl % 7 + 1, hy = nl / 7 + 1;
+                  const int node = bn[hx + 9 * hy];
+                  if (node < 0 || node >= v.n_owned || !v.row_patch[node])
+                    continue;
+                  const int c = r / 27, o = (r - c * 27) / 3, d = r % 3;
+                  const int nb = bn[(hx + o % 3 - 1) + 9 * (hy + o / 3 - 1)];
+                  const unsigned fA = v.node_flags[node], fQ = v.node_flags[nb];
+                  const bool rcon = (fA >> c) & 1u, ccon = (fQ >> d) & 1u;
+                  double val = s_row[nl * PRW + r];
+                  if (rcon || ccon)
+                    val = (rcon && o == 4 && d == c) ? s_row[nl * PRW + 84 + c] : 0.0;
+                  const long long off = v.nadj_ptr[node];
+                  const int sl = (int)((v.node_slots[node] >> (4 * o)) & 15ull);
+                  double *dst;
+                  if (il)
+                    dst = vals.b[0] + (9 * off + (long long)c * 27 + sl * 3 + d);
+                  else if (c < 2)
+                    dst = d < 2 ? vals.b[0] + (4 * off + (long long)c * 18 + sl * 2 + d) : vals.b[1] + (2 * off + (long long)c * 9 + sl);
+                  else
+                    dst = d < 2 ? vals.b[2] + (2 * off + sl * 2 + d) : vals.b[3] + (off + sl);
+                  *dst = val;
+                }
+            }
+          for (int e = tid; e < 49 * nc; e += 256)
+            {
+              const int nl = e / nc, c = e - nl * nc;
+              const int node = bn[(nl % 7 + 1) + 9 * (nl / 7 + 1)];
+              if (node < 0 || node >= v.n_owned || !v.row_patch[node])
+                continue;
+              const bool con = (v.node_flags[node] >> c) & 1u;
+              const double rv = s_row[nl * PRW + 81 + c];
+              const long long di = dof_index<dim>(v, node, c);
+              res_pde[di] = con ? 0.0 : rv;
+              if (residual_only)
+                res_tot[di] = (!con || !total_via_update) ? rv : 0.0;
+            }
+          return;
+        }
+
       // =============================== scatter through the constraints (cracks.cc:2439-2464)
       if constexpr (!ATOMIC)
         {
           // Colour class without hanging vertices: the rows of node A are touched by this thread only during this
           // launch.  Every batch of read-modify-writes loads all its old values before the first store (the adds of a
           // batch hit distinct entries; one HBM/L2 round trip per batch instead of one per entry).
-          const bool owned = A < v.n_owned; // rows of ghost nodes belong to another rank
+          // rows of ghost nodes belong to another rank, rows of regular nodes to the patch kernel (DevView::row_patch)
+          const bool owned = A < v.n_owned && !(v.row_patch && v.row_patch[A]);
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           const unsigned fA = v.node_flags[A];
           // a cell next to the atomic class (which may be running on another stream): atomic adds, see DevView::cell_ring
@@ -810,7 +933,7 @@ namespace pfm
         {
           const int P = kA < 0 ? A : v.hn_parents[r];
           const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
-          if (P >= v.n_owned)
+          if (P >= v.n_owned || (v.row_patch && v.row_patch[P]))
             continue;
           const unsigned fP = v.node_flags[P];
 #pragma unroll
@@ -855,7 +978,7 @@ namespace pfm
                 {
                   const int P = kA < 0 ? A : v.hn_parents[r];
                   const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
-                  if (P >= v.n_owned)
+                  if (P >= v.n_owned || (v.row_patch && v.row_patch[P]))
                     continue;
                   const unsigned fP = v.node_flags[P];
                   for (long long s = cb; s < ce; ++s)
@@ -896,7 +1019,7 @@ namespace pfm
           for (int m = 1; m < nv; m <<= 1)
             dsum += __shfl_xor(dsum, m, nv);
           const double avg = dsum / (double)dpc;
-          if (RESID && A < v.n_owned && (kA >= 0 || fA))
+          if (RESID && A < v.n_owned && !(v.row_patch && v.row_patch[A]) && (kA >= 0 || fA))
             {
               const int slot = (int)cs[a * nv + a];
 #pragma unroll
@@ -1202,6 +1325,85 @@ namespace pfm
         else
           hipLaunchKernelGGL((k_halo_all<3, false>), dim3(nb), dim3(bs), 0, s, v, nodes, ptr, n_peers, (long long)n_total, buf);
       }
+    return check_launch();
+  }
+
+  namespace
+  {
+    // CSR slots of the 9 lattice offsets of every regular row, from the current order of the node-graph rows:
+    // thread <-> (block, owned position)
+    __global__ void k_patch_slots(DevView v, unsigned long long *__restrict__ slots, int n_blocks)
+    {
+      const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (idx >= (long long)n_blocks * 49)
+        return;
+      const int blk = (int)(idx / 49), nl = (int)(idx % 49);
+      const int hx = nl % 7 + 1, hy = nl / 7 + 1;
+      const int32_t *bn = v.patch_nodes + (long long)blk * 81;
+      const int node = bn[hx + 9 * hy];
+      if (node < 0 || node >= v.n_owned || !v.row_patch[node])
+        return;
+      const long long off = v.nadj_ptr[node];
+      const int deg = (int)(v.nadj_ptr[node + 1] - off);
+      unsigned long long packed = 0ull;
+      for (int o = 0; o < 9; ++o)
+        {
+          const int nb = bn[(hx + o % 3 - 1) + 9 * (hy + o / 3 - 1)];
+          int sl = 15;
+          for (int k = 0; k < deg; ++k)
+            if (v.nadj[off + k] == nb)
+              sl = k;
+          if (sl == 15)
+            atomicMax(v.status, (int)PFM_ERR_INTERNAL); // a regular row must hold its 9 lattice neighbours
+          packed |= (unsigned long long)sl << (4 * o);
+        }
+      slots[node] = packed;
+    }
+  } // namespace
+
+  int launch_patch_slots(const DevView &v, unsigned long long *d_slots, int n_blocks, hipStream_t s)
+  {
+    if (n_blocks <= 0)
+      return PFM_OK;
+    const long long n = (long long)n_blocks * 49;
+    hipLaunchKernelGGL(k_patch_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, d_slots, n_blocks);
+    return check_launch();
+  }
+
+  int launch_assemble_patches(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *res_pde,
+                              double *res_tot, int n_blocks, hipStream_t s)
+  {
+    int rc = ensure_tables();
+    if (rc)
+      return rc;
+    if (n_blocks <= 0)
+      return PFM_OK;
+    if (v.dim != 2)
+      return PFM_ERR_UNSUPPORTED;
+    Vals vals{};
+    if (!residual_only)
+      for (int b = 0; b < (v.layout == PFM_LAYOUT_BLOCKED ? 4 : 1); ++b)
+        vals.b[b] = d_values[b];
+    const bool split = (p.decompose_stress_matrix > 0 && p.timestep_number > 0);
+    const dim3 grid((unsigned)n_blocks), block(256);
+#define PFM_PATCH(FULLV, SPLITV)                                                                                              \
+  hipLaunchKernelGGL((k_assemble_general<2, FULLV, SPLITV, false, -1, false, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
+                     residual_only, 0LL, 0LL)
+    if (residual_only)
+      {
+        if (split)
+          PFM_PATCH(false, true);
+        else
+          PFM_PATCH(false, false);
+      }
+    else
+      {
+        if (split)
+          PFM_PATCH(true, true);
+        else
+          PFM_PATCH(true, false);
+      }
+#undef PFM_PATCH
     return check_launch();
   }
 

@@ -229,9 +229,14 @@ int pfm_kernel_time_ms(pfm_ctx *ctx, double *mean_ms, int *n_launches);
 int pfm_kernel_times_ms(pfm_ctx *ctx, double *ms, int capacity, int *n_launches);
 
 /* -- introspection -------------------------------------------------------------------- */
-/* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian */
+/* which kernel family the context selected: 0 = general (any Q1 mesh), 1 = cartesian (uniform box; its 2-D stress-split runs
+ * use the overlay below), 3 = general family + cartesian overlay: 2-D meshes with hanging nodes, slits, several refinement
+ * levels -- the rows of regular lattice nodes are completed by one workgroup per 8 x 8 block of their level, the general
+ * family keeps the cells that touch any other row.  pfm_ctx_force_path(0) selects the general family alone (A/B runs). */
 int pfm_ctx_kernel_path(const pfm_ctx *ctx);
 int pfm_ctx_force_path(pfm_ctx *ctx, int path);
+/* composition of the overlay: rows written by the patch kernel / cells left to the general family (0 / all without it) */
+int pfm_ctx_overlay_info(const pfm_ctx *ctx, int64_t *n_patch_rows, int64_t *n_general_cells);
 /* measurement only: 1 / 2 make pfm_assemble_device run only the first / second half of pfm_assemble_overlapped (the work
  * that reads no ghost node / the rest), 0 restores the whole assembly: how much work hides the ghost import */
 int pfm_ctx_force_phase(pfm_ctx *ctx, int phase);

@@ -95,11 +95,21 @@ def test_cart_uu_overlay_monolithic_and_active_set():
     _full(c, path=2)
 
 
-def test_non_lattice_meshes_fall_back_to_general():
+def test_non_lattice_meshes_use_the_general_family_with_the_cartesian_overlay():
+    """2-D meshes that are not one lexicographic box (slit with duplicated nodes, hanging nodes): kernel path 3 = the
+    general family for the rows next to the irregularities + the patch kernel for the rows of regular lattice nodes."""
     c = cases.kat_miehe_shear_1()  # duplicated nodes along the slit
-    assert make_context(c).kernel_path == 0
+    ctx = make_context(c)
+    assert ctx.kernel_path == 3
+    rows, cells = ctx.overlay_info()
+    assert 0 < rows < c.mesh.n_nodes and 0 < cells < c.mesh.n_cells
     c = cases.kat_sneddon_2d()  # hanging nodes
-    assert make_context(c).kernel_path == 0
+    ctx = make_context(c)
+    assert ctx.kernel_path == 3
+    rows, cells = ctx.overlay_info()
+    assert 0 < rows < c.mesh.n_nodes and 0 < cells < c.mesh.n_cells
+    ctx.force_path(0)
+    assert ctx.kernel_path == 0
 
 
 @pytest.mark.parametrize("blocked", [True, False])

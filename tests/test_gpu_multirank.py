@@ -172,7 +172,7 @@ def test_general_partition_owned_rows_match_single_rank(kind, world, ghost_layer
         return sol, old, oo
 
     ref = Assembler(g, blocked=True)
-    assert ref.ctx.kernel_path == 0
+    assert ref.ctx.kernel_path == (3 if dim == 2 else 0)  # 2-D: general family + cartesian overlay
     ref.set_params(prm)
     ref.set_constraints(gflags)
     ref.set_vectors(*vectors(N, f))

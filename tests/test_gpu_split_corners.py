@@ -101,7 +101,7 @@ def test_split_at_exactly_diagonal_and_zero_strain_reproduces_the_ieee_pattern()
     ch = M.hanging_constraints(mesh, lay)
     c = cases.Case("corners", mesh, lay, _miehe_params(), sol, old, oo, cu, ch)
     ctx = make_context(c)
-    assert ctx.kernel_path == 0
+    assert ctx.kernel_path in (0, 3)  # a small mesh may have no regular row at all
     for residual_only in (True, False):
         r, rp, ci = _oracle(c, residual_only)
         assert r.err == 0  # NaN passes the reference's orthogonality check (NaN > 1e-6 is false)
