@@ -670,8 +670,8 @@ namespace
         const double x0 = X[2 * cn[0]], y0 = X[2 * cn[0] + 1], x1 = X[2 * cn[1]], y1 = X[2 * cn[1] + 1];
         const double x2 = X[2 * cn[2]], y2 = X[2 * cn[2] + 1], x3 = X[2 * cn[3]], y3 = X[2 * cn[3] + 1];
         const double hx = x1 - x0, hy = y2 - y0;
-        if (!(hx > tol && hy > tol) || std::fabs(y1 - y0) > tol || std::fabs(x2 - x0) > tol || std::fabs(x3 - x1) > tol || std::fabs(y3 - y2) > tol)
-          continue; // not an axis-parallel rectangle in deal.II's vertex order: stays with the general family
+        if (!(hx > tol && hy > tol) || y1 != y0 || x2 != x0 || x3 != x1 || y3 != y2)
+          continue; // not an EXACT axis-parallel rectangle in deal.II's vertex order (the patch kernel takes J = diag(hx, hy)): stays with the general family
         int L = -1;
         for (size_t l = 0; l < levels.size(); ++l)
           if (std::fabs(levels[l].hx - hx) <= 1e-9 * hx && std::fabs(levels[l].hy - hy) <= 1e-9 * hy)
@@ -2163,7 +2163,9 @@ extern "C"
     // the zeroing of the outputs (DevView::cell_ring; PFM_GENERAL_SEQUENTIAL=1: one after the other)
     static const bool general_sequential = getenv("PFM_GENERAL_SEQUENTIAL") != nullptr;
     // (a residual-only assembly keeps the stream order: its atomic class takes 15 us, less than a fork and a join)
-    const bool fork_general = !cart && !residual_only && c->v.cell_ring != nullptr && !general_sequential;
+    // overlay: the patch kernel on the stream, every class of the (small) rest of the general family on the side stream
+    const bool fork_general = !cart && !general_sequential &&
+                              ((!residual_only && c->v.cell_ring != nullptr) || (patches && c->n_general_cells > 0));
     if (fork_general)
       {
         if (!c->side_stream)
@@ -2197,16 +2199,15 @@ extern "C"
       rc = launch_assemble_cart(c->v, cv_launch, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, pair || fork ? s_res : c->stream, c->d_scal, phase);
     else if (patches)
       {
-        // the general family over the cells that touch a non-regular row (it skips the regular ones: DevView::row_patch),
-        // then the patch kernel: every regular row is written once, with plain stores
+        // the patch kernel: every regular row is written once, with plain stores; next to it (side stream) the general
+        // family over the cells that touch a non-regular row (it skips the regular ones: DevView::row_patch), its classes one
+        // after the other
+        rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks, c->stream);
         pfm::DevView vg = c->v;
         vg.color_cells = c->d_color_cells_reduced;
-        rc = c->n_general_cells > 0 ? launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream,
-                                                              c->color_ptr_reduced, fork_general ? c->side_stream : nullptr)
-                                    : PFM_OK;
-        if (rc == PFM_OK)
-          rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks,
-                                       fork_general ? c->side_stream : c->stream);
+        if (rc == PFM_OK && c->n_general_cells > 0)
+          rc = launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, fork_general ? c->side_stream : c->stream,
+                                       c->color_ptr_reduced, nullptr);
       }
     else
       {

@@ -225,6 +225,10 @@ namespace pfm
       const long long at = (long long)blockIdx.x * CPB + cl;
       bool active = at < class_size;
       long long cell = 0;
+      // PATCH: what the copy-out needs of the block's 9 x 9 nodes, fetched while the cell data are on their way
+      __shared__ int s_bn[PATCH ? 81 : 1], s_fl[PATCH ? 81 : 1];
+      __shared__ long long s_off[PATCH ? 49 : 1];           // first neighbour entry of the row, -1: not a row of this block
+      __shared__ unsigned long long s_inv[PATCH ? 49 : 1];  // 4-bit fields: lattice offset (0..8) stored in slot s of the row
       if constexpr (PATCH)
         {
           const int pc = v.patch_cells[(long long)blockIdx.x * CPB + cl];
@@ -232,6 +236,25 @@ namespace pfm
           cell = active ? pc : 0;
           for (int i = tid; i < 49 * PRW; i += 256)
             s_row[i] = 0.0;
+          if (tid < 81)
+            {
+              const int n = v.patch_nodes[(long long)blockIdx.x * 81 + tid];
+              const int hx = tid % 9, hy = tid / 9;
+              const bool inner = hx >= 1 && hx <= 7 && hy >= 1 && hy <= 7;
+              const bool ok = inner && n >= 0 && n < v.n_owned && v.row_patch[n];
+              s_bn[tid] = n;
+              s_fl[tid] = n >= 0 ? (int)v.node_flags[n] : 0;
+              if (inner)
+                {
+                  const unsigned long long sl = ok ? v.node_slots[n] : 0ull;
+                  unsigned long long iv = 0;
+#pragma unroll
+                  for (int o = 0; o < 9; ++o)
+                    iv |= (unsigned long long)o << (4 * (int)((sl >> (4 * o)) & 15ull));
+                  s_off[(hx - 1) + 7 * (hy - 1)] = ok ? (long long)v.nadj_ptr[n] : -1ll;
+                  s_inv[(hx - 1) + 7 * (hy - 1)] = iv;
+                }
+            }
         }
       else
         cell = active ? v.color_cells[class_begin + at] : 0;
@@ -315,8 +338,261 @@ namespace pfm
             }
         }
       bool ortho_ok = true;
+      double p_ihx = 0.0, p_ihy = 0.0, p_det = 0.0;
+      if constexpr (PATCH)
+        {
+          const double hx = s_x[0][1][cl] - s_x[0][0][cl], hy = s_x[1][2][cl] - s_x[1][0][cl];
+          p_ihx = 1.0 / hx;
+          p_ihy = 1.0 / hy;
+          p_det = hx * hy;
+        }
 
       const int nq_run = active ? nq : 0;
+      if constexpr (dim == 2 && SPLIT)
+        {
+          // ======================= stress split (2-D): the q-point states are shared out among the four lanes of the cell
+          // Everything of a q-point that does not depend on the test vertex -- MappingQ1, the Newton state, the eigen
+          // split (cracks.cc:1691-1737, 1923-1970) and its linearisation (cracks.cc:1976-2109) -- is the same for the four
+          // lanes of a cell and is most of the work.  Round j = 0, 1, 2: lane a evaluates q-point 4 j + a ONCE (phase A) and
+          // leaves what the rows need of it, already multiplied by JxW, in NO registers; then the quad goes through the
+          // round's q-points together (phase B): the values of the owner lane come by DPP, every lane adds to the rows of
+          // its own vertex.  9 q-points in 12 slots (the last round has one) instead of 36 evaluations per cell.
+          //
+          // The linearised split is linear in the direction E_LinU, and E_LinU of trial dof (b, d) is
+          // sym(e_d (x) grad N_b): the owner calls the reference function for the unit directions e0 e0, e1 e1,
+          // sym(e0 e1), folds g(phi) and decompose_stress_matrix in (a 3 x 3 tangent D in Voigt order 00, 11, 01) and the
+          // rows are the usual B_a^T D B_b.
+          constexpr double GX0 = 0.5 - 0.5 * 0.7745966692414834, GX2 = 0.5 + 0.5 * 0.7745966692414834; // make_ref_tables
+          constexpr double GW0 = 5.0 / 18.0, GW1 = 8.0 / 18.0;
+          constexpr int NO_RES = 6, NO_JAC = 14, NO_INV = PATCH ? 0 : 4;
+          constexpr int OR = FULL ? NO_JAC : 0, OI = OR + NO_RES, NO = OI + NO_INV;
+          const int ax = a & 1, ay = a >> 1;
+#pragma unroll 1
+          for (int j = 0; j < (active ? 3 : 0); ++j)
+            {
+              int cl = cl0;
+              asm volatile("" : "+v"(cl)); // the cell's nodal data are re-read from LDS per round, not pinned in registers
+              double O[NO];
+              {
+                // ---------------- phase A: q-point qa of this lane (the idle slots of the last round repeat q-point 8)
+                const int qa = min(4 * j + a, nq - 1);
+                const int qy = (qa * 11) >> 5, qx = qa - 3 * qy;
+                const double x1 = qx == 0 ? GX0 : (qx == 1 ? 0.5 : GX2), y1 = qy == 0 ? GX0 : (qy == 1 ? 0.5 : GX2);
+                const double x0 = 1.0 - x1, y0 = 1.0 - y1;
+                const double wq = (qx == 1 ? GW1 : GW0) * (qy == 1 ? GW1 : GW0);
+                const double Nl[4] = {x0 * y0, x1 * y0, x0 * y1, x1 * y1};
+                const double dNl[4][2] = {{-y0, -x0}, {y0, -x1}, {-y1, x0}, {y1, x1}};
+                double inv[2][2], det;
+                if constexpr (PATCH)
+                  {
+                    inv[0][0] = p_ihx;
+                    inv[1][1] = p_ihy;
+                    inv[0][1] = inv[1][0] = 0.0;
+                    det = p_det;
+                  }
+                else
+                  {
+                    double J[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+                    for (int vv = 0; vv < 4; ++vv)
+#pragma unroll
+                      for (int i = 0; i < 2; ++i)
+                        {
+                          const double xi = s_x[i][vv][cl];
+                          J[i][0] += xi * dNl[vv][0];
+                          J[i][1] += xi * dNl[vv][1];
+                        }
+                    det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+                    const double id = 1.0 / det;
+                    inv[0][0] = J[1][1] * id;
+                    inv[0][1] = -J[0][1] * id;
+                    inv[1][0] = -J[1][0] * id;
+                    inv[1][1] = J[0][0] * id;
+                  }
+                const double JxW = det * wq;
+                double gu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, gpf[2] = {0.0, 0.0}, pf = 0.0, pfo = 0.0, pfoo = 0.0;
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv)
+                  {
+                    double gv[2];
+                    if constexpr (PATCH)
+                      {
+                        gv[0] = inv[0][0] * dNl[vv][0];
+                        gv[1] = inv[1][1] * dNl[vv][1];
+                      }
+                    else
+                      {
+                        gv[0] = inv[0][0] * dNl[vv][0] + inv[1][0] * dNl[vv][1];
+                        gv[1] = inv[0][1] * dNl[vv][0] + inv[1][1] * dNl[vv][1];
+                      }
+                    const double ph = s_p[0][vv][cl];
+                    pf += ph * Nl[vv];
+                    pfo += s_p[1][vv][cl] * Nl[vv];
+                    pfoo += s_p[2][vv][cl] * Nl[vv];
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                      {
+                        gpf[d] += ph * gv[d];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                          gu[c][d] += s_u[c][vv][cl] * gv[d];
+                      }
+                  }
+                // q-point state, cracks.cc:2248-2306
+                if (monolithic)
+                  {
+                    pf = fmax(0.0, pf);
+                    pfo = fmax(0.0, pfo);
+                    pfoo = fmax(0.0, pfoo);
+                  }
+                const double pf_minus_old_plus = fmax(0.0, pf - pfo);
+                double pfx = pfoo + tfac * (pfo - pfoo);
+                if (pfx <= 0.0)
+                  pfx = 0.0;
+                if (pfx >= 1.0)
+                  pfx = 1.0;
+                if (prm.use_old_timestep_pf)
+                  pfx = pfo;
+                const double g = (1 - kappa) * pfx * pfx + kappa;
+                double E[2][2];
+                const double divu = gu[0][0] + gu[1][1];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                  for (int jj = 0; jj < 2; ++jj)
+                    E[i][jj] = 0.5 * (gu[i][jj] + gu[jj][i]);
+                const double trE = E[0][0] + E[1][1];
+                double sp[2][2], sm[2][2];
+                ortho_ok &= split_stress(E, trE, lam, mu, sp, sm);
+                double spE = 0.0; // scalar_product(stress_term_plus, E)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                  for (int jj = 0; jj < 2; ++jj)
+                    spE += sp[i][jj] * E[i][jj];
+                if constexpr (FULL)
+                  {
+                    const double cA = (1 - kappa) * pf * JxW, cB = 2.0 * aB1 * p * pf * JxW;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                      {
+                        double EL[2][2], spL[2][2], smL[2][2];
+                        EL[0][0] = k == 0 ? 1.0 : 0.0;
+                        EL[1][1] = k == 1 ? 1.0 : 0.0;
+                        EL[0][1] = EL[1][0] = k == 2 ? 0.5 : 0.0;
+                        ortho_ok &= split_stress_lin(E, trE, EL, k < 2 ? 1.0 : 0.0, lam, mu, spL, smL);
+                        double spLE = 0.0, spEL = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                          for (int jj = 0; jj < 2; ++jj)
+                            {
+                              spLE += spL[i][jj] * E[i][jj];
+                              spEL += sp[i][jj] * EL[i][jj];
+                            }
+                        O[0 * 3 + k] = (g * spL[0][0] + d_mat * smL[0][0]) * JxW;
+                        O[1 * 3 + k] = (g * spL[1][1] + d_mat * smL[1][1]) * JxW;
+                        O[2 * 3 + k] = (g * spL[0][1] + d_mat * smL[0][1]) * JxW;
+                        // row (a, phi): (1 - kappa) (sigma+_LinU : E + sigma+ : E_LinU) pf N_a - 2 (alpha - 1) p pf tr(E_LinU) N_a
+                        O[9 + k] = cA * (spLE + spEL) - (k < 2 ? cB : 0.0);
+                      }
+                    const double pen = ((pf - pfo) < 0.0) ? 0.0 : penal_fac; // shadowed variable, cracks.cc:2311-2315
+                    O[12] = (pen + (1 - kappa) * spE + Gc / eps - 2.0 * aB1 * p * divu) * JxW;
+                    O[13] = Gc * eps * JxW;
+                  }
+                // residual, cracks.cc:2393-2432: (g sigma+ + decompose_stress_rhs sigma- - (alpha - 1) p pfx^2 I) JxW for the rows
+                // (a, c); the factor of N_a and G_c eps grad(phi) JxW for the row (a, phi)
+                const double iso = aB1 * p * pfx * pfx;
+                O[OR + 0] = (g * sp[0][0] + d_rhs * sm[0][0] - iso) * JxW;
+                O[OR + 1] = (g * sp[1][1] + d_rhs * sm[1][1] - iso) * JxW;
+                O[OR + 2] = (g * sp[0][1] + d_rhs * sm[0][1]) * JxW;
+                O[OR + 3] = (penal_fac * pf_minus_old_plus + (1.0 - kappa) * spE * pf - Gc / eps * (1.0 - pf) - 2.0 * aB1 * p * pf * divu) * JxW;
+                O[OR + 4] = Gc * eps * JxW * gpf[0];
+                O[OR + 5] = Gc * eps * JxW * gpf[1];
+                if constexpr (!PATCH)
+                  {
+                    O[OI + 0] = inv[0][0];
+                    O[OI + 1] = inv[0][1];
+                    O[OI + 2] = inv[1][0];
+                    O[OI + 3] = inv[1][1];
+                  }
+              }
+              // ---------------- phase B: the q-points 4 j .. 4 j + 3 of the round, one after the other, all four lanes
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                {
+                  const int q = 4 * j + t;
+                  if (q >= nq) // (uniform)
+                    continue;
+                  double Q[NO];
+#pragma unroll
+                  for (int i = 0; i < NO; ++i)
+                    Q[i] = quad_bcast(O[i], t);
+                  // reference gradients at q (scalar loads), the lane's own vertex by its bits
+                  const double rx0 = refdN<2>(q, 2, 1), rx1 = refdN<2>(q, 3, 1), ry0 = refdN<2>(q, 1, 0), ry1 = refdN<2>(q, 3, 0);
+                  const double fxa = ax ? rx1 : rx0, fya = ay ? ry1 : ry0;
+                  const double Na = fxa * fya;
+                  const double dax = ax ? fya : -fya, day = ay ? fxa : -fxa; // d N_a / d xi, d eta
+                  double gNa[2], gN[4][2];
+                  if constexpr (PATCH)
+                    {
+                      gNa[0] = p_ihx * dax;
+                      gNa[1] = p_ihy * day;
+#pragma unroll
+                      for (int b = 0; b < 4; ++b)
+                        {
+                          gN[b][0] = p_ihx * refdN<2>(q, b, 0);
+                          gN[b][1] = p_ihy * refdN<2>(q, b, 1);
+                        }
+                    }
+                  else
+                    {
+                      gNa[0] = Q[OI + 0] * dax + Q[OI + 2] * day;
+                      gNa[1] = Q[OI + 1] * dax + Q[OI + 3] * day;
+#pragma unroll
+                      for (int b = 0; b < 4; ++b)
+                        {
+                          gN[b][0] = Q[OI + 0] * refdN<2>(q, b, 0) + Q[OI + 2] * refdN<2>(q, b, 1);
+                          gN[b][1] = Q[OI + 1] * refdN<2>(q, b, 0) + Q[OI + 3] * refdN<2>(q, b, 1);
+                        }
+                    }
+                  if constexpr (FULL)
+                    {
+                      // G = B_a^T (D JxW), B_a = [gNa_x 0; 0 gNa_y; gNa_y gNa_x]
+                      double G[2][3];
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        {
+                          G[0][k] = gNa[0] * Q[0 * 3 + k] + gNa[1] * Q[2 * 3 + k];
+                          G[1][k] = gNa[1] * Q[1 * 3 + k] + gNa[0] * Q[2 * 3 + k];
+                        }
+                      const double m0 = Na * Q[9], m1 = Na * Q[10], m2 = Na * Q[11];
+                      const double cpp = Na * Q[12], cgx = Q[13] * gNa[0], cgy = Q[13] * gNa[1];
+#pragma unroll
+                      for (int b = 0; b < 4; ++b)
+                        {
+                          const double gbx = gN[b][0], gby = gN[b][1];
+                          // trial dofs (b, d): rows (a, c) = sum_k G[c][k] B_b[k][d], B_b[.][0] = (gbx, 0, gby), B_b[.][1] = (0, gby, gbx)
+#pragma unroll
+                          for (int c = 0; c < 2; ++c)
+                            {
+                              Kuu[b][c][0] += G[c][0] * gbx + G[c][2] * gby;
+                              Kuu[b][c][1] += G[c][1] * gby + G[c][2] * gbx;
+                            }
+                          Kpu[b][0] += m0 * gbx + m2 * gby;
+                          Kpu[b][1] += m1 * gby + m2 * gbx;
+                          // trial dof (b, phi): rows (a, c < dim) get exactly 0 (cracks.cc:2333-2337)
+                          Kpp[b] += cpp * refN<2>(q, b) + (cgx * gbx + cgy * gby);
+                        }
+                    }
+                  R[0] -= Q[OR + 0] * gNa[0] + Q[OR + 2] * gNa[1];
+                  R[1] -= Q[OR + 2] * gNa[0] + Q[OR + 1] * gNa[1];
+                  R[2] -= Na * Q[OR + 3] + (Q[OR + 4] * gNa[0] + Q[OR + 5] * gNa[1]);
+                }
+            }
+        }
+      else
+        {
 #pragma unroll 1
       for (int q = 0; q < nq_run; ++q)
         {
@@ -324,23 +600,34 @@ namespace pfm
           asm volatile("" : "+v"(cl)); // the cell's nodal data are re-read from LDS per q-point, not pinned in registers
           // ---- fe_values.reinit at q: J, J^-1, JxW (MappingQ1)
           double J[dim][dim];
+          if constexpr (!PATCH)
+            {
 #pragma unroll
-          for (int i = 0; i < dim; ++i)
-#pragma unroll
-            for (int j = 0; j < dim; ++j)
-              J[i][j] = 0.0;
-#pragma unroll
-          for (int vv = 0; vv < nv; ++vv)
-#pragma unroll
-            for (int i = 0; i < dim; ++i)
-              {
-                const double xi = s_x[i][vv][cl];
+              for (int i = 0; i < dim; ++i)
 #pragma unroll
                 for (int j = 0; j < dim; ++j)
-                  J[i][j] += xi * refdN<dim>(q, vv, j);
-              }
+                  J[i][j] = 0.0;
+#pragma unroll
+              for (int vv = 0; vv < nv; ++vv)
+#pragma unroll
+                for (int i = 0; i < dim; ++i)
+                  {
+                    const double xi = s_x[i][vv][cl];
+#pragma unroll
+                    for (int j = 0; j < dim; ++j)
+                      J[i][j] += xi * refdN<dim>(q, vv, j);
+                  }
+            }
           double inv[dim][dim], det;
-          if constexpr (dim == 2)
+          if constexpr (PATCH)
+            {
+              // the cells of a patch block are exact axis-parallel rectangles (pfm_host.cpp: build_patches2d)
+              inv[0][0] = p_ihx;
+              inv[1][1] = p_ihy;
+              inv[0][1] = inv[1][0] = 0.0;
+              det = p_det;
+            }
+          else if constexpr (dim == 2)
             {
               det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
               const double id = 1.0 / det;
@@ -386,9 +673,14 @@ namespace pfm
               for (int d = 0; d < dim; ++d)
                 {
                   double s = 0.0;
+                  if constexpr (PATCH)
+                    s = inv[d][d] * refdN<dim>(q, vv, d);
+                  else
+                    {
 #pragma unroll
-                  for (int e = 0; e < dim; ++e)
-                    s += inv[e][d] * refdN<dim>(q, vv, e);
+                      for (int e = 0; e < dim; ++e)
+                        s += inv[e][d] * refdN<dim>(q, vv, e);
+                    }
                   gN[vv][d] = s;
                 }
               const double Nv = refN<dim>(q, vv);
@@ -411,9 +703,14 @@ namespace pfm
           for (int d = 0; d < dim; ++d)
             {
               double s = 0.0;
+              if constexpr (PATCH)
+                s = inv[d][d] * refdN<dim>(q, a, d);
+              else
+                {
 #pragma unroll
-              for (int e = 0; e < dim; ++e)
-                s += inv[e][d] * refdN<dim>(q, a, e);
+                  for (int e = 0; e < dim; ++e)
+                    s += inv[e][d] * refdN<dim>(q, a, e);
+                }
               gNa[d] = s;
             }
           const double Na = refN<dim>(q, a);
@@ -469,36 +766,35 @@ namespace pfm
               spE += sp[i][j] * E[i][j];
 
           // ---- Jacobian rows of vertex a, cracks.cc:2308-2389
-          // Stress split (2-D): the linearised split of trial dof (b, d) is the expensive part of a q-point (divisions,
-          // cracks.cc:1976-2109) and does not depend on the test vertex: the lane of vertex a evaluates it for b = a only
-          // and the four lanes of the cell exchange the results (a quad of the wave), instead of every lane evaluating
-          // all eight.
-          double mine[SPLIT && FULL ? dim : 1][9];
+          // Stress split (2-D): decompose_stress(derivative = true) (cracks.cc:1976-2109) is LINEAR in the direction E_LinU
+          // for a fixed strain, and E_LinU of trial dof (b, d) is sym(e_d (x) grad N_b): the linearised split of all eight
+          // trial dofs of the cell is the 3 x 3 tangent D (Voigt: 00, 11, 01) applied to grad N_b.  The lanes of vertex 0,
+          // 1, 2 of the cell evaluate the reference function for the unit directions e_0 e_0, e_1 e_1, sym(e_0 e_1) -- one
+          // call per lane and q-point instead of the two of round 3 (the lane of b for its own two trial dofs) -- fold
+          // g(phi) and decompose_stress_matrix in, and the quad exchanges 3 x 4 numbers instead of 8 x 9.  The products
+          // with grad N_b and grad N_a are then the usual B_a^T D B_b.
+          double mineD[SPLIT && FULL ? 4 : 1];
           if constexpr (FULL && SPLIT)
             {
+              const int k = a < 2 ? a : 2;
+              double EL[dim][dim], spL[dim][dim], smL[dim][dim];
+              EL[0][0] = k == 0 ? 1.0 : 0.0;
+              EL[1][1] = k == 1 ? 1.0 : 0.0;
+              EL[0][1] = EL[1][0] = k == 2 ? 0.5 : 0.0;
+              ortho_ok &= split_stress_lin(E, trE, EL, k < 2 ? 1.0 : 0.0, lam, mu, spL, smL);
+              double spLE = 0.0, spEL = 0.0;
 #pragma unroll
-              for (int d = 0; d < dim; ++d)
-                {
-                  double EL[dim][dim], spL[dim][dim], smL[dim][dim];
+              for (int i = 0; i < dim; ++i)
 #pragma unroll
-                  for (int i = 0; i < dim; ++i)
-#pragma unroll
-                    for (int j = 0; j < dim; ++j)
-                      EL[i][j] = 0.5 * ((i == d ? gNa[j] : 0.0) + (j == d ? gNa[i] : 0.0));
-                  ortho_ok &= split_stress_lin(E, trE, EL, gNa[d], lam, mu, spL, smL);
-                  double spLE = 0.0, spEL = 0.0;
-#pragma unroll
-                  for (int i = 0; i < dim; ++i)
-#pragma unroll
-                    for (int j = 0; j < dim; ++j)
-                      {
-                        spLE += spL[i][j] * E[i][j];
-                        spEL += sp[i][j] * EL[i][j];
-                        mine[d][i * dim + j] = spL[i][j];
-                        mine[d][4 + i * dim + j] = smL[i][j];
-                      }
-                  mine[d][8] = spLE + spEL;
-                }
+                for (int j = 0; j < dim; ++j)
+                  {
+                    spLE += spL[i][j] * E[i][j];
+                    spEL += sp[i][j] * EL[i][j];
+                  }
+              mineD[0] = g * spL[0][0] + d_mat * smL[0][0];
+              mineD[1] = g * spL[1][1] + d_mat * smL[1][1];
+              mineD[2] = g * spL[0][1] + d_mat * smL[0][1];
+              mineD[3] = spLE + spEL;
             }
           if constexpr (FULL && !SPLIT)
             {
@@ -559,88 +855,45 @@ namespace pfm
             }
           if constexpr (FULL && SPLIT)
             {
+              double D[3][3], lin[3]; // D[r][k]: stress component r (00, 11, 01) of unit direction k
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                {
+#pragma unroll
+                  for (int r = 0; r < 3; ++r)
+                    D[r][k] = quad_bcast(mineD[r], k);
+                  lin[k] = quad_bcast(mineD[3], k);
+                }
+              // G = (B_a^T D) JxW, B_a = [gNa_x 0; 0 gNa_y; gNa_y gNa_x]
+              const double gax = gNa[0] * JxW, gay = gNa[1] * JxW;
+              double G[dim][3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k)
+                {
+                  G[0][k] = gax * D[0][k] + gay * D[2][k];
+                  G[1][k] = gay * D[1][k] + gax * D[2][k];
+                }
+              const double NaW = Na * JxW;
+              const double cA = (1 - kappa) * pf * NaW, cB = 2.0 * aB1 * p * pf * NaW;
+              const double m0 = cA * lin[0] - cB, m1 = cA * lin[1] - cB, m2 = cA * lin[2];
+              const double cpp = ((1 - kappa) * spE + Gc / eps) * NaW - 2.0 * aB1 * p * divu * NaW, cgg = Gc * eps * JxW;
+              const double cpen = ((pf - pfo) < 0.0) ? 0.0 : penal_fac * NaW; // shadowed variable, cracks.cc:2311-2315
 #pragma unroll
               for (int b = 0; b < nv; ++b)
                 {
-                  const double Nb = refN<dim>(q, b);
-                  // trial dofs i = (b, d), displacement
+                  const double gbx = gN[b][0], gby = gN[b][1], Nb = refN<dim>(q, b);
+                  // trial dofs (b, d): rows (a, c) = sum_k G[c][k] B_b[k][d], B_b[.][0] = (gbx, 0, gby), B_b[.][1] = (0, gby, gbx)
 #pragma unroll
-                  for (int d = 0; d < dim; ++d)
+                  for (int c = 0; c < dim; ++c)
                     {
-                      // E_LinU = sym(e_d (x) grad N_b)
-                      double EL[dim][dim];
-#pragma unroll
-                      for (int i = 0; i < dim; ++i)
-#pragma unroll
-                        for (int j = 0; j < dim; ++j)
-                          EL[i][j] = 0.5 * ((i == d ? gN[b][j] : 0.0) + (j == d ? gN[b][i] : 0.0));
-                      const double trEL = gN[b][d]; // == divergence_u_LinU
-                      double spL[dim][dim], smL[dim][dim];
-                      double sum_split = 0.0; // spL:E + sp:EL as evaluated by the lane of vertex b
-                      if constexpr (SPLIT)
-                        {
-#pragma unroll
-                          for (int i = 0; i < dim; ++i)
-#pragma unroll
-                            for (int j = 0; j < dim; ++j)
-                              {
-                                spL[i][j] = quad_bcast(mine[d][i * dim + j], b);
-                                smL[i][j] = quad_bcast(mine[d][4 + i * dim + j], b);
-                              }
-                          sum_split = quad_bcast(mine[d][8], b);
-                        }
-                      else
-                        {
-#pragma unroll
-                          for (int i = 0; i < dim; ++i)
-#pragma unroll
-                            for (int j = 0; j < dim; ++j)
-                              {
-                                spL[i][j] = lam * trEL * (i == j ? 1.0 : 0.0) + 2 * mu * EL[i][j];
-                                smL[i][j] = 0.0;
-                              }
-                        }
-                      // rows (a, c), c < dim: scalar_product(sigma_LinU, e_c (x) grad N_a)
-#pragma unroll
-                      for (int c = 0; c < dim; ++c)
-                        {
-                          double t = 0.0, tm = 0.0;
-#pragma unroll
-                          for (int k = 0; k < dim; ++k)
-                            {
-                              t += g * spL[c][k] * gNa[k];
-                              tm += smL[c][k] * gNa[k];
-                            }
-                          Kuu[b][c][d] += (t + d_mat * tm) * JxW;
-                        }
-                      // row (a, phi)
-                      double spLE = 0.0, spEL = 0.0;
-                      if constexpr (!SPLIT)
-                        {
-#pragma unroll
-                          for (int i = 0; i < dim; ++i)
-#pragma unroll
-                            for (int j = 0; j < dim; ++j)
-                              {
-                                spLE += spL[i][j] * E[i][j];
-                                spEL += sp[i][j] * EL[i][j];
-                              }
-                        }
-                      const double lin = SPLIT ? sum_split : spLE + spEL;
-                      Kpu[b][d] += ((1 - kappa) * lin * pf * Na - 2.0 * aB1 * p * (pf * trEL) * Na) * JxW;
+                      Kuu[b][c][0] += G[c][0] * gbx + G[c][2] * gby;
+                      Kuu[b][c][1] += G[c][1] * gby + G[c][2] * gbx;
                     }
-                  // trial dof i = (b, phi): rows (a, c<dim) get exactly 0 (cracks.cc:2333-2337)
-                  {
-                    const double pen_i = ((pf - pfo) < 0.0) ? 0.0 : Nb; // shadowed variable, cracks.cc:2311-2315
-                    double gg = 0.0;
-#pragma unroll
-                    for (int k = 0; k < dim; ++k)
-                      gg += gN[b][k] * gNa[k];
-                    Kpp[b] += penal_fac * pen_i * Na * JxW;
-                    Kpp[b] += ((1 - kappa) * spE * Nb * Na + Gc / eps * Nb * Na + Gc * eps * gg -
-                               2.0 * aB1 * p * (Nb * divu) * Na) *
-                              JxW;
-                  }
+                  // row (a, phi): (1 - kappa) (sigma+_LinU : E + sigma+ : E_LinU) pf N_a - 2 (alpha - 1) p pf div(u_LinU) N_a
+                  Kpu[b][0] += m0 * gbx + m2 * gby;
+                  Kpu[b][1] += m1 * gby + m2 * gbx;
+                  // trial dof (b, phi): rows (a, c < dim) get exactly 0 (cracks.cc:2333-2337)
+                  Kpp[b] += (cpen + cpp) * Nb + cgg * (gbx * gNa[0] + gby * gNa[1]);
                 }
             }
 
@@ -671,6 +924,7 @@ namespace pfm
           }
             }
         } // q
+        }
 
       if (!ortho_ok)
         atomicMax(v.status, (int)PFM_ERR_NOT_ORTHOGONAL);
@@ -703,6 +957,7 @@ namespace pfm
 #pragma unroll 1
           for (int phase = 0; phase < nv; ++phase)
             {
+              // (ds_add_f64: a node receives one cell per phase, the lanes of a phase hit distinct addresses)
               if (mine && a == phase)
                 {
                   if constexpr (FULL)
@@ -715,60 +970,89 @@ namespace pfm
                           for (int c = 0; c < dim; ++c)
 #pragma unroll
                             for (int d = 0; d < dim; ++d)
-                              row[(c * 9 + o) * 3 + d] += Kuu[b][c][d];
+                              unsafeAtomicAdd(&row[(c * 9 + o) * 3 + d], Kuu[b][c][d]);
 #pragma unroll
                           for (int d = 0; d < dim; ++d)
-                            row[(dim * 9 + o) * 3 + d] += Kpu[b][d];
-                          row[(dim * 9 + o) * 3 + dim] += Kpp[b];
+                            unsafeAtomicAdd(&row[(dim * 9 + o) * 3 + d], Kpu[b][d]);
+                          unsafeAtomicAdd(&row[(dim * 9 + o) * 3 + dim], Kpp[b]);
                         }
 #pragma unroll
                       for (int c = 0; c < nc; ++c)
-                        row[84 + c] += diag[c] != 0.0 ? diag[c] : avg;
+                        unsafeAtomicAdd(&row[84 + c], diag[c] != 0.0 ? diag[c] : avg);
                     }
 #pragma unroll
                   for (int c = 0; c < nc; ++c)
-                    row[81 + c] += R[c];
+                    unsafeAtomicAdd(&row[81 + c], R[c]);
                 }
               __syncthreads();
             }
-          const int32_t *bn = v.patch_nodes + (long long)blockIdx.x * 81;
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           if constexpr (FULL)
             {
+              // one pass in the order of the destination: the 81 values of a row are contiguous (interleaved layout) or four
+              // contiguous pieces (blocked layout) -- whole lines, no read
               const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
               for (int e = tid; e < 49 * 81; e += 256)
                 {
                   const int nl = e / 81, r = e - nl * 81;
-                  const int hx = nl % 7 + 1, hy = nl / 7 + 1;
-                  const int node = bn[hx + 9 * hy];
-                  if (node < 0 || node >= v.n_owned || !v.row_patch[node])
+                  const long long off = s_off[nl];
+                  if (off < 0)
                     continue;
-                  const int c = r / 27, o = (r - c * 27) / 3, d = r % 3;
-                  const int nb = bn[(hx + o % 3 - 1) + 9 * (hy + o / 3 - 1)];
-                  const unsigned fA = v.node_flags[node], fQ = v.node_flags[nb];
-                  const bool rcon = (fA >> c) & 1u, ccon = (fQ >> d) & 1u;
-                  double val = s_row[nl * PRW + r];
-                  if (rcon || ccon)
-                    val = (rcon && o == 4 && d == c) ? s_row[nl * PRW + 84 + c] : 0.0;
-                  const long long off = v.nadj_ptr[node];
-                  const int sl = (int)((v.node_slots[node] >> (4 * o)) & 15ull);
+                  int c, sl, d;
                   double *dst;
                   if (il)
-                    dst = vals.b[0] + (9 * off + (long long)c * 27 + sl * 3 + d);
-                  else if (c < 2)
-                    dst = d < 2 ? vals.b[0] + (4 * off + (long long)c * 18 + sl * 2 + d) : vals.b[1] + (2 * off + (long long)c * 9 + sl);
+                    {
+                      c = r / 27;
+                      sl = (r - c * 27) / 3;
+                      d = r % 3;
+                      dst = vals.b[0] + (9 * off + r);
+                    }
+                  else if (r < 36)
+                    {
+                      c = r / 18;
+                      sl = (r - c * 18) / 2;
+                      d = r & 1;
+                      dst = vals.b[0] + (4 * off + r);
+                    }
+                  else if (r < 54)
+                    {
+                      c = (r - 36) / 9;
+                      sl = (r - 36) - c * 9;
+                      d = 2;
+                      dst = vals.b[1] + (2 * off + (r - 36));
+                    }
+                  else if (r < 72)
+                    {
+                      c = 2;
+                      sl = (r - 54) / 2;
+                      d = (r - 54) & 1;
+                      dst = vals.b[2] + (2 * off + (r - 54));
+                    }
                   else
-                    dst = d < 2 ? vals.b[2] + (2 * off + sl * 2 + d) : vals.b[3] + (off + sl);
+                    {
+                      c = 2;
+                      sl = r - 72;
+                      d = 2;
+                      dst = vals.b[3] + (off + (r - 72));
+                    }
+                  const int o = (int)((s_inv[nl] >> (4 * sl)) & 15ull);
+                  const int hx = nl % 7 + 1, hy = nl / 7 + 1;
+                  const unsigned fA = (unsigned)s_fl[hx + 9 * hy], fQ = (unsigned)s_fl[(hx + o % 3 - 1) + 9 * (hy + o / 3 - 1)];
+                  const bool rcon = (fA >> c) & 1u, ccon = (fQ >> d) & 1u;
+                  double val = s_row[nl * PRW + (c * 9 + o) * 3 + d];
+                  if (rcon || ccon)
+                    val = (rcon && o == 4 && d == c) ? s_row[nl * PRW + 84 + c] : 0.0;
                   *dst = val;
                 }
             }
           for (int e = tid; e < 49 * nc; e += 256)
             {
               const int nl = e / nc, c = e - nl * nc;
-              const int node = bn[(nl % 7 + 1) + 9 * (nl / 7 + 1)];
-              if (node < 0 || node >= v.n_owned || !v.row_patch[node])
+              if (s_off[nl] < 0)
                 continue;
-              const bool con = (v.node_flags[node] >> c) & 1u;
+              const int hp = (nl % 7 + 1) + 9 * (nl / 7 + 1);
+              const int node = s_bn[hp];
+              const bool con = ((unsigned)s_fl[hp] >> c) & 1u;
               const double rv = s_row[nl * PRW + 81 + c];
               const long long di = dof_index<dim>(v, node, c);
               res_pde[di] = con ? 0.0 : rv;

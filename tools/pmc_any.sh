@@ -10,13 +10,13 @@ python - <<PY
 import csv, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open("$O/raw/p_counter_collection.csv")):
-    acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    acc[r["Kernel_Name"][:105]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = {}
 for r in csv.DictReader(open("$O/raw2/p_kernel_stats.csv")):
-    dur[r["Name"][:70]] = (int(r["Calls"]), float(r["AverageNs"]))
+    dur[r["Name"][:105]] = (int(r["Calls"]), float(r["AverageNs"]))
 for k, d in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_INSTS_VALU", [0]))):
     m = {c: sum(v) / len(v) for c, v in d.items()}
     f = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0)
-    print("%-72s calls %4d avg %9.1f us  VALU %.3e FP64 %.3e (%.0f%%) LDS %.2e waves %.2e" % (k, dur.get(k, (0, 0))[0], dur.get(k, (0, 0))[1] / 1e3, m.get("SQ_INSTS_VALU", 0), f, 100 * f / max(m.get("SQ_INSTS_VALU", 1), 1), m.get("SQ_INSTS_LDS", 0), m.get("SQ_WAVES", 0)))
+    print("%-106s calls %4d avg %9.1f us  VALU %.3e FP64 %.3e (%.0f%%) LDS %.2e waves %.2e" % (k, dur.get(k, (0, 0))[0], dur.get(k, (0, 0))[1] / 1e3, m.get("SQ_INSTS_VALU", 0), f, 100 * f / max(m.get("SQ_INSTS_VALU", 1), 1), m.get("SQ_INSTS_LDS", 0), m.get("SQ_WAVES", 0)))
 PY
 rm -rf $O/raw $O/raw2

@@ -11,7 +11,7 @@ import csv, collections, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/raw/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"][:105]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
     m = {c: sum(v) / len(v) for c, v in d.items()}
     print(k)
