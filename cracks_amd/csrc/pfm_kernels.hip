@@ -989,61 +989,70 @@ namespace pfm
           const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
           if constexpr (FULL)
             {
-              // one pass in the order of the destination: the 81 values of a row are contiguous (interleaved layout) or four
-              // contiguous pieces (blocked layout) -- whole lines, no read
+              // in the order of the destination: the 81 values of a row are contiguous (interleaved layout) or four contiguous
+              // pieces (blocked layout) -- whole lines, no read.  A thread keeps its position r in the row (component pair and
+              // slot, decoded once) and walks over the nodes, three rows per pass of the workgroup.
               const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
-              for (int e = tid; e < 49 * 81; e += 256)
+              const int sub = tid / 81, r = tid - sub * 81;
+              int c, sl, d, piece, rr, mul;
+              if (il)
                 {
-                  const int nl = e / 81, r = e - nl * 81;
-                  const long long off = s_off[nl];
-                  if (off < 0)
-                    continue;
-                  int c, sl, d;
-                  double *dst;
-                  if (il)
-                    {
-                      c = r / 27;
-                      sl = (r - c * 27) / 3;
-                      d = r % 3;
-                      dst = vals.b[0] + (9 * off + r);
-                    }
-                  else if (r < 36)
-                    {
-                      c = r / 18;
-                      sl = (r - c * 18) / 2;
-                      d = r & 1;
-                      dst = vals.b[0] + (4 * off + r);
-                    }
-                  else if (r < 54)
-                    {
-                      c = (r - 36) / 9;
-                      sl = (r - 36) - c * 9;
-                      d = 2;
-                      dst = vals.b[1] + (2 * off + (r - 36));
-                    }
-                  else if (r < 72)
-                    {
-                      c = 2;
-                      sl = (r - 54) / 2;
-                      d = (r - 54) & 1;
-                      dst = vals.b[2] + (2 * off + (r - 54));
-                    }
-                  else
-                    {
-                      c = 2;
-                      sl = r - 72;
-                      d = 2;
-                      dst = vals.b[3] + (off + (r - 72));
-                    }
-                  const int o = (int)((s_inv[nl] >> (4 * sl)) & 15ull);
-                  const int hx = nl % 7 + 1, hy = nl / 7 + 1;
-                  const unsigned fA = (unsigned)s_fl[hx + 9 * hy], fQ = (unsigned)s_fl[(hx + o % 3 - 1) + 9 * (hy + o / 3 - 1)];
-                  const bool rcon = (fA >> c) & 1u, ccon = (fQ >> d) & 1u;
-                  double val = s_row[nl * PRW + (c * 9 + o) * 3 + d];
-                  if (rcon || ccon)
-                    val = (rcon && o == 4 && d == c) ? s_row[nl * PRW + 84 + c] : 0.0;
-                  *dst = val;
+                  c = r / 27;
+                  sl = (r - c * 27) / 3;
+                  d = r % 3;
+                  piece = 0, rr = r, mul = 9;
                 }
+              else if (r < 36)
+                {
+                  c = r / 18;
+                  sl = (r - c * 18) / 2;
+                  d = r & 1;
+                  piece = 0, rr = r, mul = 4;
+                }
+              else if (r < 54)
+                {
+                  c = (r - 36) / 9;
+                  sl = (r - 36) - c * 9;
+                  d = 2;
+                  piece = 1, rr = r - 36, mul = 2;
+                }
+              else if (r < 72)
+                {
+                  c = 2;
+                  sl = (r - 54) / 2;
+                  d = (r - 54) & 1;
+                  piece = 2, rr = r - 54, mul = 2;
+                }
+              else
+                {
+                  c = 2;
+                  sl = r - 72;
+                  d = 2;
+                  piece = 3, rr = r - 72, mul = 1;
+                }
+              double *const base = vals.b[piece] + rr;
+              const unsigned *inv32 = reinterpret_cast<const unsigned *>(s_inv) + (sl >= 8 ? 1 : 0);
+              const int sh = 4 * (sl & 7);
+              const int src0 = c * 27 + d;
+              if (sub < 3)
+                for (int nl = sub, hx = sub + 1, hy = 1; nl < 49; nl += 3)
+                  {
+                    const long long off = s_off[nl];
+                    const int hp = hx + 9 * hy;
+                    hx += 3;
+                    if (hx > 7)
+                      hx -= 7, ++hy;
+                    if (off < 0)
+                      continue;
+                    const int o = (int)((inv32[2 * nl] >> sh) & 15u);
+                    const int oy = (o * 11) >> 5; // o / 3
+                    const unsigned fA = (unsigned)s_fl[hp], fQ = (unsigned)s_fl[hp + o + 6 * oy - 10];
+                    const bool rcon = (fA >> c) & 1u, ccon = (fQ >> d) & 1u;
+                    double val = s_row[nl * PRW + src0 + 3 * o];
+                    if (rcon || ccon)
+                      val = (rcon && o == 4 && d == c) ? s_row[nl * PRW + 84 + c] : 0.0;
+                    base[mul * off] = val;
+                  }
             }
           for (int e = tid; e < 49 * nc; e += 256)
             {
