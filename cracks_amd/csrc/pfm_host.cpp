@@ -830,6 +830,28 @@ namespace
     const int n_blocks = (int)(blk_cells.size() / 64);
     if (n_blocks == 0)
       return;
+    // only the rows some block really writes are the patch kernel's (a level without a table above keeps its rows general)
+    {
+      std::vector<uint8_t> covered((size_t)N, 0);
+      n_regular = 0;
+      for (int b = 0; b < n_blocks; ++b)
+        for (int hy = 1; hy <= 7; ++hy)
+          for (int hx = 1; hx <= 7; ++hx)
+            {
+              const int32_t n = blk_nodes[(size_t)b * 81 + hx + 9 * hy];
+              if (n >= 0 && n < NO && regular[n] && !covered[n])
+                {
+                  covered[n] = 1;
+                  ++n_regular;
+                }
+            }
+      regular.swap(covered);
+    }
+    // the rows of the general family (zeroed before every Jacobian; the patch kernel stores its rows whole)
+    std::vector<int32_t> rows_general;
+    for (int32_t n = 0; n < NO; ++n)
+      if (!regular[n])
+        rows_general.push_back(n);
     // reduced lists of the general family: the cells that touch a row the patches do not write
     std::vector<uint8_t> need((size_t)NC, 0);
     for (int64_t k = 0; k < NC; ++k)
@@ -861,6 +883,10 @@ namespace
     c->d_node_slots = dev_alloc<unsigned long long>(c, (size_t)std::max<int32_t>(NO, 1));
     v.node_slots = c->d_node_slots;
     c->d_color_cells_reduced = dev_upload(c, order_red.data(), order_red.size());
+    c->n_rows_general = (int32_t)rows_general.size();
+    if (rows_general.empty())
+      rows_general.push_back(0);
+    c->d_rows_general = dev_upload(c, rows_general.data(), rows_general.size());
     c->n_patch_blocks = n_blocks;
     c->n_patch_rows = n_regular;
     c->patch_slots_valid = false;
@@ -2154,9 +2180,12 @@ extern "C"
             return fail(c, PFM_ERR_BAD_ARG, "null matrix block");
           // the row-owner kernels write every value once, the structurally zero (u,phi) block
           // of the blocked layout included (k_cart_phi4)
-          if (!cart)
+          if (!cart && !patches)
             e = hipMemsetAsync(d_values[b], 0, sizeof(double) * (size_t)c->block_nnz(b), c->stream);
         }
+    if (e == hipSuccess && patches && !residual_only && c->n_rows_general > 0 &&
+        launch_zero_rows(c->v, d_values, c->d_rows_general, c->n_rows_general, c->stream) != PFM_OK)
+      return fail(c, PFM_ERR_HIP, "zero the rows of the general family");
     if (e != hipSuccess)
       return hipfail(c, e, "zero outputs");
     // general family: the atomic class (cells with hanging vertices) on the side stream next to the colour classes, behind

@@ -183,6 +183,7 @@ namespace pfm
   int launch_assemble_patches(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *d_res_pde,
                               double *d_res_tot, int n_blocks, hipStream_t s);
   // fills DevView::node_slots from the current order of the node-graph rows (context creation, pfm_pattern_bind)
+  int launch_zero_rows(const DevView &v, double *const *d_values, const int32_t *rows, int n_rows, hipStream_t s);
   int launch_patch_slots(const DevView &v, unsigned long long *d_slots, int n_blocks, hipStream_t s);
 } // namespace pfm
 
@@ -235,6 +236,8 @@ struct pfm_ctx
   int64_t n_patch_rows = 0, n_general_cells = 0;
   unsigned long long *d_node_slots = nullptr;
   bool patch_slots_valid = false;
+  int32_t *d_rows_general = nullptr;        // owned nodes whose rows the general family writes in an overlay assembly
+  int32_t n_rows_general = 0;
   int32_t *d_color_cells_reduced = nullptr; // colour-sorted cells that touch a row the patches do not write
   std::vector<long long> color_ptr_reduced;
   uint8_t *d_cell_ring_reduced = nullptr;

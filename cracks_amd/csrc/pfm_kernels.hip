@@ -473,28 +473,18 @@ namespace pfm
                 if constexpr (FULL)
                   {
                     const double cA = (1 - kappa) * pf * JxW, cB = 2.0 * aB1 * p * pf * JxW;
+                    double spL[3][3], smL[3][3];
+                    ortho_ok &= split_tangent(E, trE, lam, mu, spL, smL);
+                    const double spELk[3] = {sp[0][0], sp[1][1], sp[0][1] * 0.5 + sp[1][0] * 0.5}; // sigma+ : E_LinU of direction k
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
                       {
-                        double EL[2][2], spL[2][2], smL[2][2];
-                        EL[0][0] = k == 0 ? 1.0 : 0.0;
-                        EL[1][1] = k == 1 ? 1.0 : 0.0;
-                        EL[0][1] = EL[1][0] = k == 2 ? 0.5 : 0.0;
-                        ortho_ok &= split_stress_lin(E, trE, EL, k < 2 ? 1.0 : 0.0, lam, mu, spL, smL);
-                        double spLE = 0.0, spEL = 0.0;
+                        const double spLE = spL[k][0] * E[0][0] + spL[k][2] * E[0][1] + spL[k][2] * E[1][0] + spL[k][1] * E[1][1];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                          for (int jj = 0; jj < 2; ++jj)
-                            {
-                              spLE += spL[i][jj] * E[i][jj];
-                              spEL += sp[i][jj] * EL[i][jj];
-                            }
-                        O[0 * 3 + k] = (g * spL[0][0] + d_mat * smL[0][0]) * JxW;
-                        O[1 * 3 + k] = (g * spL[1][1] + d_mat * smL[1][1]) * JxW;
-                        O[2 * 3 + k] = (g * spL[0][1] + d_mat * smL[0][1]) * JxW;
+                        for (int r = 0; r < 3; ++r)
+                          O[r * 3 + k] = (g * spL[k][r] + d_mat * smL[k][r]) * JxW;
                         // row (a, phi): (1 - kappa) (sigma+_LinU : E + sigma+ : E_LinU) pf N_a - 2 (alpha - 1) p pf tr(E_LinU) N_a
-                        O[9 + k] = cA * (spLE + spEL) - (k < 2 ? cB : 0.0);
+                        O[9 + k] = cA * (spLE + spELk[k]) - (k < 2 ? cB : 0.0);
                       }
                     const double pen = ((pf - pfo) < 0.0) ? 0.0 : penal_fac; // shadowed variable, cracks.cc:2311-2315
                     O[12] = (pen + (1 - kappa) * spE + Gc / eps - 2.0 * aB1 * p * divu) * JxW;
@@ -1653,6 +1643,46 @@ namespace pfm
       slots[node] = packed;
     }
   } // namespace
+
+  namespace
+  {
+    // overlay assemblies: only the rows of the general family are added to and need zeros (one wave per row)
+    __global__ void k_zero_rows(DevView v, Vals vals, const int32_t *__restrict__ rows, int n_rows)
+    {
+      const int w = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+      if (w >= n_rows)
+        return;
+      const int node = rows[w];
+      const long long off = v.nadj_ptr[node], deg = v.nadj_ptr[node + 1] - off;
+      const int nc = v.dim + 1, dim = v.dim;
+      if (v.layout == PFM_LAYOUT_INTERLEAVED)
+        {
+          for (long long i = lane; i < nc * nc * deg; i += 64)
+            vals.b[0][nc * nc * off + i] = 0.0;
+          return;
+        }
+      for (long long i = lane; i < dim * dim * deg; i += 64)
+        vals.b[0][dim * dim * off + i] = 0.0;
+      for (long long i = lane; i < dim * deg; i += 64)
+        {
+          vals.b[1][dim * off + i] = 0.0;
+          vals.b[2][dim * off + i] = 0.0;
+        }
+      for (long long i = lane; i < deg; i += 64)
+        vals.b[3][off + i] = 0.0;
+    }
+  } // namespace
+
+  int launch_zero_rows(const DevView &v, double *const *d_values, const int32_t *rows, int n_rows, hipStream_t s)
+  {
+    if (n_rows <= 0)
+      return PFM_OK;
+    Vals vals{};
+    for (int b = 0; b < (v.layout == PFM_LAYOUT_BLOCKED ? 4 : 1); ++b)
+      vals.b[b] = d_values[b];
+    hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)(((long long)n_rows * 64 + 255) / 256)), dim3(256), 0, s, v, vals, rows, n_rows);
+    return check_launch();
+  }
 
   int launch_patch_slots(const DevView &v, unsigned long long *d_slots, int n_blocks, hipStream_t s)
   {
