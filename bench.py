@@ -322,7 +322,91 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
     wall, k_ms = time_mode(a2, dev, False, steps, 2)
     record("jacobian_2d", 2, n2, False, wall, k_ms, n2 * n2, 3 * (n2 + 1) ** 2)
     a2.ctx.close()
+    try:
+        out["config5_standin"] = config5_standin(dev, local_rank, steps)
+    except Exception as e:  # a missing mesh helper must not take the other lines away
+        out["config5_standin"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def config5_problem(levels: int, step: int):
+    """Stand-in for BASELINE config 5 (Miehe shear with adaptive refinement, cracks.cc:4137-4174): unit-slit square,
+    2^(levels+1) cells per edge, a band of refined cells with hanging nodes along the crack that grows with `step`,
+    one-block (direct solver) layout, stress split active.  Returns mesh, layout, parameters, node flags and the three
+    vectors."""
+    from cracks_amd import mesh as M
+    from cracks_amd.assembler import node_flags_from_dof_flags
+    from cracks_amd.capi import PfmParams
+
+    base = M.slit_mesh(levels)
+    n = 2 ** (levels + 1)
+    h = 1.0 / n
+    tip = 0.5 - 0.08 * step  # the band follows a crack growing to the left
+    cc = base.coords[base.cells].mean(axis=1)
+    flags = (np.abs(cc[:, 1] - 0.5) < 6 * h) & (cc[:, 0] > tip - 4 * h)
+    t0 = time.perf_counter()
+    mesh = M.refine_cells(base, flags)
+    t_refine = time.perf_counter() - t0
+    lay = M.DofLayout(mesh.n_nodes, 2, blocked=False)
+    hfine = 0.5 * h
+    dt = 1.0e-4
+    prm = PfmParams(lambda_=121.15e3, mu=80.77e3, G_c=2.7, alpha_eps=2.0 * hfine * np.sqrt(2.0),
+                    constant_k=1.0e-10 * hfine, pressure=0.0, alpha_biot=0.0, gamma_penal=0.0, timestep=dt,
+                    time=5 * dt, old_timestep=dt, old_old_timestep=dt, decompose_stress_rhs=1.0,
+                    decompose_stress_matrix=1.0, timestep_number=5, outer_solver=0, use_old_timestep_pf=0,
+                    reserved=0)
+    ch = M.hanging_constraints(mesh, lay)
+    cu = M.update_constraints(mesh, lay, M.miehe_shear_dirichlet_dofs(mesh, lay))
+    # state: shear ramp + noise, phase field with a smeared crack along the slit line
+    rng = np.random.default_rng(1234 + step)
+    x, y = mesh.coords[:, 0], mesh.coords[:, 1]
+    u = np.stack([-5 * dt * y + 1e-6 * rng.standard_normal(x.size), 1e-6 * rng.standard_normal(x.size)], axis=1)
+    phi = np.clip(1.0 - np.exp(-np.abs(y - 0.5) / (4 * hfine)) * (x > tip), 0.0, 1.0)
+    sol = ch.distribute(lay.pack(u, phi))
+    old = ch.distribute(lay.pack(0.9 * u, np.clip(phi + 0.01 * rng.random(x.size), 0, 1)))
+    oldold = ch.distribute(lay.pack(0.8 * u, np.clip(phi + 0.02 * rng.random(x.size), 0, 1)))
+    return {"mesh": mesh, "layout": lay, "params": prm, "cu": cu, "ch": ch, "refine_host_s": t_refine,
+            "node_flags": node_flags_from_dof_flags(lay, cu.flag, ch.flag), "vectors": (sol, old, oldold)}
+
+
+def config5_standin(dev, local_rank, steps: int, levels: int = 8):
+    """The config-5 stand-in in the driver's run: two meshes of the adaptive sequence (the first context of a process pays
+    one-time module loads), per-call times of the second one: Jacobian + residual, residual only, context rebuild."""
+    import torch
+
+    from cracks_amd.assembler import Assembler
+
+    rec = {}
+    for step in range(2):
+        pb = config5_problem(levels, step)
+        mesh, lay = pb["mesh"], pb["layout"]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        asm = Assembler(mesh, blocked=False, device=local_rank)
+        asm.allocate_matrix()
+        asm.set_params(pb["params"])
+        asm.set_constraints(pb["node_flags"])
+        torch.cuda.synchronize(dev)
+        t_ctx = time.perf_counter() - t0
+        asm.set_vectors(*pb["vectors"])
+        if step == 1:
+            w_j, k_j = time_mode(asm, dev, False, steps, 3)
+            w_r, k_r = time_mode(asm, dev, True, 2 * steps, 3)
+            rows, cells = asm.ctx.overlay_info()
+            ab_j, ab_r = algorithmic_bytes_per_cell(2, False), algorithmic_bytes_per_cell(2, True)
+            rec = {"workload": f"unit-slit square, {2 ** (levels + 1)}^2 base cells + refined band, stress split on, one-block layout",
+                   "cells": int(mesh.n_cells), "dofs": int(lay.n_dofs), "hanging_nodes": int(mesh.hn_nodes.size),
+                   "kernel_path": int(asm.ctx.kernel_path),
+                   "overlay": {"rows_of_the_patch_kernel": int(rows), "cells_left_to_the_general_family": int(cells)},
+                   "jacobian_ms": w_j, "jacobian_kernel_ms": k_j, "residual_only_ms": w_r, "residual_only_kernel_ms": k_r,
+                   "jacobian_hbm_frac": ab_j * mesh.n_cells / (w_j * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "residual_only_hbm_frac": ab_r * mesh.n_cells / (w_r * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "algorithmic_bytes_per_cell": {"jacobian": ab_j, "residual_only": ab_r},
+                   "context_rebuild_ms": 1e3 * t_ctx,
+                   "context_rebuild_note": "pfm_ctx_create + pattern + pfm_set_params + pfm_set_constraints after refine_mesh, second mesh of the sequence",
+                   "DoFs_per_s_jacobian": lay.n_dofs / (w_j * 1e-3)}
+        asm.ctx.close()
+    return rec
 
 
 def d2h_bandwidth(dev, gib: float = 2.0):

@@ -620,7 +620,7 @@ namespace pfm
       for (int b = 0; b < (v.layout == PFM_LAYOUT_BLOCKED ? 4 : 1); ++b)
         vals.b[b] = d_values[b];
     if (split)
-      return PFM_ERR_UNSUPPORTED; // stress-split runs are not a moment of a q-point field: see pfm_cart2d_split.hip / the general family
+      return PFM_ERR_UNSUPPORTED; // stress-split runs are not a moment of a q-point field: they take the general family with the cartesian overlay (pfm_kernels.hip, PATCH; kernel path 3)
     if (residual_only)
       return PFM_ERR_UNSUPPORTED; // residual-only 2-D assemblies: k_cart_residual2m (pfm_cart.hip)
     if (cv.o1[0] < cv.o0[0] || cv.o1[1] < cv.o0[1])

@@ -1,5 +1,5 @@
 // pfm_split.h — 2-D stress split on the device (decompose_stress + eigen_vectors_and_values, cracks.cc:1691-1737,
-// 1923-2120), shared by the general cell kernel (pfm_kernels.hip) and the 2-D row-owner kernel (pfm_cart2d.hip).
+// 1923-2120), used by the general cell kernel and its patch form (pfm_kernels.hip).
 // The closed forms are the reference's; its divisions are taken as products with shared reciprocals (see below).  The IEEE
 // corner cases (diagonal / zero strain: 0/0 and x/0 in the derivative branch) produce the reference's NaN / Inf pattern
 // (tests/test_gpu_split_corners.py).

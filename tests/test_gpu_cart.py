@@ -481,3 +481,16 @@ def test_assemble_nl_residual_device_reads_the_solution_itself(dim, n, blocked):
     A = blocks_to_global(ctx, c.layout, [v.cpu().numpy() for v in vals])
     A.sort_indices()
     assert linf_scaled(A.data, A_ref.data) < TOL and linf_scaled(bufs[0].cpu().numpy(), r.residual_pde) < TOL
+
+
+def test_bench_reports_the_config5_standin():
+    """bench.py's `extra.config5_standin`: the adaptive stress-split stand-in runs through the general
+    family + cartesian overlay (kernel path 3) and the record carries the times, the roofline fraction and the rebuild."""
+    import bench
+
+    rec = bench.config5_standin("cuda:0", 0, steps=3, levels=5)
+    assert rec["kernel_path"] == 3
+    assert rec["overlay"]["rows_of_the_patch_kernel"] > 0.5 * rec["dofs"] / 3
+    for key in ("jacobian_ms", "residual_only_ms", "context_rebuild_ms", "jacobian_hbm_frac"):
+        assert rec[key] > 0.0
+    assert rec["hanging_nodes"] > 0

@@ -36,35 +36,14 @@ def config5(args):
     from cracks_amd.assembler import Assembler, node_flags_from_dof_flags
     from cracks_amd.capi import PfmParams
 
+    import bench as B
+
     rows = []
-    base = M.slit_mesh(args.levels)  # 2^(levels+1) cells per edge
-    n = 2 ** (args.levels + 1)
-    h = 1.0 / n
     for step in range(args.meshes):
-        tip = 0.5 - 0.08 * step  # the band follows a crack growing to the left
-        cc = base.coords[base.cells].mean(axis=1)
-        flags = (np.abs(cc[:, 1] - 0.5) < 6 * h) & (cc[:, 0] > tip - 4 * h)
-        t0 = time.perf_counter()
-        mesh = M.refine_cells(base, flags)
-        t_refine = time.perf_counter() - t0
-        lay = M.DofLayout(mesh.n_nodes, 2, blocked=False)
-        hfine = 0.5 * h
-        dt = 1.0e-4
-        prm = PfmParams(lambda_=121.15e3, mu=80.77e3, G_c=2.7, alpha_eps=2.0 * hfine * np.sqrt(2.0),
-                        constant_k=1.0e-10 * hfine, pressure=0.0, alpha_biot=0.0, gamma_penal=0.0, timestep=dt,
-                        time=5 * dt, old_timestep=dt, old_old_timestep=dt, decompose_stress_rhs=1.0,
-                        decompose_stress_matrix=1.0, timestep_number=5, outer_solver=0, use_old_timestep_pf=0,
-                        reserved=0)
-        ch = M.hanging_constraints(mesh, lay)
-        cu = M.update_constraints(mesh, lay, M.miehe_shear_dirichlet_dofs(mesh, lay))
-        # state: shear ramp + noise, phase field with a smeared crack along the slit line
-        rng = np.random.default_rng(1234 + step)
-        x, y = mesh.coords[:, 0], mesh.coords[:, 1]
-        u = np.stack([-5 * dt * y + 1e-6 * rng.standard_normal(x.size), 1e-6 * rng.standard_normal(x.size)], axis=1)
-        phi = np.clip(1.0 - np.exp(-np.abs(y - 0.5) / (4 * hfine)) * (x > tip), 0.0, 1.0)
-        sol = ch.distribute(lay.pack(u, phi))
-        old = ch.distribute(lay.pack(0.9 * u, np.clip(phi + 0.01 * rng.random(x.size), 0, 1)))
-        oldold = ch.distribute(lay.pack(0.8 * u, np.clip(phi + 0.02 * rng.random(x.size), 0, 1)))
+        pb = B.config5_problem(args.levels, step)
+        mesh, lay, prm, cu, ch = pb["mesh"], pb["layout"], pb["params"], pb["cu"], pb["ch"]
+        t_refine = pb["refine_host_s"]
+        sol, old, oldold = pb["vectors"]
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -156,7 +135,7 @@ def config5(args):
         print(rows[-1], flush=True)
         del asm
     out = {"config": "SURVEY §8(d) config 5 stand-in: unit slit, %d^2 base cells, refined band, one-block layout, "
-                     "stress split active, single MI355X" % n, "rows": rows}
+                     "stress split active, single MI355X" % (2 ** (args.levels + 1)), "rows": rows}
     if args.out:
         json.dump(out, open(os.path.join(ROOT, args.out), "w"), indent=1)
 

@@ -11,7 +11,6 @@ python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err
 python bench.py --residual-only --no-cpu-baseline --no-extras > $O/bench_216cube_residual_only.json 2>/dev/null
 python bench.py --dim 2 --residual-only --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
 python bench.py --dim 2 --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
-PFM_UU4=1 PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_216cube_uu4.json 2>/dev/null
 PFM_RES_KERNEL=1 python bench.py --no-cpu-baseline --no-extras > $O/bench_216cube_residual_kernel.json 2>/dev/null
 python bench.py --n 100 --path general --no-cpu-baseline --no-extras --steps 5 > $O/bench_100cube_general.json 2>/dev/null
 python bench.py --dim 2 --path general --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_general.json 2>/dev/null
@@ -47,6 +46,14 @@ mix 3d_216
 mix 3d_216_residual --residual-only
 mix 2d_1000 --dim 2
 mix 2d_1000_residual --dim 2 --residual-only
+# config-5 stand-in (general family + cartesian overlay): per-kernel times and instruction mix of one mesh of the sequence
+run_prof stats_c5 --stats --output-format csv -d $O/stats_c5 -o p -- python $R/tools/bench_extra.py config5 --levels 8 --meshes 1 --world 1
+cp $O/stats_c5/p_kernel_stats.csv $O/rocprofv3_kernel_stats_config5.csv 2>/dev/null
+run_prof pmc_mix_c5 --pmc $MIX --output-format csv -d $O/pmc_mix_c5 -o p -- python $R/tools/bench_extra.py config5 --levels 8 --meshes 1 --world 1
+cp $O/pmc_mix_c5/p_counter_collection.csv $O/rocprofv3_pmc_MIX_config5.csv 2>/dev/null
+run_prof pmc_sq_c5 --pmc $SQ --output-format csv -d $O/pmc_sq_c5 -o p -- python $R/tools/bench_extra.py config5 --levels 8 --meshes 1 --world 1
+cp $O/pmc_sq_c5/p_counter_collection.csv $O/rocprofv3_pmc_SQ_config5.csv 2>/dev/null
+rm -rf $O/stats_c5 $O/pmc_mix_c5 $O/pmc_sq_c5
 python - <<PY
 import csv, collections, json, re
 O = "$O"
@@ -63,7 +70,7 @@ res = collections.defaultdict(dict)
 for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
     for k, d in per_kernel(f"{O}/rocprofv3_pmc_{ctr}_216cube.csv").items():
         res[k][ctr.lower().replace("_size", "_bytes")] = d[ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0)
-keep = ("k_cart_residual3", "k_cart_uu3", "k_cart_uu4", "k_cart_uu5", "k_cart_phi4", "k_state_set")
+keep = ("k_cart_residual3", "k_cart_uu3", "k_cart_phi4", "k_state_set")
 json.dump({"args": "--steps 3 --warmup 1 --no-cpu-baseline --no-extras", "kernel_source_hash": HASH, "per_launch": {k: v for k, v in res.items() if k in keep}},
           open(f"{O}/hbm_traffic_3d_216.json", "w"), indent=1)
 for tag in ("3d_216", "3d_216_residual", "2d_1000", "2d_1000_residual"):
@@ -98,7 +105,7 @@ cd $R && python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err; cd /tm
 grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
 python -c "
 import json
-for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residual_only','bench_2d_1000sq_jacobian','bench_216cube_uu4','bench_216cube_residual_kernel','bench_100cube_general','bench_2d_1000sq_general'):
+for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residual_only','bench_2d_1000sq_jacobian','bench_216cube_residual_kernel','bench_100cube_general','bench_2d_1000sq_general'):
     try:
         d=json.load(open('$O/'+f+'.json')); r=d['roofline']; print(f, 'ms/step %.3f kernel_ms %.3f median %.3f frac %.4f value %.3e ctx_create %s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['frac'], d['value'], d['config'].get('ctx_create_s')))
     except Exception as e: print(f, 'FAILED', e)
