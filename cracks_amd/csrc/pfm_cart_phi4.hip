@@ -45,13 +45,14 @@ namespace pfm
     constexpr int SLAB_PU = NPN * 27, SLAB_PP = NPN * 9;
 
 
+    template <int NF /* 6 with the old phase fields (penalisation term: gamma != 0), else 4 */>
     struct Lds4
     {
       // destinations of the global -> LDS transfers first: M0 carries a 16-bit LDS offset
-      double U[2][6][NPH];   // nodal ring: u_x u_y u_z phi phi_old phi_oldold
+      double U[2][NF][NPH];  // nodal ring: u_x u_y u_z phi [phi_old phi_oldold]
       long long off[2][NPN]; // node-graph offset of the row, -1 = not an owned node of this tile
       int deg[2][NPN];       // neighbour mask of the row (bit o: lattice offset o exists)
-      unsigned char flag[4][NPH];
+      unsigned flag[4][2 * NPH]; // constraint flag byte of the halo nodes of 4 planes, one dword per requesting lane: node hn at [2 hn]
       int irregular[2];
       int anyflag[4];
       double pu[5][SLAB_PU]; // staged (phi,u) rows: [0,1] oz=-1 ring, [2,3] oz=0 ring, [4] oz=+1; [node][o9][d]
@@ -71,6 +72,16 @@ namespace pfm
       const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(byte_off), "s"(base), "s"(l)
+                   : "memory");
+    }
+    // one byte per lane, zero-extended to the lane's dword in LDS
+    __device__ __forceinline__ void dma_u8(const void *base, unsigned byte_off, void *lds)
+    {
+      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(byte_off), "s"(base), "s"(l)
                    : "memory");
@@ -147,6 +158,7 @@ namespace pfm
         }
     }
 
+    static_assert(sizeof(Lds4<4>) <= 64 * 1280, "two workgroups per CU: 64 allocation granules of LDS each");
     struct PushDst // staged rows the 8 vertices of a cell push into
     {
       double *lo_z0, *lo_p1; // current plane: oz = 0 and oz = +1 slabs (lower vertices)
@@ -306,13 +318,13 @@ namespace pfm
     }
 
     // ---- role 3: (phi,phi) entries of one cell, same scheme; returns the 8 diagonal entries of the element matrix
-    template <bool HET>
+    template <bool HET, bool OLDF>
     __device__ __forceinline__ void pp_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
                                             double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
                                             double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
                                             double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
     {
-      const bool use_pen = S.gamma_fac != 0.0;
+      const bool use_pen = OLDF && S.gamma_fac != 0.0; // (the launcher instantiates OLDF exactly when gamma != 0)
       double M[27]; // M[g_x + 3 g_y + 9 g_z]
 #pragma unroll
       for (int m = 0; m < 27; ++m)
@@ -349,11 +361,14 @@ namespace pfm
                   });
                   line_of_field<false, false>(V[3], ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[3], dummy, dummy);
                   L[4][0] = L[4][1] = 0.0;
-                  if (use_pen) // phi_old enters only through the penalisation term (gamma != 0: monolithic runs)
+                  if constexpr (OLDF)
                     {
-                      double Vo[8];
-                      load_cell_field_raw(Ulo + 4 * NPH, Uhi + 4 * NPH, Vo);
-                      line_of_field<false, false>(Vo, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy, dummy);
+                      if (use_pen) // phi_old enters only through the penalisation term (gamma != 0: monolithic runs)
+                        {
+                          double Vo[8];
+                          load_cell_field_raw(Ulo + 4 * NPH, Uhi + 4 * NPH, Vo);
+                          line_of_field<false, false>(Vo, ny0, ny1, nz0, nz1, S.ih[1], S.ih[2], L[4], dummy, dummy);
+                        }
                     }
                   double Dx[3];
 #pragma unroll
@@ -439,14 +454,17 @@ namespace pfm
     // =====================================================================================
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */,
               bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
-              bool RES = false /* also writes the phase-field rows of the residual (res_pde) */>
+              bool RES = false /* also writes the phase-field rows of the residual (res_pde) */,
+              bool OLDF = false /* phi_old / phi_oldold in the nodal ring (penalisation term); else fetched where the rare
+                                   placeholder path needs them */>
     __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
                                                           double *__restrict__ vals_up /* blocked layout: structurally zero (u,phi) block, cleared here */,
                                                           int zc_in /* node planes per chunk */,
                                                           unsigned long long *__restrict__ dbg, double *__restrict__ res_pde)
     {
-      __shared__ Lds4 s;
+      constexpr int NF = OLDF ? 6 : 4;
+      __shared__ Lds4<NF> s;
       // wave priorities per phase (the requests and the copy-out are a few instructions with long latencies: issued ahead
       // of the co-resident workgroup's arithmetic they finish sooner and cost it nothing measurable; -0.2 ms at 216^3).
       // PFM_NO_PRIO=1 switches them off (A/B runs): the launcher then passes the chunk length negated
@@ -488,8 +506,9 @@ namespace pfm
       // = 162 dwords), one node id per lane; their even lanes also fetch the node's flag byte, which goes through a
       // register (sub-dword transfers to LDS would still occupy one dword per lane) and is stored at the end of the
       // step.  Wave 3: value offset (64-bit: 98 dwords) and neighbour mask of the 49 rows.
-      unsigned pf = 0u; // flag byte in flight
-      bool pf_ok = false;
+      // (round 4: the flag byte travels global -> LDS like everything else.  As a register load it was live across the
+      // march and the compiler waited for it with vmcnt(0) at the entry of every role, right behind the requests -- which
+      // made them synchronous -- and behind the copy-out stores -- which made every wave drain its own stores.)
       // node id of the lane's halo dword in plane kz (role < 3) -- SEPARATE from the requests: cart_local_id may look the id up
       // in the lattice table (a load inside a branch, which the compiler waits for at the join with vmcnt(0)); with the
       // transfers of the same step already in flight that wait made them synchronous (round 4: ids of the plane AND of
@@ -504,26 +523,24 @@ namespace pfm
         ok = role < 3 && inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
         return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
       };
-      auto dma_plane_at = [&](unsigned n, bool ok, bool inside, int dw, int buf) __attribute__((always_inline)) {
+      auto dma_plane_at = [&](unsigned n, bool ok, bool inside, int dw, int buf, int kz) __attribute__((always_inline)) {
         if (role < 3)
           {
             const unsigned boff = 8u * n + 4u * (dw & 1);
             const double *const fld[6] = {v.u[0], v.u[1], v.u[2], v.phi, v.phi_old, v.phi_oldold};
-            // the flag byte: an unconditional load (n = 0 where there is no node), the validity is applied when it is stored
-            // (flags_put) -- loaded inside the branch below it would be waited for at the join, behind the transfers
-            pf = v.node_flags[n];
-            pf_ok = ok && (dw & 1) == 0;
             if (ok)
               {
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
+                for (int c = 0; c < NF; ++c)
                   dma_b32(fld[c], boff, reinterpret_cast<uint32_t *>(&s.U[buf][c][0]) + 64 * role);
+                dma_u8(v.node_flags, n, &s.flag[kz & 3][0] + 64 * role); // both lanes of a node fetch its byte: [2 hn] is read
               }
             else if (inside)
               {
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
+                for (int c = 0; c < NF; ++c)
                   reinterpret_cast<uint32_t *>(&s.U[buf][c][0])[dw] = 0u;
+                s.flag[kz & 3][dw] = 0u;
               }
           }
       };
@@ -531,12 +548,7 @@ namespace pfm
         bool ok, inside;
         int dw;
         const unsigned n = plane_node(kz, ok, inside, dw);
-        dma_plane_at(n, ok, inside, dw, buf);
-      };
-      auto flags_put = [&](int kz) __attribute__((always_inline)) {
-        const int dw = 64 * role + lane;
-        if (role < 3 && (dw & 1) == 0 && dw < 2 * NPH)
-          s.flag[kz & 3][dw >> 1] = (unsigned char)(pf_ok ? pf : 0u);
+        dma_plane_at(n, ok, inside, dw, buf, kz);
       };
       auto rows_node = [&](int kz, bool &ok) __attribute__((always_inline)) -> unsigned {
         int lq = lane;
@@ -584,13 +596,12 @@ namespace pfm
       if (t < 4)
         s.anyflag[t] = 0;
       dma_plane(kA - 1, 0);
-      flags_put(kA - 1);
       dma_plane(kA, 1);
-      flags_put(kA);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (t < NPH && s.flag[(kA - 1) & 3][t])
+      if (t < NPH && s.flag[(kA - 1) & 3][2 * t])
         s.anyflag[(kA - 1) & 3] = 1;
+      int nst = 0;       // lower bound of the vector-memory instructions this wave has issued behind its last requests
       double r_m1 = 0.0; // RES, wave 3, lane <-> node: the oz = -1 part of K_phiphi phi of the next plane
 #pragma unroll 1
       for (int ck = kA - 1; ck < kB; ++ck)
@@ -600,8 +611,15 @@ namespace pfm
           stamp(3);
           if constexpr (CLK == 2)
             tclk = clock64();
-          // plane ck + 1 and the rows of plane ck were requested before the previous step's copy-out
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // plane ck + 1 and the rows of plane ck were requested before the previous step's copy-out.  vmcnt counts loads
+          // and stores in issue order: with at least 28 stores issued behind the requests (fast blocked copy-out: 7 y-lines x
+          // 4 unconditional stores per wave), "at most 28 outstanding" means the requests have landed -- the wave does not
+          // wait for its own stores to drain, they have the whole next role phase for that
+          if (nst >= 28)
+            asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          nst = 0;
           if (t == 0)
             {
               s.anyflag[(ck + 1) & 3] = 0;
@@ -609,7 +627,7 @@ namespace pfm
             }
           lds_barrier();
           stamp(0);
-          if (t < NPH && s.flag[(ck + 1) & 3][t])
+          if (t < NPH && s.flag[(ck + 1) & 3][2 * t])
             s.anyflag[(ck + 1) & 3] = 1;
           if (ck >= kA && t >= 128 && t < 128 + NPN && s.off[cp][t - 128] >= 0 && s.deg[cp][t - 128] != 0x7ffffff)
             s.irregular[cp] = 1;
@@ -644,7 +662,7 @@ namespace pfm
           else
             {
               double Mdiag[8];
-              pp_role<HET>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+              pp_role<HET, OLDF>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
               double avg = 0.0, patch = 0.0;
               if (cell_ok)
                 {
@@ -660,18 +678,30 @@ namespace pfm
                       const double dg = fabs(Mdiag[a]);
                       dsum += dg;
                       zero_diag = zero_diag || dg == 0.0;
-                      anyflag |= s.flag[(ck + (a >> 2)) & 3][hb + (a & 1) + PH * ((a >> 1) & 1)];
+                      anyflag |= s.flag[(ck + (a >> 2)) & 3][2 * (hb + (a & 1) + PH * ((a >> 1) & 1))];
                     }
                   const bool g_positive = S.kappa > 0.0 && S.kappa <= 1.0;
                   if (anyflag != 0 && (zero_diag || !g_positive))
                     {
                       double po[8], poo[8];
+                      int cio = ci, cjo = cj;
+                      asm volatile("" : "+v"(cio), "+v"(cjo)); // (addresses formed here, not hoisted out of the march and spilled)
 #pragma unroll
                       for (int b = 0; b < 8; ++b)
                         {
-                          const double *src = (b >> 2) ? Uhi : Ulo;
-                          po[b] = src[4 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
-                          poo[b] = src[5 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
+                          if constexpr (OLDF)
+                            {
+                              const double *src = (b >> 2) ? Uhi : Ulo;
+                              po[b] = src[4 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
+                              poo[b] = src[5 * NPH + (b & 1) + PH * ((b >> 1) & 1)];
+                            }
+                          else
+                            {
+                              // rare path (a constrained row next to a cell with a vanishing diagonal): straight from memory
+                              const int id = cart_local_id(cv, cio + (b & 1), cjo + ((b >> 1) & 1), ck + (b >> 2));
+                              po[b] = v.phi_old[id];
+                              poo[b] = v.phi_oldold[id];
+                            }
                         }
                       // sum_{a,c} K_uu[(a,c),(a,c)] = sum_k (sum_c cA[c][k]) 2 sum_q w g mu(q_i) mu(q_j), mu = m_00 + m_11
                       double gsum = 0.0, gk[3] = {0.0, 0.0, 0.0};
@@ -753,7 +783,7 @@ namespace pfm
                           const int gi = i0 + nx, gj = j0 + ny;
                           const int ncell = ((gi > 0) + (gi < cv.NX - 1)) * ((gj > 0) + (gj < cv.NY - 1)) * ((ck > 0) + (ck < cv.NZ - 1));
                           const double mass = S.gc_eps * (S.vol * 0.125) * (double)ncell;
-                          const bool con = (s.flag[ck & 3][hn] >> 3) & 1u;
+                          const bool con = (s.flag[ck & 3][2 * hn] >> 3) & 1u;
                           const int row = cart_local_id(cv, gi, gj, ck);
                           const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + 3 : (long long)v.n_owned * 3 + row;
                           res_pde[di] = con ? 0.0 : mass - sum;
@@ -788,7 +818,10 @@ namespace pfm
               int dwp;
               const unsigned np_ = plane_node(ck + 2, okp, inp, dwp);
               const unsigned nr_ = rows_node(ck + 1, okr);
-              dma_plane_at(np_, okp, inp, dwp, lo); // slot lo (plane ck) is dead once the entries of layer ck are done
+              // a use on every path: a table look-up of cart_local_id left pending where the requests are skipped would be
+              // waited for with vmcnt(0) wherever its register is written next -- at the top of the next step, behind the stores
+              asm volatile("" ::"v"(np_), "v"(nr_));
+              dma_plane_at(np_, okp, inp, dwp, lo, ck + 2); // slot lo (plane ck) is dead once the entries of layer ck are done
               dma_rows_at(nr_, okr, ck + 1);
             }
           stamp(10);
@@ -872,6 +905,7 @@ namespace pfm
                           spp[ny * (PN * 9)] = 0.0;
                         }
                     }
+                  nst = 4 * PN;
                 }
               else if (t < 2 * 108)
                 {
@@ -917,7 +951,7 @@ namespace pfm
                     {
                       // constraint flags near the plane, partial tiles at the high faces, boundary rows with fewer
                       // than 27 neighbours
-                      const unsigned char *nfl = &s.flag[(ck + fe_oz - 1) & 3][fe_nbo];
+                      const unsigned *nfl = &s.flag[(ck + fe_oz - 1) & 3][2 * fe_nbo];
                       const unsigned below = (1u << fe_o) - 1u;
 #pragma unroll 1
                       for (int nl = fe_sub; nl < NPN; nl += 2)
@@ -929,7 +963,7 @@ namespace pfm
                           if (masked)
                             {
                               const int hn = (nl % PN + 1) + PH * (nl / PN + 1);
-                              const unsigned row_flag = s.flag[ck & 3][hn], nflag = nfl[hn];
+                              const unsigned row_flag = s.flag[ck & 3][2 * hn], nflag = nfl[2 * hn];
                               const bool rcon = (row_flag >> 3) & 1u;
                               if (fe_pp)
                                 {
@@ -946,6 +980,7 @@ namespace pfm
                               int sl = __popc(nmask & below);
                               if (nmask >> 31) // row not in lattice order: permutation of the ranks
                                 sl = cv.row_perm[off + sl];
+                              asm volatile("" ::"v"(sl));
                               if constexpr (NCOL == 3)
                                 {
                                   if (fe_pp)
@@ -975,12 +1010,13 @@ namespace pfm
                   if (masked && off >= 0 && patch != 0.0)
                     {
                       // constrained displacement rows whose element diagonal vanished in some cell
-                      const unsigned row_flag = s.flag[ck & 3][(nl % PN + 1) + PH * (nl / PN + 1)];
+                      const unsigned row_flag = s.flag[ck & 3][2 * ((nl % PN + 1) + PH * (nl / PN + 1))];
                       const unsigned nmask = (unsigned)s.deg[cp][nl];
                       const int deg = __popc(nmask & 0x7ffffffu);
                       int sself = __popc(nmask & ((1u << 13) - 1u));
                       if (nmask >> 31)
                         sself = cv.row_perm[off + sself];
+                      asm volatile("" ::"v"(sself)); // consumed on every path (see the requests: no load may stay pending)
                       for (int c = 0; c < 3; ++c)
                         if ((row_flag >> c) & 1u)
                           {
@@ -1000,8 +1036,6 @@ namespace pfm
                     }
                 }
             }
-          if (ck + 1 < kB)
-            flags_put(ck + 2);
         }
       stamp(3);
     }
@@ -1024,7 +1058,6 @@ namespace pfm
     int rc = ensure_g1();
     if (rc)
       return rc;
-    (void)p;
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
     // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
@@ -1036,9 +1069,20 @@ namespace pfm
     const unsigned nb = (unsigned)(ntx * nty * nch);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
     const dim3 grid(xcd_grid(nb)), block(NT4);
-#define PFM_PHI4(NC, HETV, RESV)                                                                                                  \
-  hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),            \
+  // the old phase fields ride in the nodal ring only when the penalisation term needs them (same rule as make_mat_scal)
+  const bool oldf = make_mat_scal(p, cv).gamma_fac != 0.0;
+#define PFM_PHI4_(NC, HETV, RESV, OLDV)                                                                                           \
+  hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV, OLDV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),      \
                      (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 ? d_values[1] : nullptr), zc, nullptr, res_pde)
+#define PFM_PHI4(NC, HETV, RESV)                                                                                                  \
+  do                                                                                                                              \
+    {                                                                                                                             \
+      if (oldf && !(RESV))                                                                                                        \
+        PFM_PHI4_(NC, HETV, false, true);                                                                                         \
+      else                                                                                                                        \
+        PFM_PHI4_(NC, HETV, RESV, false);                                                                                         \
+    }                                                                                                                             \
+  while (0)
     if (il)
       {
         if (het)
@@ -1085,6 +1129,7 @@ namespace pfm
     else
       PFM_PHI4(3, false, false);
 #undef PFM_PHI4
+#undef PFM_PHI4_
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
   bool cart_matrix_supported(int dim) { return dim == 2 || dim == 3; }
