@@ -61,8 +61,33 @@ namespace pfm
     {
       double n[2][3], m[3][3], w[3]; // n_al(q), m_g(q) (g = 0:00, 1:01, 2:11), weights
       double mb[3];                  // 1-D mass moments mbar_g = sum_q w m_g(q)
+      double sx[3][5];               // sx[j][W] = sum_q w t_q^j W(q), t = n_1, W = n_0, n_1, m_0, m_1, m_2 (k_cart_phi4: contraction of
+                                     // a polynomial in t along a line from its coefficients; 3-point Gauss is exact for these degrees)
     };
     __constant__ G1 c_g1;
+
+    // G1::sx as compile-time constants: literals are materialised where they are used (s_mov pairs), values loaded from
+    // c_g1 occupy scalar registers across the whole line loop -- and the role loops of k_cart_phi4 have none to spare
+    // (the loaded table cost 76 spill reloads per z-level when it was tried)
+    constexpr double g1_sx(int j, int W)
+    {
+      const double gx[3] = {0.5 - 0.5 * 0.7745966692414834, 0.5, 0.5 + 0.5 * 0.7745966692414834};
+      const double gw[3] = {5.0 / 18.0, 8.0 / 18.0, 5.0 / 18.0};
+      double sum = 0.0;
+      for (int q = 0; q < 3; ++q)
+        {
+          const double n0 = 1.0 - gx[q], n1 = gx[q];
+          const double tj = j == 0 ? 1.0 : (j == 1 ? gx[q] : gx[q] * gx[q]);
+          const double Wq = W == 0 ? n0 : (W == 1 ? n1 : (W == 2 ? n0 * n0 : (W == 3 ? n0 * n1 : n1 * n1)));
+          sum += gw[q] * tj * Wq;
+        }
+      return sum;
+    }
+    template <int J, int W>
+    struct G1Sx
+    {
+      static constexpr double v = g1_sx(J, W);
+    };
 
     G1 make_g1()
     {
@@ -80,6 +105,17 @@ namespace pfm
         }
       for (int g = 0; g < 3; ++g)
         t.mb[g] = t.w[0] * t.m[g][0] + t.w[1] * t.m[g][1] + t.w[2] * t.m[g][2];
+      for (int j = 0; j < 3; ++j)
+        for (int W = 0; W < 5; ++W)
+          {
+            double sum = 0.0;
+            for (int q = 0; q < 3; ++q)
+              {
+                const double tj = j == 0 ? 1.0 : (j == 1 ? gx[q] : gx[q] * gx[q]);
+                sum += gw[q] * tj * (W < 2 ? t.n[W][q] : t.m[W - 2][q]);
+              }
+            t.sx[j][W] = sum;
+          }
       return t;
     }
 

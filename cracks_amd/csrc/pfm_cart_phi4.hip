@@ -169,7 +169,7 @@ namespace pfm
     // ---- role d: (phi,u) entries of column component D of one cell.  The x- and y-contractions are factored
     // (X, Y accumulators); the z-contraction is folded into the push, one push per z-level of q-points, so the
     // 54 numbers C^{dk}[al][g_i][g_j] never have to be held in registers.
-    template <int D, bool HET>
+    template <int D, bool HET, bool GENQ>
     __device__ __forceinline__ void pu_role(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
                                             double cell_muh, double cell_la, bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
     {
@@ -228,6 +228,71 @@ namespace pfm
                   for (int f = 0; f < 3; ++f)
                     dDz[f] = Dz[f][1] - Dz[f][0]; // unused components are dropped by the compiler
                   double Xx[2] = {0.0, 0.0}, Xy[3] = {0.0, 0.0, 0.0}, Xz[3] = {0.0, 0.0, 0.0};
+                  if constexpr (!GENQ)
+                    {
+                      // Round 4: the x-contraction from COEFFICIENTS.  Along the line pf = p0 + t p1 and every requested
+                      // gradient a0 + t a1 are linear in t = n_1(q_x), so Phi^{dk} = w pf (A0 + t A1) and
+                      //   sum_q Phi W(q) = A0 Q0[W] + A1 Q1[W],  Q0[W] = sum_q w pf W = p0 s0[W] + p1 s1[W],  Q1[W] = p0 s1[W] + p1 s2[W]
+                      // with the constants s_j[W] = sum_q w t^j W(q) (G1::sx): the same sums as the q-point loop below (which
+                      // stays for the clamped phase field of the monolithic scheme: GENQ), regrouped -- 52 instead of ~100
+                      // instructions per line.
+                      const double p0 = wyz * L[3][0], p1 = wyz * dpf;
+                      double Q0[5], Q1[5];
+                      static_for<5>([&](auto Wc) __attribute__((always_inline)) {
+                        constexpr int W = decltype(Wc)::value;
+                        Q0[W] = p0 * G1Sx<0, W>::v + p1 * G1Sx<1, W>::v;
+                        Q1[W] = p0 * G1Sx<1, W>::v + p1 * G1Sx<2, W>::v;
+                      });
+                      // gradient of u_c along the line: constant part and slope in t (d/dx is constant along x)
+                      auto g0 = [&](auto Cc, auto Kk) __attribute__((always_inline)) -> double {
+                        constexpr int c = decltype(Cc)::value, k = decltype(Kk)::value;
+                        if constexpr (k == 0)
+                          return Dx[c];
+                        else if constexpr (k == 1)
+                          return Dy[c][0];
+                        else
+                          return Dz[c][0];
+                      };
+                      auto g1 = [&](auto Cc, auto Kk) __attribute__((always_inline)) -> double {
+                        constexpr int c = decltype(Cc)::value, k = decltype(Kk)::value;
+                        if constexpr (k == 0)
+                          return 0.0;
+                        else if constexpr (k == 1)
+                          return dDy[c];
+                        else
+                          return dDz[c];
+                      };
+                      using I0 = std::integral_constant<int, 0>;
+                      using I1 = std::integral_constant<int, 1>;
+                      using I2 = std::integral_constant<int, 2>;
+                      using ID = std::integral_constant<int, D>;
+                      const double d0 = c_la * (Dx[0] + Dy[1][0] + Dz[2][0]) + cdiag, d1 = c_la * (dDy[1] + dDz[2]);
+                      double A0[3], A1[3];
+                      static_for<3>([&](auto K) __attribute__((always_inline)) {
+                        constexpr int k = decltype(K)::value;
+                        using IK = std::integral_constant<int, k>;
+                        A0[k] = c_muh * (g0(ID{}, IK{}) + g0(IK{}, ID{})) + (k == D ? d0 : 0.0);
+                        if constexpr (k == 0 && D == 0)
+                          A1[k] = d1;
+                        else if constexpr (k == 0)
+                          A1[k] = c_muh * g1(IK{}, ID{});
+                        else if constexpr (D == 0)
+                          A1[k] = c_muh * g1(ID{}, IK{});
+                        else
+                          A1[k] = c_muh * (g1(ID{}, IK{}) + g1(IK{}, ID{})) + (k == D ? d1 : 0.0);
+                      });
+                      (void)sizeof(I0), (void)sizeof(I1), (void)sizeof(I2);
+                      Xx[0] = A0[0] * Q0[0] + A1[0] * Q1[0];
+                      Xx[1] = A0[0] * Q0[1] + A1[0] * Q1[1];
+#pragma unroll
+                      for (int g = 0; g < 3; ++g)
+                        {
+                          Xy[g] = A0[1] * Q0[2 + g] + A1[1] * Q1[2 + g];
+                          Xz[g] = A0[2] * Q0[2 + g] + A1[2] * Q1[2 + g];
+                        }
+                    }
+                  else
+                    {
 #pragma unroll
                   for (int qx = 0; qx < 3; ++qx)
                     {
@@ -265,6 +330,7 @@ namespace pfm
                           Xy[g] += Phi1 * c_g1.m[g][qx];
                           Xz[g] += Phi2 * c_g1.m[g][qx];
                         }
+                    }
                     }
 #pragma unroll
                   for (int g = 0; g < 3; ++g)
@@ -324,7 +390,7 @@ namespace pfm
                                             double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
                                             double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
     {
-      const bool use_pen = OLDF && S.gamma_fac != 0.0; // (the launcher instantiates OLDF exactly when gamma != 0)
+      const bool use_pen = OLDF && S.gamma_fac != 0.0; // (the launcher instantiates OLDF when gamma != 0 or the scheme is monolithic)
       double M[27]; // M[g_x + 3 g_y + 9 g_z]
 #pragma unroll
       for (int m = 0; m < 27; ++m)
@@ -375,6 +441,30 @@ namespace pfm
                   for (int f = 0; f < 3; ++f)
                     Dx[f] = (L[f][1] - L[f][0]) * S.ih[0];
                   double X[3] = {0.0, 0.0, 0.0};
+                  if constexpr (!OLDF)
+                    {
+                      // Round 4: from coefficients, as in the (phi,u) roles.  Along the line every gradient is a0 + t a1, so
+                      // c(q) = (1-kappa) sigma+:E + G_c/eps - 2(alpha_B-1) p div u is a quadratic c0 + c1 t + c2 t^2 and
+                      // sum_q w c m_g = c0 s0[m_g] + c1 s1[m_g] + c2 s2[m_g]
+                      const double y0 = Dy[1][0], y1 = Dy[1][1] - Dy[1][0], z0 = Dz[2][0], z1 = Dz[2][1] - Dz[2][0];
+                      const double u0 = Dy[0][0] + Dx[1], u1 = Dy[0][1] - Dy[0][0];
+                      const double v0 = Dz[0][0] + Dx[2], v1 = Dz[0][1] - Dz[0][0];
+                      const double w0 = Dz[1][0] + Dy[2][0], w1 = (Dz[1][1] - Dz[1][0]) + (Dy[2][1] - Dy[2][0]);
+                      const double a = Dx[0] + y0 + z0, b = y1 + z1; // tr E
+                      const double e0 = (Dx[0] * Dx[0] + y0 * y0 + z0 * z0) + 0.5 * (u0 * u0 + v0 * v0 + w0 * w0);
+                      const double e1 = 2.0 * (y0 * y1 + z0 * z1) + (u0 * u1 + v0 * v1 + w0 * w1);
+                      const double e2 = (y1 * y1 + z1 * z1) + 0.5 * (u1 * u1 + v1 * v1 + w1 * w1);
+                      const double la = HET ? cell_lam : S.lam, mu2 = 2 * (HET ? cell_mu : S.mu);
+                      const double c0 = wyz * (S.omk * (la * a * a + mu2 * e0) + S.gc_eps - S.aB1p2 * a);
+                      const double c1 = wyz * (S.omk * (la * (2.0 * a * b) + mu2 * e1) - S.aB1p2 * b);
+                      const double c2 = wyz * (S.omk * (la * b * b + mu2 * e2));
+                      static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+                        constexpr int g = decltype(Gc)::value;
+                        X[g] = c0 * G1Sx<0, 2 + g>::v + c1 * G1Sx<1, 2 + g>::v + c2 * G1Sx<2, 2 + g>::v;
+                      });
+                    }
+                  else
+                    {
 #pragma unroll
                   for (int qx = 0; qx < 3; ++qx)
                     {
@@ -406,6 +496,7 @@ namespace pfm
                       X[0] += wc * c_g1.m[0][qx];
                       X[1] += wc * c_g1.m[1][qx];
                       X[2] += wc * c_g1.m[2][qx];
+                    }
                     }
 #pragma unroll
                   for (int gy = 0; gy < 3; ++gy)
@@ -455,8 +546,9 @@ namespace pfm
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */,
               bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
               bool RES = false /* also writes the phase-field rows of the residual (res_pde) */,
-              bool OLDF = false /* phi_old / phi_oldold in the nodal ring (penalisation term); else fetched where the rare
-                                   placeholder path needs them */>
+              bool OLDF = false /* the general form: q-point loops along x (clamped phase field of the monolithic scheme,
+                                   penalisation term) and phi_old / phi_oldold in the nodal ring; else the x-contraction from
+                                   coefficients, the old fields fetched where the rare placeholder path needs them */>
     __global__ __launch_bounds__(NT4, 2) void k_cart_phi4(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals_pu,
                                                           double *__restrict__ vals_pp, double *__restrict__ vals_uu,
                                                           double *__restrict__ vals_up /* blocked layout: structurally zero (u,phi) block, cleared here */,
@@ -654,11 +746,11 @@ namespace pfm
               c_la = 2.0 * (1.0 - S.kappa) * lam;
             }
           if (role == 0)
-            pu_role<0, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu_role<0, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else if (role == 1)
-            pu_role<1, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu_role<1, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else if (role == 2)
-            pu_role<2, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu_role<2, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           else
             {
               double Mdiag[8];
@@ -1069,8 +1161,10 @@ namespace pfm
     const unsigned nb = (unsigned)(ntx * nty * nch);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
     const dim3 grid(xcd_grid(nb)), block(NT4);
-  // the old phase fields ride in the nodal ring only when the penalisation term needs them (same rule as make_mat_scal)
-  const bool oldf = make_mat_scal(p, cv).gamma_fac != 0.0;
+  // the general form (q-point loops, old phase fields in the nodal ring) only where the scheme needs it: clamped phase field
+  // (monolithic) or penalisation term (same rules as make_mat_scal)
+  const MatScal Sh = make_mat_scal(p, cv);
+  const bool oldf = Sh.gamma_fac != 0.0 || Sh.monolithic;
 #define PFM_PHI4_(NC, HETV, RESV, OLDV)                                                                                           \
   hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV, OLDV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),      \
                      (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 ? d_values[1] : nullptr), zc, nullptr, res_pde)
