@@ -542,6 +542,356 @@ namespace pfm
         Mdiag[a] = M[2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * (a >> 2)];
     }
 
+    // ===================================================================================== round 4
+    // The roles from POLYNOMIAL COEFFICIENTS (staggered scheme without penalisation: nothing is clamped at the q-points).
+    // On a box cell every nodal field is trilinear in the reference coordinates (t, s, r), its gradient is multilinear, so
+    //   Phi^{dk} = w pf [c_muh (d_k u_d + d_d u_k) + delta_dk (c_la div u + cdiag)]      (degree <= 2 per variable)
+    //   c        = (1-kappa) sigma+:E + G_c/eps - 2 (alpha_B-1) p div u                  (degree <= 2 per variable)
+    // are polynomials with 27 coefficients, and the sums over the 27 Gauss points against the weights n_al / m_g are
+    // contractions of those coefficients with the 3 x 5 constants s_j[W] = sum_q w t_q^j W(q) (G1Sx; the 3-point rule is exact
+    // for every degree that occurs, the values are those of the quadrature up to rounding): vertex values -> 8 monomial
+    // coefficients per field (12 subtractions), coefficient products (<= 64 per role field), three contraction stages of 54
+    // FMAs per (d,k) -- no q-point is ever visited.  ~1100 instead of ~2500 instructions per cell and (phi,u) role, ~600 for
+    // the (phi,phi) role; the z-contraction happens in registers, so a cell pushes ONCE per role (64 instead of 192 LDS adds).
+    __device__ __forceinline__ void monomials(double (&v)[8]) // in: vertex values, index x + 2 y + 4 z; out: coefficient of t^a s^b r^c at a + 2 b + 4 c
+    {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2)
+        v[i + 1] -= v[i];
+      v[2] -= v[0], v[3] -= v[1], v[6] -= v[4], v[7] -= v[5];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i + 4] -= v[i];
+    }
+    constexpr int pow_of(int ia, int ip) // power index i_x + 3 i_y + 9 i_z of the product of two multilinear monomials
+    {
+      return ((ia & 1) + (ip & 1)) + 3 * (((ia >> 1) & 1) + ((ip >> 1) & 1)) + 9 * (((ia >> 2) & 1) + ((ip >> 2) & 1));
+    }
+    // the derivative along axis c of a trilinear field has no monomial with t_c: A^{dk} has a coefficient at idx iff ...
+    constexpr bool a_nz(int D, int K, int idx) { return K == D ? idx != 7 : (!(idx & (1 << K)) || !(idx & (1 << D))); }
+    constexpr bool pair_first(int D, int K, int ia, int ip) // first (ia outer, ip inner) contribution to its power?
+    {
+      const int pw = pow_of(ia, ip);
+      for (int a = 0; a < 8; ++a)
+        for (int q = 0; q < 8; ++q)
+          {
+            if (a == ia && q == ip)
+              return true;
+            if (a_nz(D, K, a) && pow_of(a, q) == pw)
+              return false;
+          }
+      return true;
+    }
+    constexpr bool pow_any(int D, int K, int pw)
+    {
+      for (int a = 0; a < 8; ++a)
+        for (int q = 0; q < 8; ++q)
+          if (a_nz(D, K, a) && pow_of(a, q) == pw)
+            return true;
+      return false;
+    }
+    constexpr int ipow3(int a) { return a == 0 ? 1 : (a == 1 ? 3 : 9); }
+
+    template <int D, bool HET>
+    __device__ __forceinline__ void pu_role_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
+                                                 double cell_muh, double cell_la, bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
+    {
+      const double c_muh = HET ? cell_muh : S.c_muh, c_la = HET ? cell_la : S.c_la;
+      // vertices of the cell whose rows this lane pushes into (bit a of the vertex loop below)
+      bool vok[8];
+      static_for<8>([&](auto A) __attribute__((always_inline)) {
+        constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+        const int hx = cx + ax, hy = cy + ay;
+        vok[decltype(A)::value] = cell_ok && (az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN;
+      });
+      if (cell_ok)
+        {
+          double F[4][8]; // u_x u_y u_z phi
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            {
+              load_cell_field_raw(Ulo + f * NPH, Uhi + f * NPH, F[f]);
+              monomials(F[f]);
+            }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            F[3][i] *= S.vol; // JxW = vol w w w, and the weights are inside the constants s_j[W]
+          static_for<3>([&](auto Kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(Kc)::value;
+            constexpr int a1 = k == 0 ? 1 : 0, a2 = k == 2 ? 1 : 2; // the other axes, ascending
+            const double ihk = S.ih[k];
+            const double sDk = c_muh * ihk * ihk, skD = c_muh * S.ih[D] * ihk;
+            const double sl[3] = {c_la * S.ih[0] * ihk, c_la * S.ih[1] * ihk, c_la * S.ih[2] * ihk};
+            double A[8];
+            static_for<8>([&](auto Ic) __attribute__((always_inline)) {
+              constexpr int idx = decltype(Ic)::value;
+              if constexpr (a_nz(D, k, idx))
+                {
+                  double acc = 0.0;
+                  bool any = false;
+                  auto add = [&](double x) __attribute__((always_inline)) {
+                    acc = any ? acc + x : x;
+                    any = true;
+                  };
+                  if constexpr (k == D)
+                    {
+                      if constexpr (!(idx & (1 << k)))
+                        add((2.0 * sDk + sl[k]) * F[D][idx | (1 << k)]);
+                      static_for<3>([&](auto Cc) __attribute__((always_inline)) {
+                        constexpr int c = decltype(Cc)::value;
+                        if constexpr (c != k && !(idx & (1 << c)))
+                          add(sl[c] * F[c][idx | (1 << c)]);
+                      });
+                      if constexpr (idx == 0)
+                        add(S.cdiag * ihk);
+                    }
+                  else
+                    {
+                      if constexpr (!(idx & (1 << k)))
+                        add(sDk * F[D][idx | (1 << k)]); // d_k u_D
+                      if constexpr (!(idx & (1 << D)))
+                        add(skD * F[k][idx | (1 << D)]); // d_D u_k
+                    }
+                  A[idx] = acc;
+                }
+            });
+            double c[27];
+            static_for<8>([&](auto Ia) __attribute__((always_inline)) {
+              constexpr int ia = decltype(Ia)::value;
+              if constexpr (a_nz(D, k, ia))
+                static_for<8>([&](auto Ip) __attribute__((always_inline)) {
+                  constexpr int ip = decltype(Ip)::value;
+                  constexpr int pw = pow_of(ia, ip);
+                  if constexpr (pair_first(D, k, ia, ip))
+                    c[pw] = A[ia] * F[3][ip];
+                  else
+                    c[pw] = fma(A[ia], F[3][ip], c[pw]);
+                });
+            });
+            static_for<27>([&](auto Pw) __attribute__((always_inline)) {
+              if constexpr (!pow_any(D, k, decltype(Pw)::value))
+                c[decltype(Pw)::value] = 0.0;
+            });
+            // contraction: the special axis k first (2 weights n_al), then a1, a2 (3 weights m_g each)
+            double R1[2][3][3], R2[2][3][3];
+            static_for<2>([&](auto Wc) __attribute__((always_inline)) {
+              constexpr int w = decltype(Wc)::value;
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int l = 0; l < 3; ++l)
+                  {
+                    const int b = j * ipow3(a1) + l * ipow3(a2);
+                    R1[w][j][l] = c[b] * G1Sx<0, w>::v + c[b + ipow3(k)] * G1Sx<1, w>::v + c[b + 2 * ipow3(k)] * G1Sx<2, w>::v;
+                  }
+            });
+            static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+              constexpr int g = decltype(Gc)::value;
+#pragma unroll
+              for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int l = 0; l < 3; ++l)
+                  R2[w][g][l] = R1[w][0][l] * G1Sx<0, 2 + g>::v + R1[w][1][l] * G1Sx<1, 2 + g>::v + R1[w][2][l] * G1Sx<2, 2 + g>::v;
+            });
+            // C[al + 2 (g_i + 3 g_j)], i < j the axes other than k (1/h_k and the volume folded in), and its negative: the entry
+            // of trial vertex b gets s(b_k) C; the LDS add takes no sign
+            double Cp[18], Cn[18];
+            static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+              constexpr int g2 = decltype(Gc)::value;
+#pragma unroll
+              for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int g1 = 0; g1 < 3; ++g1)
+                  {
+                    const double x = R2[w][g1][0] * G1Sx<0, 2 + g2>::v + R2[w][g1][1] * G1Sx<1, 2 + g2>::v + R2[w][g1][2] * G1Sx<2, 2 + g2>::v;
+                    Cp[w + 2 * (g1 + 3 * g2)] = x;
+                    Cn[w + 2 * (g1 + 3 * g2)] = -x;
+                  }
+            });
+            // the k-part of the cell's entries, vertex by vertex in the order of a lexicographic cell loop (three adds per
+            // entry and cell, k = 0, 1, 2: a fixed order)
+            static_for<8>([&](auto A) __attribute__((always_inline)) {
+              constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+              if (vok[decltype(A)::value])
+                {
+                  const int nb = (nl0 + ax + PN * ay) * 27 + D;
+                  static_for<8>([&](auto B) __attribute__((always_inline)) {
+                    constexpr int bx = decltype(B)::value & 1, by = (decltype(B)::value >> 1) & 1, bz = decltype(B)::value >> 2;
+                    constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
+                    constexpr int gx = ax + bx, gy = ay + by, gz = az + bz;
+                    constexpr int o9 = (ox + 1) + 3 * (oy + 1);
+                    constexpr int ci = k == 0 ? ax + 2 * (gy + 3 * gz) : (k == 1 ? ay + 2 * (gx + 3 * gz) : az + 2 * (gx + 3 * gy));
+                    constexpr int bk = k == 0 ? bx : (k == 1 ? by : bz);
+                    double *slab = (az == 0) ? (oz == 0 ? dst.lo_z0 : dst.lo_p1) : (oz == -1 ? dst.hi_m1 : dst.hi_z0);
+                    lds_add(&slab[nb + o9 * 3], bk ? Cp[ci] : Cn[ci]);
+                  });
+                }
+            });
+          });
+        }
+    }
+
+    // sum += w p^2 for a multilinear polynomial p whose coefficients outside MASK (bit idx) vanish structurally
+    template <int MASK>
+    __device__ __forceinline__ void add_square(const double (&p)[8], double w, double (&Q)[27])
+    {
+      double pw1[8], pw2[8]; // w p_i, 2 w p_i
+      static_for<8>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value;
+        if constexpr ((MASK >> i) & 1)
+          {
+            pw1[i] = w * p[i];
+            pw2[i] = pw1[i] + pw1[i];
+          }
+      });
+      static_for<8>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value;
+        if constexpr ((MASK >> i) & 1)
+          static_for<8>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(Jc)::value;
+            if constexpr (j >= i && ((MASK >> j) & 1))
+              Q[pow_of(i, j)] = fma(j == i ? pw1[i] : pw2[i], p[j], Q[pow_of(i, j)]);
+          });
+      });
+    }
+
+    template <bool HET>
+    __device__ __forceinline__ void pp_role_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
+                                                 double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
+                                                 double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
+                                                 double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
+    {
+      double M[27]; // M[g_x + 3 g_y + 9 g_z]
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+        M[m] = 0.0;
+      if (cell_ok)
+        {
+          double F[3][8];
+#pragma unroll
+          for (int f = 0; f < 3; ++f)
+            {
+              load_cell_field_raw(Ulo + f * NPH, Uhi + f * NPH, F[f]);
+              monomials(F[f]);
+            }
+          // gradient polynomials: d_k u_c = ih_k sum_{idx without bit k} F[c][idx | 1 << k] x^idx, formed where they are used
+          auto G = [&](auto Cc, auto Kc, auto Ic) __attribute__((always_inline)) -> double {
+            constexpr int c = decltype(Cc)::value, k = decltype(Kc)::value, idx = decltype(Ic)::value;
+            static_assert(!(idx & (1 << k)), "no such monomial in this derivative");
+            return S.ih[k] * F[c][idx | (1 << k)];
+          };
+          using I0 = std::integral_constant<int, 0>;
+          using I1 = std::integral_constant<int, 1>;
+          using I2 = std::integral_constant<int, 2>;
+          using I3 = std::integral_constant<int, 3>;
+          using I4 = std::integral_constant<int, 4>;
+          using I5 = std::integral_constant<int, 5>;
+          using I6 = std::integral_constant<int, 6>;
+          constexpr int NOX = 0x55, NOY = 0x33, NOZ = 0x0f; // monomials without t, without s, without r
+          double Q[27];
+#pragma unroll
+          for (int m = 0; m < 27; ++m)
+            Q[m] = 0.0;
+          const double la = HET ? cell_lam : S.lam, mu2 = 2 * (HET ? cell_mu : S.mu);
+          // tr E = div u (kept: the linear term of c needs it again)
+          double T[8];
+          T[0] = (G(I0{}, I0{}, I0{}) + G(I1{}, I1{}, I0{})) + G(I2{}, I2{}, I0{});
+          T[1] = G(I1{}, I1{}, I1{}) + G(I2{}, I2{}, I1{});
+          T[2] = G(I0{}, I0{}, I2{}) + G(I2{}, I2{}, I2{});
+          T[3] = G(I2{}, I2{}, I3{});
+          T[4] = G(I0{}, I0{}, I4{}) + G(I1{}, I1{}, I4{});
+          T[5] = G(I1{}, I1{}, I5{});
+          T[6] = G(I0{}, I0{}, I6{});
+          add_square<0x7f>(T, la, Q);
+          static_for<3>([&](auto Cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(Cc)::value;
+            constexpr int mc = c == 0 ? NOX : (c == 1 ? NOY : NOZ);
+            double P[8];
+            static_for<8>([&](auto Ic) __attribute__((always_inline)) {
+              if constexpr ((mc >> decltype(Ic)::value) & 1)
+                P[decltype(Ic)::value] = G(Cc, Cc, Ic);
+            });
+            add_square<mc>(P, mu2, Q);
+          });
+          // 2 E_cd = d_d u_c + d_c u_d
+          static_for<3>([&](auto Pc) __attribute__((always_inline)) {
+            constexpr int pr = decltype(Pc)::value;
+            constexpr int c = pr == 2 ? 1 : 0, d = pr == 0 ? 1 : 2; // (0,1), (0,2), (1,2)
+            constexpr int mc = c == 0 ? NOX : NOY, md = d == 1 ? NOY : NOZ;
+            using IC = std::integral_constant<int, c>;
+            using ID = std::integral_constant<int, d>;
+            double Sp[8];
+            static_for<8>([&](auto Ic) __attribute__((always_inline)) {
+              constexpr int idx = decltype(Ic)::value;
+              constexpr bool hd = (md >> idx) & 1, hc = (mc >> idx) & 1; // d_d u_c lives on the monomials without x_d
+              if constexpr (hd && hc)
+                Sp[idx] = G(IC{}, ID{}, Ic) + G(ID{}, IC{}, Ic);
+              else if constexpr (hd)
+                Sp[idx] = G(IC{}, ID{}, Ic);
+              else if constexpr (hc)
+                Sp[idx] = G(ID{}, IC{}, Ic);
+            });
+            add_square<(mc | md)>(Sp, 0.5 * mu2, Q);
+          });
+          // c = vol [ (1-kappa) sigma+:E + G_c/eps - 2 (alpha_B-1) p div u ]
+          const double ov = S.omk * S.vol;
+          double c[27];
+#pragma unroll
+          for (int m = 0; m < 27; ++m)
+            c[m] = ov * Q[m];
+          c[0] += S.gc_eps * S.vol;
+          const double av = S.aB1p2 * S.vol;
+          static_for<7>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int idx = decltype(Ic)::value;
+            c[pow_of(idx, 0)] = fma(-av, T[idx], c[pow_of(idx, 0)]);
+          });
+          double R1[3][3][3], R2[3][3][3];
+          static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gc)::value;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int l = 0; l < 3; ++l)
+                R1[g][j][l] = c[3 * j + 9 * l] * G1Sx<0, 2 + g>::v + c[1 + 3 * j + 9 * l] * G1Sx<1, 2 + g>::v + c[2 + 3 * j + 9 * l] * G1Sx<2, 2 + g>::v;
+          });
+          static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gc)::value;
+#pragma unroll
+            for (int gx = 0; gx < 3; ++gx)
+#pragma unroll
+              for (int l = 0; l < 3; ++l)
+                R2[gx][g][l] = R1[gx][0][l] * G1Sx<0, 2 + g>::v + R1[gx][1][l] * G1Sx<1, 2 + g>::v + R1[gx][2][l] * G1Sx<2, 2 + g>::v;
+          });
+          static_for<3>([&](auto Gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gc)::value;
+#pragma unroll
+            for (int gx = 0; gx < 3; ++gx)
+#pragma unroll
+              for (int gy = 0; gy < 3; ++gy)
+                M[gx + 3 * gy + 9 * g] = (R2[gx][gy][0] * G1Sx<0, 2 + g>::v + R2[gx][gy][1] * G1Sx<1, 2 + g>::v + R2[gx][gy][2] * G1Sx<2, 2 + g>::v) +
+                                         S.lapM[gx + 3 * gy + 9 * g];
+          });
+        }
+      static_for<8>([&](auto A) __attribute__((always_inline)) {
+        constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+        const int hx = cx + ax, hy = cy + ay;
+        if ((az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN)
+          {
+            const int nb = (nl0 + ax + PN * ay) * 9;
+            static_for<8>([&](auto B) __attribute__((always_inline)) {
+              constexpr int bx = decltype(B)::value & 1, by = (decltype(B)::value >> 1) & 1, bz = decltype(B)::value >> 2;
+              constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
+              constexpr int o9 = (ox + 1) + 3 * (oy + 1);
+              double *slab = (az == 0) ? (oz == 0 ? pp_lo_z0 : pp_lo_p1) : (oz == -1 ? pp_hi_m1 : pp_hi_z0);
+              lds_add(&slab[nb + o9], M[(ax + bx) + 3 * (ay + by) + 9 * (az + bz)]);
+            });
+          }
+      });
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        Mdiag[a] = M[2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * (a >> 2)];
+    }
+
     // =====================================================================================
     template <int NCOL, int CLK = 0 /* profiling only: 1 = cycles per phase of thread 0, 2 = cycles per role */,
               bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
@@ -745,16 +1095,26 @@ namespace pfm
               c_muh = 2.0 * (1.0 - S.kappa) * mu;
               c_la = 2.0 * (1.0 - S.kappa) * lam;
             }
+          auto pu = [&](auto Dc) __attribute__((always_inline)) {
+            constexpr int d = decltype(Dc)::value;
+            if constexpr (OLDF)
+              pu_role<d, HET, true>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            else
+              pu_role_poly<d, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+          };
           if (role == 0)
-            pu_role<0, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu(std::integral_constant<int, 0>{});
           else if (role == 1)
-            pu_role<1, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu(std::integral_constant<int, 1>{});
           else if (role == 2)
-            pu_role<2, HET, OLDF>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+            pu(std::integral_constant<int, 2>{});
           else
             {
               double Mdiag[8];
-              pp_role<HET, OLDF>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+              if constexpr (OLDF)
+                pp_role<HET, true>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+              else
+                pp_role_poly<HET>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
               double avg = 0.0, patch = 0.0;
               if (cell_ok)
                 {
