@@ -57,3 +57,15 @@ def sneddon_3d_setup() -> ProblemSetup:
                         initial_bc=lambda time: {int(d): 0.0 for d in dd}, solution0=c.sol.copy(), E_modulus=1.0,
                         timestep=1.0, max_no_timesteps=5, newton_tol=1.0e-7, max_newton_steps=60,
                         max_line_search=50, line_search_damping=0.6)
+
+
+def sneddon_2d_setup() -> ProblemSetup:
+    """tests/sneddon_2d_1.prm (BASELINE config 0: 100 cells + one local pre-refinement = 124 cells with hanging nodes,
+    iterative solver layout, active set, no stress split)."""
+    c = cases.kat_sneddon_2d()
+    mesh, lay = c.mesh, c.layout
+    dd = M.sneddon_dirichlet_dofs(mesh, lay)
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd,
+                        initial_bc=lambda time: {int(d): 0.0 for d in dd}, solution0=c.sol.copy(), E_modulus=1.0,
+                        timestep=1.0, max_no_timesteps=3, newton_tol=1.0e-7, max_newton_steps=50,
+                        max_line_search=10, line_search_damping=0.6)

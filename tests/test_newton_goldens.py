@@ -86,3 +86,34 @@ def test_sneddon_3d_on_gpu_cartesian_family():
     assert asm.ctx.kernel_path == 1
     recs = ActiveSetDriver(setup, asm).run(n_steps=3)
     _check_sneddon_3d(recs)
+
+
+def _check_sneddon_2d(recs):
+    """tests/sneddon_2d_1.output (BASELINE config 0): line-0 residual, energies and the converged active set of every
+    time step.  The reference solves with GMRES to a relative tolerance, the harness exactly: intermediate rows differ,
+    converged quantities agree to the printed digits."""
+    g = cases.golden()["sneddon_2d_1"]["timesteps"]
+    assert len(recs) == 3
+    for rec, gg in zip(recs, g):
+        assert rec.residual0 == pytest.approx(gg["residual0"], rel=2e-6)
+        assert rec.bulk_energy == pytest.approx(gg["bulk_energy"], rel=2e-5)
+        assert rec.crack_energy == pytest.approx(gg["crack_energy"], rel=2e-6)
+        assert rec.newton[-1].residual < 1e-7
+        assert rec.newton[-1].active_set == gg["newton"][-1]["active_set"]  # 9, 85, 115
+
+
+def test_sneddon_2d_with_oracle():
+    setup = NC.sneddon_2d_setup()
+    _check_sneddon_2d(ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout)).run(n_steps=3))
+
+
+@pytest.mark.gpu
+def test_sneddon_2d_on_gpu_end_to_end():
+    """SURVEY.md 8(f) N1 widened: the reference's sneddon_2d_1 run -- hanging nodes, iterative-solver
+    layout, active set -- with every assembly on the GPU (general family + cartesian overlay)."""
+    from cracks_amd.newton import GpuAssembler
+
+    setup = NC.sneddon_2d_setup()
+    asm = GpuAssembler(setup.mesh, setup.layout)
+    assert asm.ctx.kernel_path in (0, 3)
+    _check_sneddon_2d(ActiveSetDriver(setup, asm).run(n_steps=3))
