@@ -25,6 +25,7 @@
 // Arithmetic is the reference's (cracks.cc:2248-2432) re-associated; parity with the CPU
 // oracle is at round-off level (tests/test_gpu_parity.py, tolerance 1e-12).
 #include "pfm_internal.h"
+#include "pfm_poly.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -72,6 +73,9 @@ namespace pfm
     {
       double lam, mu, kappa, eps, Gc, p, aB1, gamma_fac, tfac;
       int monolithic, use_old, total_via_update;
+      // uniform constants of residual_cell_poly, formed on the host so that they arrive in scalar registers
+      double ih[3], vol, vih[3], geih[3]; // 1 / h_k, h_x h_y h_z, vol / h_k, G_c eps vol / h_k^2
+      double c_g, c_pd, c_r2, c_r3;       // 1 - kappa, (alpha_B - 1) p, -2 (alpha_B - 1) p, G_c / eps
     };
 
     Scal make_scal(const pfm_params &prm, const CartView &cv, int dim)
@@ -96,6 +100,19 @@ namespace pfm
       s.monolithic = prm.outer_solver == PFM_SOLVER_SIMPLE_MONOLITHIC;
       s.use_old = prm.use_old_timestep_pf;
       s.total_via_update = prm.outer_solver != PFM_SOLVER_ACTIVE_SET;
+      s.vol = 1.0;
+      for (int d = 0; d < dim; ++d)
+        s.vol *= cv.h[d];
+      for (int d = 0; d < 3; ++d)
+        {
+          s.ih[d] = d < dim ? 1.0 / cv.h[d] : 0.0;
+          s.vih[d] = s.vol * s.ih[d];
+          s.geih[d] = (s.Gc * s.eps) * s.ih[d] * s.vih[d];
+        }
+      s.c_g = 1.0 - s.kappa;
+      s.c_pd = s.aB1 * s.p;
+      s.c_r2 = -2.0 * s.aB1 * s.p;
+      s.c_r3 = s.Gc / s.eps;
       return s;
     }
 
@@ -388,6 +405,268 @@ namespace pfm
       return __hiloint2double(hi, lo);
     }
 
+    // ---- round 4: one cell of k_cart_residual3 (LIN: staggered scheme without penalisation) WITHOUT a loop over its
+    // q-points for anything but the clamped factor.  pfm_poly.h: u and phi are trilinear on the cell, every strain /
+    // stress component is a multilinear polynomial with known zeros, and the accumulators M[i][j][k][c] are moments against
+    // the monomials psi = t^i s^j r^k (the "moment basis" of the test functions: index 1 = phi_1 = t with gradient 1/h,
+    // index 0 = phi_0 + phi_1 = 1 with gradient 0).  Therefore, with H_f[m] = sum_q w f(q) x_q^m the discrete moments of a
+    // factor f against the monomials of powers 0..2:
+    //   sum_q w g sigma_ck psi        = sum_idx sigma_ck[idx] H_g[idx + psi]         g = (1-kappa) pfx^2 + kappa, pfx CLAMPED at q
+    //   sum_q w pf Theta psi          = sum_idx pf[idx] H_Theta[idx + psi]           Theta = (1-kappa) sigma:E - 2(alpha-1)p div u + G_c/eps
+    // H_g needs the 27 q-point values of pfx^2 (interpolate, clamp, square: the only thing evaluated at q-points) and a
+    // three-stage contraction (243 FMAs); H_Theta comes from the 27 coefficients of Theta and the integrals of t^n (the 3-point
+    // rule is exact up to t^5).  ~1500 instead of ~4000 instructions per cell; the sums are the reference's, regrouped.
+    __device__ __forceinline__ void residual_cell_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const Scal &S,
+                                                       double lam, double mu, double (&M)[2][2][2][4])
+    {
+      const double c_g = S.c_g, c_pd = S.c_pd, c_r2 = S.c_r2, c_r3 = S.c_r3, vol = S.vol;
+      const double(&ih)[3] = S.ih;
+      const double(&vih)[3] = S.vih;
+      auto load8 = [&](int f, double (&a)[8]) __attribute__((always_inline)) {
+        a[0] = Ulo[f * RPL], a[1] = Ulo[f * RPL + 1], a[2] = Ulo[f * RPL + RHX], a[3] = Ulo[f * RPL + RHX + 1];
+        a[4] = Uhi[f * RPL], a[5] = Uhi[f * RPL + 1], a[6] = Uhi[f * RPL + RHX], a[7] = Uhi[f * RPL + RHX + 1];
+      };
+      auto Madd = [&](auto Psi, auto Cc, double x) __attribute__((always_inline)) {
+        constexpr int psi = decltype(Psi)::value, c = decltype(Cc)::value;
+        M[psi & 1][(psi >> 1) & 1][psi >> 2][c] += x;
+      };
+      // ---------------- discrete moments of pfx^2 (HP) and of g (Hg) against t^p s^q r^r, p, q, r = 0..2
+      double Hg[27], HP8[8]; // HP8: the moments of pfx^2 against the multilinear monomials (pressure term)
+      {
+        double W[8];
+        load8(4, W); // LIN: the combined old field (load_plane)
+        monomials(W);
+        double Pq[27];
+        poly_for<3>([&](auto Qx) __attribute__((always_inline)) {
+          constexpr int qx = decltype(Qx)::value;
+          double X[4];
+#pragma unroll
+          for (int bc = 0; bc < 4; ++bc)
+            X[bc] = fma(GqT<qx>::v, W[2 * bc + 1], W[2 * bc]);
+          poly_for<3>([&](auto Qy) __attribute__((always_inline)) {
+            constexpr int qy = decltype(Qy)::value;
+            const double y0 = fma(GqT<qy>::v, X[1], X[0]), y1 = fma(GqT<qy>::v, X[3], X[2]);
+            poly_for<3>([&](auto Qz) __attribute__((always_inline)) {
+              constexpr int qz = decltype(Qz)::value;
+              double pfx = fma(GqT<qz>::v, y1, y0);
+              if (!S.use_old)
+                pfx = fmin(fmax(pfx, 0.0), 1.0); // cracks.cc:2270-2277
+              Pq[qx + 3 * qy + 9 * qz] = pfx * pfx;
+            });
+          });
+        });
+        __builtin_amdgcn_sched_barrier(0); // stage by stage: interleaved, the stages do not fit the registers
+        double A1[27], A2[27];
+        poly_for<3>([&](auto Pp) __attribute__((always_inline)) {
+          constexpr int pp = decltype(Pp)::value;
+#pragma unroll
+          for (int yz = 0; yz < 9; ++yz)
+            A1[pp + 3 * yz] = GqWt<0, pp>::v * Pq[3 * yz] + GqWt<1, pp>::v * Pq[3 * yz + 1] + GqWt<2, pp>::v * Pq[3 * yz + 2];
+        });
+        __builtin_amdgcn_sched_barrier(0); // stage by stage: interleaved, the stages do not fit the registers
+        poly_for<3>([&](auto Qp) __attribute__((always_inline)) {
+          constexpr int qp = decltype(Qp)::value;
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int qz = 0; qz < 3; ++qz)
+              A2[pp + 3 * qp + 9 * qz] =
+                GqWt<0, qp>::v * A1[pp + 9 * qz] + GqWt<1, qp>::v * A1[pp + 3 + 9 * qz] + GqWt<2, qp>::v * A1[pp + 6 + 9 * qz];
+        });
+        __builtin_amdgcn_sched_barrier(0); // stage by stage: interleaved, the stages do not fit the registers
+        poly_for<27>([&](auto Mm) __attribute__((always_inline)) {
+          constexpr int m = decltype(Mm)::value, pp = m % 3, qp = (m / 3) % 3, rp = m / 9;
+          const double hp = GqWt<0, rp>::v * A2[pp + 3 * qp] + GqWt<1, rp>::v * A2[pp + 3 * qp + 9] + GqWt<2, rp>::v * A2[pp + 3 * qp + 18];
+          constexpr double Im = GqMom<pp>::v * GqMom<qp>::v * GqMom<rp>::v;
+          Hg[m] = fma(c_g, hp, S.kappa * Im);
+          if constexpr (pp < 2 && qp < 2 && rp < 2)
+            HP8[pp + 2 * qp + 4 * rp] = hp;
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- displacement rows
+      double F[3][8];
+#pragma unroll
+      for (int f = 0; f < 3; ++f)
+        {
+          load8(f, F[f]);
+          monomials(F[f]);
+        }
+      auto G = [&](auto Cc, auto Kc, auto Ic) __attribute__((always_inline)) -> double { // d_k u_c, coefficient idx
+        constexpr int c = decltype(Cc)::value, k = decltype(Kc)::value, idx = decltype(Ic)::value;
+        static_assert(!(idx & (1 << k)), "no such monomial in this derivative");
+        return ih[k] * F[c][idx | (1 << k)];
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
+      using I4 = std::integral_constant<int, 4>;
+      using I5 = std::integral_constant<int, 5>;
+      using I6 = std::integral_constant<int, 6>;
+      double T[8]; // div u
+      T[0] = (G(I0{}, I0{}, I0{}) + G(I1{}, I1{}, I0{})) + G(I2{}, I2{}, I0{});
+      T[1] = G(I1{}, I1{}, I1{}) + G(I2{}, I2{}, I1{});
+      T[2] = G(I0{}, I0{}, I2{}) + G(I2{}, I2{}, I2{});
+      T[3] = G(I2{}, I2{}, I3{});
+      T[4] = G(I0{}, I0{}, I4{}) + G(I1{}, I1{}, I4{});
+      T[5] = G(I1{}, I1{}, I5{});
+      T[6] = G(I0{}, I0{}, I6{});
+      const double mu2 = 2.0 * mu;
+      poly_for<3>([&](auto Cc) __attribute__((always_inline)) {
+        poly_for<3>([&](auto Kc) __attribute__((always_inline)) {
+          constexpr int c = decltype(Cc)::value, k = decltype(Kc)::value;
+          constexpr int mc = c == 0 ? NOX : (c == 1 ? NOY : NOZ), mk = k == 0 ? NOX : (k == 1 ? NOY : NOZ);
+          constexpr int mask = c == k ? 0x7f : (mc | mk);
+          // sigma_ck = lambda div u delta_ck + mu (d_k u_c + d_c u_k)
+          double sg[8];
+          poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int idx = decltype(Ic)::value;
+            if constexpr ((mask >> idx) & 1)
+              {
+                if constexpr (c == k)
+                  {
+                    if constexpr ((mc >> idx) & 1)
+                      sg[idx] = fma(mu2, G(Cc, Cc, Ic), lam * T[idx]);
+                    else
+                      sg[idx] = lam * T[idx];
+                  }
+                else
+                  {
+                    constexpr bool hk = (mk >> idx) & 1, hc = (mc >> idx) & 1; // d_k u_c lives on the monomials without x_k
+                    if constexpr (hk && hc)
+                      sg[idx] = mu * (G(Cc, Kc, Ic) + G(Kc, Cc, Ic));
+                    else if constexpr (hk)
+                      sg[idx] = mu * G(Cc, Kc, Ic);
+                    else
+                      sg[idx] = mu * G(Kc, Cc, Ic);
+                  }
+              }
+          });
+          // flux moments against the 4 monomials on the two other axes; the gradient factor of psi along k is 1/h_k
+          constexpr int a1 = k == 0 ? 1 : 0, a2 = k == 2 ? 1 : 2;
+          poly_for<4>([&](auto Jl) __attribute__((always_inline)) {
+            constexpr int midx = ((decltype(Jl)::value & 1) << a1) | ((decltype(Jl)::value >> 1) << a2);
+            double val = 0.0;
+            bool any = false;
+            poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+              constexpr int idx = decltype(Ic)::value;
+              if constexpr ((mask >> idx) & 1)
+                {
+                  val = any ? fma(sg[idx], Hg[pow_of(idx, midx)], val) : sg[idx] * Hg[pow_of(idx, midx)];
+                  any = true;
+                }
+            });
+            if constexpr (c == k)
+              val = fma(-c_pd, HP8[midx], val); // - (alpha_B - 1) p pfx^2 delta_ck
+            Madd(std::integral_constant<int, (1 << k) | midx>{}, Cc, vih[k] * val);
+          });
+        });
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase-field row: value term pf Theta - G_c/eps and the flux G_c eps grad(pf)
+      double Th[27];
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+        Th[m] = 0.0;
+      add_square<0x7f>(T, lam, Th);
+      poly_for<3>([&](auto Cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(Cc)::value;
+        constexpr int mc = c == 0 ? NOX : (c == 1 ? NOY : NOZ);
+        double P[8];
+        poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+          if constexpr ((mc >> decltype(Ic)::value) & 1)
+            P[decltype(Ic)::value] = G(Cc, Cc, Ic);
+        });
+        add_square<mc>(P, mu2, Th);
+      });
+      poly_for<3>([&](auto Pc) __attribute__((always_inline)) {
+        constexpr int pr = decltype(Pc)::value;
+        constexpr int c = pr == 2 ? 1 : 0, d = pr == 0 ? 1 : 2; // (0,1), (0,2), (1,2)
+        constexpr int mc = c == 0 ? NOX : NOY, md = d == 1 ? NOY : NOZ;
+        using IC = std::integral_constant<int, c>;
+        using ID = std::integral_constant<int, d>;
+        double Sp[8];
+        poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int idx = decltype(Ic)::value;
+          constexpr bool hd = (md >> idx) & 1, hc = (mc >> idx) & 1;
+          if constexpr (hd && hc)
+            Sp[idx] = G(IC{}, ID{}, Ic) + G(ID{}, IC{}, Ic);
+          else if constexpr (hd)
+            Sp[idx] = G(IC{}, ID{}, Ic);
+          else if constexpr (hc)
+            Sp[idx] = G(ID{}, IC{}, Ic);
+        });
+        add_square<(mc | md)>(Sp, mu, Th); // mu t_cd^2
+      });
+#pragma unroll
+      for (int m = 0; m < 27; ++m)
+        Th[m] *= c_g;
+      Th[0] += c_r3;
+      poly_for<7>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int idx = decltype(Ic)::value;
+        Th[pow_of(idx, 0)] = fma(c_r2, T[idx], Th[pow_of(idx, 0)]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      // H_Theta[p + 3 q + 9 r] = sum_abc Theta_abc I(a + p) I(b + q) I(c + r), I(n) = integral of t^n
+      double B1[27], B2[27], HT[27];
+      poly_for<3>([&](auto Pp) __attribute__((always_inline)) {
+        constexpr int pp = decltype(Pp)::value;
+#pragma unroll
+        for (int bc = 0; bc < 9; ++bc)
+          B1[pp + 3 * bc] = GqMom<pp>::v * Th[3 * bc] + GqMom<pp + 1>::v * Th[3 * bc + 1] + GqMom<pp + 2>::v * Th[3 * bc + 2];
+      });
+      poly_for<3>([&](auto Qp) __attribute__((always_inline)) {
+        constexpr int qp = decltype(Qp)::value;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc)
+            B2[pp + 3 * qp + 9 * cc] =
+              GqMom<qp>::v * B1[pp + 9 * cc] + GqMom<qp + 1>::v * B1[pp + 3 + 9 * cc] + GqMom<qp + 2>::v * B1[pp + 6 + 9 * cc];
+      });
+      poly_for<3>([&](auto Rp) __attribute__((always_inline)) {
+        constexpr int rp = decltype(Rp)::value;
+#pragma unroll
+        for (int pq = 0; pq < 9; ++pq)
+          HT[pq + 9 * rp] = GqMom<rp>::v * B2[pq] + GqMom<rp + 1>::v * B2[pq + 9] + GqMom<rp + 2>::v * B2[pq + 18];
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      double Pf[8];
+      load8(3, Pf);
+      monomials(Pf);
+      poly_for<8>([&](auto Psi) __attribute__((always_inline)) {
+        constexpr int psi = decltype(Psi)::value;
+        constexpr double Ipsi = GqMom<(psi & 1)>::v * GqMom<((psi >> 1) & 1)>::v * GqMom<(psi >> 2)>::v;
+        double val = -c_r3 * Ipsi;
+        poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int idx = decltype(Ic)::value;
+          val = fma(Pf[idx], HT[pow_of(idx, psi)], val);
+        });
+        Madd(Psi, I3{}, vol * val);
+      });
+      poly_for<3>([&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        constexpr int a1 = k == 0 ? 1 : 0, a2 = k == 2 ? 1 : 2;
+        poly_for<4>([&](auto Jl) __attribute__((always_inline)) {
+          constexpr int midx = ((decltype(Jl)::value & 1) << a1) | ((decltype(Jl)::value >> 1) << a2);
+          double val = 0.0;
+          bool any = false;
+          poly_for<8>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int idx = decltype(Ic)::value;
+            if constexpr (!(idx & (1 << k)))
+              {
+                constexpr int pw = pow_of(idx, midx);
+                constexpr double Ic3 = GqMom<pw % 3>::v * GqMom<(pw / 3) % 3>::v * GqMom<pw / 9>::v;
+                val = any ? fma(Pf[idx | (1 << k)], Ic3, val) : Pf[idx | (1 << k)] * Ic3;
+                any = true;
+              }
+          });
+          Madd(std::integral_constant<int, (1 << k) | midx>{}, I3{}, S.geih[k] * val);
+        });
+      });
+    }
+
     template <bool LIN>
     __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3(DevView v, CartView cv, Scal S,
                                                                  double *__restrict__ res_pde,
@@ -502,9 +781,11 @@ namespace pfm
                   mu = cv.cell_mu[cidx];
                 }
               const double mu2 = 2 * mu;
+              if constexpr (LIN)
+                residual_cell_poly(Ulo, Uhi, S, lam, mu, M);
               double Dy0[4], dDy[4]; // d/dy at x-vertex 0 and its x-difference: depend on the z-level only
 #pragma unroll 1
-              for (int p = 0; p < 9; ++p)
+              for (int p = 0; p < (LIN ? 0 : 9); ++p)
                 {
                   const int qy = p % 3, qz = p / 3;
                   const double eta = c_t1.n[1][qy], zeta = c_t1.n[1][qz];

@@ -28,6 +28,7 @@
 //   c(q) = (1-kappa) sigma+:E + G_c/eps - 2(alpha_B-1) p div u + gamma/dt/diam^2 [pf >= pf_old].
 #include "pfm_internal.h"
 #include "pfm_cart_common.h"
+#include "pfm_poly.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -553,20 +554,6 @@ namespace pfm
     // coefficients per field (12 subtractions), coefficient products (<= 64 per role field), three contraction stages of 54
     // FMAs per (d,k) -- no q-point is ever visited.  ~1100 instead of ~2500 instructions per cell and (phi,u) role, ~600 for
     // the (phi,phi) role; the z-contraction happens in registers, so a cell pushes ONCE per role (64 instead of 192 LDS adds).
-    __device__ __forceinline__ void monomials(double (&v)[8]) // in: vertex values, index x + 2 y + 4 z; out: coefficient of t^a s^b r^c at a + 2 b + 4 c
-    {
-#pragma unroll
-      for (int i = 0; i < 8; i += 2)
-        v[i + 1] -= v[i];
-      v[2] -= v[0], v[3] -= v[1], v[6] -= v[4], v[7] -= v[5];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        v[i + 4] -= v[i];
-    }
-    constexpr int pow_of(int ia, int ip) // power index i_x + 3 i_y + 9 i_z of the product of two multilinear monomials
-    {
-      return ((ia & 1) + (ip & 1)) + 3 * (((ia >> 1) & 1) + ((ip >> 1) & 1)) + 9 * (((ia >> 2) & 1) + ((ip >> 2) & 1));
-    }
     // the derivative along axis c of a trilinear field has no monomial with t_c: A^{dk} has a coefficient at idx iff ...
     constexpr bool a_nz(int D, int K, int idx) { return K == D ? idx != 7 : (!(idx & (1 << K)) || !(idx & (1 << D))); }
     constexpr bool pair_first(int D, int K, int ia, int ip) // first (ia outer, ip inner) contribution to its power?
@@ -731,30 +718,6 @@ namespace pfm
         }
     }
 
-    // sum += w p^2 for a multilinear polynomial p whose coefficients outside MASK (bit idx) vanish structurally
-    template <int MASK>
-    __device__ __forceinline__ void add_square(const double (&p)[8], double w, double (&Q)[27])
-    {
-      double pw1[8], pw2[8]; // w p_i, 2 w p_i
-      static_for<8>([&](auto Ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(Ic)::value;
-        if constexpr ((MASK >> i) & 1)
-          {
-            pw1[i] = w * p[i];
-            pw2[i] = pw1[i] + pw1[i];
-          }
-      });
-      static_for<8>([&](auto Ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(Ic)::value;
-        if constexpr ((MASK >> i) & 1)
-          static_for<8>([&](auto Jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(Jc)::value;
-            if constexpr (j >= i && ((MASK >> j) & 1))
-              Q[pow_of(i, j)] = fma(j == i ? pw1[i] : pw2[i], p[j], Q[pow_of(i, j)]);
-          });
-      });
-    }
-
     template <bool HET>
     __device__ __forceinline__ void pp_role_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
                                                  double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
@@ -787,7 +750,6 @@ namespace pfm
           using I4 = std::integral_constant<int, 4>;
           using I5 = std::integral_constant<int, 5>;
           using I6 = std::integral_constant<int, 6>;
-          constexpr int NOX = 0x55, NOY = 0x33, NOZ = 0x0f; // monomials without t, without s, without r
           double Q[27];
 #pragma unroll
           for (int m = 0; m < 27; ++m)
