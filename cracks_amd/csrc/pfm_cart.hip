@@ -138,6 +138,163 @@ namespace pfm
     // read once per tile, and a wave waits for one memory round trip per row that the evaluation of the previous row
     // covers.  LIN: one combined old phase field as in k_cart_residual3.
     // =====================================================================================
+    // ---- round 4: one cell of k_cart_residual2m (LIN) without a quadrature loop -- residual_cell_poly (below) in 2-D: bilinear
+    // fields, 9 discrete moments of the clamped pfx^2, M[i][j][c] = moments against t^i s^j
+    __device__ __forceinline__ void residual_cell_poly2(const double (&lo)[4], const double (&lo1)[4], const double (&up)[4],
+                                                        const double (&up1)[4], const Scal &S, double lam, double mu, double (&M)[2][2][3])
+    {
+      const double c_g = S.c_g, c_pd = S.c_pd, c_r2 = S.c_r2, c_r3 = S.c_r3, vol = S.vol;
+      const double(&ih)[3] = S.ih;
+      const double(&vih)[3] = S.vih;
+      auto Madd = [&](auto Psi, auto Cc, double x) __attribute__((always_inline)) {
+        constexpr int psi = decltype(Psi)::value, c = decltype(Cc)::value;
+        M[psi & 1][psi >> 1][c] += x;
+      };
+      double Hg[9], HP4[4];
+      {
+        double W[4] = {lo[3], lo1[3], up[3], up1[3]}; // LIN: the combined old field
+        monomials2(W);
+        double Pq[9];
+        poly_for<3>([&](auto Qx) __attribute__((always_inline)) {
+          constexpr int qx = decltype(Qx)::value;
+          const double x0 = fma(GqT<qx>::v, W[1], W[0]), x1 = fma(GqT<qx>::v, W[3], W[2]);
+          poly_for<3>([&](auto Qy) __attribute__((always_inline)) {
+            constexpr int qy = decltype(Qy)::value;
+            double pfx = fma(GqT<qy>::v, x1, x0);
+            if (!S.use_old)
+              pfx = fmin(fmax(pfx, 0.0), 1.0); // cracks.cc:2270-2277
+            Pq[qx + 3 * qy] = pfx * pfx;
+          });
+        });
+        double A1[9];
+        poly_for<3>([&](auto Pp) __attribute__((always_inline)) {
+          constexpr int pp = decltype(Pp)::value;
+#pragma unroll
+          for (int qy = 0; qy < 3; ++qy)
+            A1[pp + 3 * qy] = GqWt<0, pp>::v * Pq[3 * qy] + GqWt<1, pp>::v * Pq[3 * qy + 1] + GqWt<2, pp>::v * Pq[3 * qy + 2];
+        });
+        poly_for<9>([&](auto Mm) __attribute__((always_inline)) {
+          constexpr int m = decltype(Mm)::value, pp = m % 3, qp = m / 3;
+          const double hp = GqWt<0, qp>::v * A1[pp] + GqWt<1, qp>::v * A1[pp + 3] + GqWt<2, qp>::v * A1[pp + 6];
+          constexpr double Im = GqMom<pp>::v * GqMom<qp>::v;
+          Hg[m] = fma(c_g, hp, S.kappa * Im);
+          if constexpr (pp < 2 && qp < 2)
+            HP4[pp + 2 * qp] = hp;
+        });
+      }
+      double F[2][4];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        {
+          F[f][0] = lo[f], F[f][1] = lo1[f], F[f][2] = up[f], F[f][3] = up1[f];
+          monomials2(F[f]);
+        }
+      auto G = [&](auto Cc, auto Kc, auto Ic) __attribute__((always_inline)) -> double { // d_k u_c, coefficient idx
+        constexpr int c = decltype(Cc)::value, k = decltype(Kc)::value, idx = decltype(Ic)::value;
+        static_assert(!(idx & (1 << k)), "no such monomial in this derivative");
+        return ih[k] * F[c][idx | (1 << k)];
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      constexpr int N2X = 0x5, N2Y = 0x3; // monomials without t: {1, s}; without s: {1, t}
+      const double T[4] = {G(I0{}, I0{}, I0{}) + G(I1{}, I1{}, I0{}), G(I1{}, I1{}, I1{}), G(I0{}, I0{}, I2{}), 0.0}; // div u
+      const double mu2 = 2.0 * mu;
+      poly_for<2>([&](auto Cc) __attribute__((always_inline)) {
+        poly_for<2>([&](auto Kc) __attribute__((always_inline)) {
+          constexpr int c = decltype(Cc)::value, k = decltype(Kc)::value;
+          constexpr int mc = c == 0 ? N2X : N2Y, mk = k == 0 ? N2X : N2Y;
+          double sg[4]; // sigma_ck = lambda div u delta_ck + mu (d_k u_c + d_c u_k): coefficients 0, 1, 2
+          poly_for<3>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int idx = decltype(Ic)::value;
+            if constexpr (c == k)
+              {
+                if constexpr ((mc >> idx) & 1)
+                  sg[idx] = fma(mu2, G(Cc, Cc, Ic), lam * T[idx]);
+                else
+                  sg[idx] = lam * T[idx];
+              }
+            else
+              {
+                constexpr bool hk = (mk >> idx) & 1, hc = (mc >> idx) & 1;
+                if constexpr (hk && hc)
+                  sg[idx] = mu * (G(Cc, Kc, Ic) + G(Kc, Cc, Ic));
+                else if constexpr (hk)
+                  sg[idx] = mu * G(Cc, Kc, Ic);
+                else
+                  sg[idx] = mu * G(Kc, Cc, Ic);
+              }
+          });
+          poly_for<2>([&](auto Jc) __attribute__((always_inline)) {
+            constexpr int midx = decltype(Jc)::value << (1 - k); // the monomial 1 or x_other
+            double val = sg[0] * Hg[pow2_of(0, midx)];
+            val = fma(sg[1], Hg[pow2_of(1, midx)], val);
+            val = fma(sg[2], Hg[pow2_of(2, midx)], val);
+            if constexpr (c == k)
+              val = fma(-c_pd, HP4[midx], val);
+            Madd(std::integral_constant<int, (1 << k) | midx>{}, Cc, vih[k] * val);
+          });
+        });
+      });
+      // phase-field row
+      double Th[9];
+#pragma unroll
+      for (int m = 0; m < 9; ++m)
+        Th[m] = 0.0;
+      add_square2<0x7>(T, lam, Th);
+      {
+        const double P0[4] = {G(I0{}, I0{}, I0{}), 0.0, G(I0{}, I0{}, I2{}), 0.0};
+        add_square2<N2X>(P0, mu2, Th);
+        const double P1[4] = {G(I1{}, I1{}, I0{}), G(I1{}, I1{}, I1{}), 0.0, 0.0};
+        add_square2<N2Y>(P1, mu2, Th);
+        const double Sp[4] = {G(I0{}, I1{}, I0{}) + G(I1{}, I0{}, I0{}), G(I0{}, I1{}, I1{}), G(I1{}, I0{}, I2{}), 0.0};
+        add_square2<0x7>(Sp, mu, Th); // mu t_01^2
+      }
+#pragma unroll
+      for (int m = 0; m < 9; ++m)
+        Th[m] *= c_g;
+      Th[0] += c_r3;
+      poly_for<3>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int idx = decltype(Ic)::value;
+        Th[pow2_of(idx, 0)] = fma(c_r2, T[idx], Th[pow2_of(idx, 0)]);
+      });
+      double B1[9], HT[9];
+      poly_for<3>([&](auto Pp) __attribute__((always_inline)) {
+        constexpr int pp = decltype(Pp)::value;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          B1[pp + 3 * b] = GqMom<pp>::v * Th[3 * b] + GqMom<pp + 1>::v * Th[3 * b + 1] + GqMom<pp + 2>::v * Th[3 * b + 2];
+      });
+      poly_for<3>([&](auto Qp) __attribute__((always_inline)) {
+        constexpr int qp = decltype(Qp)::value;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+          HT[pp + 3 * qp] = GqMom<qp>::v * B1[pp] + GqMom<qp + 1>::v * B1[pp + 3] + GqMom<qp + 2>::v * B1[pp + 6];
+      });
+      double Pf[4] = {lo[2], lo1[2], up[2], up1[2]};
+      monomials2(Pf);
+      poly_for<4>([&](auto Psi) __attribute__((always_inline)) {
+        constexpr int psi = decltype(Psi)::value;
+        constexpr double Ipsi = GqMom<(psi & 1)>::v * GqMom<(psi >> 1)>::v;
+        double val = -c_r3 * Ipsi;
+        poly_for<4>([&](auto Ic) __attribute__((always_inline)) {
+          constexpr int idx = decltype(Ic)::value;
+          val = fma(Pf[idx], HT[pow2_of(idx, psi)], val);
+        });
+        Madd(Psi, I2{}, vol * val);
+      });
+      poly_for<2>([&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        poly_for<2>([&](auto Jc) __attribute__((always_inline)) {
+          constexpr int j = decltype(Jc)::value, midx = j << (1 - k);
+          // d_k pf = ih_k (Pf[1 << k] + x_other Pf[3]); integral against the monomial midx
+          constexpr double Ia = GqMom<j>::v, Ib = GqMom<j + 1>::v;
+          const double val = fma(Pf[3], Ib, Pf[1 << k] * Ia);
+          Madd(std::integral_constant<int, (1 << k) | midx>{}, I2{}, S.geih[k] * val);
+        });
+      });
+    }
+
     constexpr int R2N = 62; // owned nodes per wave
     template <bool LIN>
     __global__ __launch_bounds__(64) void k_cart_residual2m(DevView v, CartView cv, Scal S, double *__restrict__ res_pde,
@@ -233,8 +390,10 @@ namespace pfm
                   dDy[f] = (up1[f] - lo1[f]) * ihy - Dy0[f];
                 }
               const double mu2 = 2 * mu;
+              if constexpr (LIN)
+                residual_cell_poly2(lo, lo1, up, up1, S, lam, mu, M);
 #pragma unroll 1
-              for (int qy = 0; qy < 3; ++qy)
+              for (int qy = 0; qy < (LIN ? 0 : 3); ++qy)
                 {
                   const double eta = c_t1.n[1][qy];
                   const double wy = vol * c_t1.w[qy];

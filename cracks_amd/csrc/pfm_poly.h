@@ -92,5 +92,29 @@ namespace pfm
       static constexpr double v = gq_t(Q);
     };
     constexpr int NOX = 0x55, NOY = 0x33, NOZ = 0x0f; // monomial masks: without t, without s, without r
+
+    // ---- the same in 2-D: bilinear fields, 4 monomial coefficients (index a + 2 b), products with 9 (power index i_x + 3 i_y)
+    __device__ __forceinline__ void monomials2(double (&v)[4])
+    {
+      v[1] -= v[0], v[3] -= v[2];
+      v[2] -= v[0], v[3] -= v[1];
+    }
+    constexpr int pow2_of(int ia, int ip) { return ((ia & 1) + (ip & 1)) + 3 * (((ia >> 1) & 1) + ((ip >> 1) & 1)); }
+    template <int MASK>
+    __device__ __forceinline__ void add_square2(const double (&p)[4], double w, double (&Q)[9])
+    {
+      poly_for<4>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(Ic)::value;
+        if constexpr ((MASK >> i) & 1)
+          {
+            const double a = w * p[i], a2 = a + a;
+            poly_for<4>([&](auto Jc) __attribute__((always_inline)) {
+              constexpr int j = decltype(Jc)::value;
+              if constexpr (j >= i && ((MASK >> j) & 1))
+                Q[pow2_of(i, j)] = fma(j == i ? a : a2, p[j], Q[pow2_of(i, j)]);
+            });
+          }
+      });
+    }
   } // namespace
 } // namespace pfm
