@@ -637,14 +637,21 @@ namespace
   // lattice nodes around it is hanging -- its row is then the plain 9-point row of that level, completed by one workgroup
   // of the patch kernel.  Blocks of 8 x 8 cells (7 x 7 nodes owned per block) tile each level; the general family keeps
   // the cells that touch any other row (reduced colour lists), and skips the regular rows.
-  void build_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, const std::vector<int32_t> &hn_index, const std::vector<int32_t> &order,
-                       const std::vector<uint8_t> &ring)
+  // host-only part (no context access: it runs on its own thread next to the uploads and the node graph build)
+  struct PatchPlan
   {
-    DevView &v = c->v;
+    std::vector<uint8_t> regular, hang; // per node: row of the patch kernel; hanging or duplicated position
+    std::vector<int32_t> blk_cells, blk_nodes, rows_general;
+    int64_t n_regular = 0;
+    int n_blocks = 0;
+  };
+  PatchPlan plan_patches2d(const pfm_mesh_desc *m, const std::vector<int32_t> &hn_index)
+  {
+    PatchPlan pl;
     const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
     const int64_t NC = m->n_cells;
     if (m->dim != 2 || NC == 0 || getenv("PFM_NO_PATCH"))
-      return;
+      return pl;
     const double *X = m->coords;
     double xmin = X[0], ymin = X[1], xmax = X[0], ymax = X[1];
     for (int32_t n = 0; n < N; ++n)
@@ -697,7 +704,12 @@ namespace
         lv.iy1 = std::max(lv.iy1, iy);
       }
     if (levels.empty())
-      return;
+      return pl;
+    // cells by level (the per-level tables below walk their own cells only)
+    std::vector<std::vector<int32_t>> level_cells(levels.size());
+    for (int64_t k = 0; k < NC; ++k)
+      if (cell_level[k] >= 0)
+        level_cells[(size_t)cell_level[k]].push_back((int32_t)k);
     // incident cells per node: count, common level, the 4 cells by the vertex the node is of them
     std::vector<uint8_t> n_inc((size_t)N, 0), is_parent((size_t)N, 0);
     std::vector<int8_t> node_level((size_t)N, -2); // -2 none yet, -1 mixed / off-lattice
@@ -726,8 +738,7 @@ namespace
         if ((double)W * (double)Hh > 4.0e8)
           continue;
         std::vector<int32_t> node_at((size_t)(W * Hh), -1);
-        for (int64_t k = 0; k < NC; ++k)
-          if (cell_level[k] == (int8_t)L)
+        for (const int32_t k : level_cells[L])
             for (int a = 0; a < 4; ++a)
               {
                 const int32_t n = m->cell_nodes[4 * k + a];
@@ -761,8 +772,6 @@ namespace
             ok = cix[k2] == cix[k3] + 1 && ciy[k2] == ciy[k3] && cix[k1] == cix[k3] && ciy[k1] == ciy[k3] + 1 && cix[k0] == cix[k3] + 1 &&
                  ciy[k0] == ciy[k3] + 1;
           }
-        if (ok && c->h_nadj_ptr.size() == (size_t)NO + 1)
-          ok = c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n] == 9;
         if (ok)
           {
             regular[n] = 1;
@@ -770,7 +779,7 @@ namespace
           }
       }
     if (n_regular == 0)
-      return;
+      return pl;
     // blocks: block (bx, by) of a level owns the lattice nodes [7 bx, 7 bx + 6] x [7 by, 7 by + 6] and holds the cells
     // [7 bx - 1, 7 bx + 6] x [7 by - 1, 7 by + 6]; node (i, j) of the lattice = upper-right vertex of cell (i - 1, j - 1)
     std::vector<int32_t> blk_cells, blk_nodes;
@@ -783,9 +792,8 @@ namespace
         if ((double)W * (double)Hh > 4.0e8)
           continue; // a level whose bounding box is mostly empty: not worth a dense table
         std::vector<int32_t> at((size_t)(W * Hh), -1);
-        for (int64_t k = 0; k < NC; ++k)
-          if (cell_level[k] == (int8_t)L)
-            at[(size_t)((ciy[k] - lv.iy0) * W + (cix[k] - lv.ix0))] = (int32_t)k;
+        for (const int32_t k : level_cells[L])
+          at[(size_t)((ciy[k] - lv.iy0) * W + (cix[k] - lv.ix0))] = k;
         auto cell_at = [&](long long i, long long j) -> int32_t {
           return (i < lv.ix0 || i > lv.ix1 || j < lv.iy0 || j > lv.iy1) ? -1 : at[(size_t)((j - lv.iy0) * W + (i - lv.ix0))];
         };
@@ -829,7 +837,7 @@ namespace
       }
     const int n_blocks = (int)(blk_cells.size() / 64);
     if (n_blocks == 0)
-      return;
+      return pl;
     // only the rows some block really writes are the patch kernel's (a level without a table above keeps its rows general)
     {
       std::vector<uint8_t> covered((size_t)N, 0);
@@ -852,6 +860,38 @@ namespace
     for (int32_t n = 0; n < NO; ++n)
       if (!regular[n])
         rows_general.push_back(n);
+    pl.hang.assign((size_t)N, 0);
+    for (int32_t n = 0; n < N; ++n)
+      pl.hang[n] = hanging(n) ? 1 : 0;
+    pl.regular.swap(regular);
+    pl.blk_cells.swap(blk_cells);
+    pl.blk_nodes.swap(blk_nodes);
+    pl.rows_general.swap(rows_general);
+    pl.n_regular = n_regular;
+    pl.n_blocks = n_blocks;
+    return pl;
+  }
+
+  // context part: reduced colour lists, uploads (after the colour classes and the node graph exist)
+  void finish_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan &pl, const std::vector<int32_t> &order)
+  {
+    DevView &v = c->v;
+    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    const int64_t NC = m->n_cells;
+    if (pl.n_blocks == 0)
+      return;
+    std::vector<uint8_t> &regular = pl.regular;
+    std::vector<int32_t> &blk_cells = pl.blk_cells, &blk_nodes = pl.blk_nodes, &rows_general = pl.rows_general;
+    const int n_blocks = pl.n_blocks;
+    const int64_t n_regular = pl.n_regular;
+    // a regular node has the nine nodes of its 2 x 2 cells in its row and nothing else, by construction; checked where the
+    // node graph is on the host (a violation would mean a coupling this classification does not know: no overlay then)
+    if (c->h_nadj_ptr.size() == (size_t)NO + 1)
+      for (int32_t n = 0; n < NO; ++n)
+        if (regular[n] && c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n] != 9)
+          return;
+    auto hanging = [&](int32_t n) { return pl.hang[n] != 0; };
+    (void)N;
     // reduced lists of the general family: the cells that touch a row the patches do not write
     std::vector<uint8_t> need((size_t)NC, 0);
     for (int64_t k = 0; k < NC; ++k)
@@ -862,7 +902,6 @@ namespace
             need[k] = 1;
         }
     std::vector<int32_t> order_red;
-    std::vector<uint8_t> ring_red;
     c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
     for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
       {
@@ -872,8 +911,6 @@ namespace
             order_red.push_back(order[(size_t)i]);
       }
     c->color_ptr_reduced.back() = (long long)order_red.size();
-    (void)ring;
-    (void)ring_red;
     c->n_general_cells = (int64_t)order_red.size();
     if (order_red.empty())
       order_red.push_back(0);
@@ -1093,6 +1130,22 @@ extern "C"
         std::thread colour_thread;
         if (!lattice_ok && NC > 65536)
           colour_thread = std::thread(colour_classes);
+        // cartesian overlay of a 2-D mesh: the host classification (8 ms at 2.7e5 cells) on its own thread as well
+        PatchPlan patch_plan;
+        std::exception_ptr patch_err;
+        auto plan_patches = [&]() {
+          try
+            {
+              patch_plan = plan_patches2d(m, hn_index);
+            }
+          catch (...)
+            {
+              patch_err = std::current_exception();
+            }
+        };
+        std::thread patch_thread;
+        if (dim == 2 && NC > 65536)
+          patch_thread = std::thread(plan_patches);
         struct Joiner
         {
           std::thread &t;
@@ -1101,7 +1154,7 @@ extern "C"
             if (t.joinable())
               t.join();
           }
-        } colour_joiner{colour_thread}; // an exception on the way must not leave a running thread behind
+        } colour_joiner{colour_thread}, patch_joiner{patch_thread}; // an exception on the way must not leave a running thread behind
 
         // ---- device mirrors (SoA)
         {
@@ -1195,7 +1248,13 @@ extern "C"
         v.color_cells = dev_upload(c, order.data(), order.size());
         v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
         clk.mark("colour classes");
-        build_patches2d(c, m, hn_index, order, ring);
+        if (patch_thread.joinable())
+          patch_thread.join();
+        else
+          plan_patches();
+        if (patch_err)
+          std::rethrow_exception(patch_err);
+        finish_patches2d(c, m, patch_plan, order);
         clk.mark("cartesian overlay (2-D)");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
