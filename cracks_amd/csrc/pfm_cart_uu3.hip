@@ -278,6 +278,8 @@ namespace pfm
       __shared__ double s_u[RES ? 3 * NH3 : 1];                    // displacements of the halo nodes [component][node]
       __shared__ double s_part[RES ? 2 * 8 * NN3 : 1];             // K u per [component & 1][wave = slot set][node]
       __shared__ double s_pres[RES ? 3 * NN3 : 1];                 // pressure part of the residual [component][node]
+      __shared__ int s_resrow[RES ? NN3 : 1]; // local id of the tile's nodes (residual rows): looked up ONCE, before any store of the
+                                               // workgroup -- a table look-up behind the copy-out stores is a wait for them (round 4)
       __shared__ int s_any[4]; // waves 0..2: some node of the halo carries a displacement flag; [3]: some row is not full
       static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
 
@@ -349,6 +351,8 @@ namespace pfm
               const int r = cart_local_id(cv, gi, gj, k);
               base = (long long)NCOL * NCOL * v.nadj_ptr[r];
               mask = cv.nbr_mask[r];
+              if constexpr (RES)
+                s_resrow[nl] = r;
             }
           s_rowbase[nl] = base;
           s_mask[nl] = mask;
@@ -703,7 +707,7 @@ namespace pfm
                 for (int w = 0; w < 8; ++w)
                   sum += s_part[((c & 1) * 8 + w) * NN3 + t]; // component 2 reuses buffer 0 behind the barrier of component 1
                 const int li = t % T3X, lj = t / T3X;
-                const int row = cart_local_id(cv, i0 + li, j0 + lj, k);
+                const int row = s_resrow[RES ? t : 0];
                 const bool con = (s_flag[(li + 1) + H3X * ((lj + 1) + H3Y * 1)] >> c) & 1u;
                 const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + c : (long long)row * 3 + c;
                 res_pde[di] = con ? 0.0 : -sum;
