@@ -101,7 +101,11 @@ rm -rf $O/stats $O/stats_res $O/pmc_sq $O/pmc_lds $O/pmc_WRITE_SIZE $O/pmc_FETCH
 # profiles/r*/ summary whose source hash matches; the first run above could only see the previous ones)
 mkdir -p $R/profiles/$TAG
 cp $O/hbm_traffic_3d_216.json $O/instruction_mix_*.json $R/profiles/$TAG/
-cd $R && python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err; cd /tmp
+cd $R && python bench.py > $O/bench_216cube.json 2> $O/bench_216cube.err
+python bench.py --residual-only --no-cpu-baseline --no-extras > $O/bench_216cube_residual_only.json 2>/dev/null
+python bench.py --dim 2 --residual-only --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_residual_only.json 2>/dev/null
+python bench.py --dim 2 --no-cpu-baseline --no-extras > $O/bench_2d_1000sq_jacobian.json 2>/dev/null
+cd /tmp
 grep -h "k_cart\|k_state" $O/rocprofv3_kernel_stats_216cube.csv | cut -c1-60,150-260
 python -c "
 import json
