@@ -29,6 +29,7 @@
 #include "pfm_internal.h"
 #include "pfm_cart_common.h"
 #include "pfm_poly.h"
+#include "pfm_dma.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -62,31 +63,7 @@ namespace pfm
     };
 
 
-    // d/dy of one nodal field at x-vertex 0/1: depends on the z-level only, evaluated once per qz
-    // global -> LDS without staging registers: LDS address = (wave-uniform) lds + lane * size.  Written as asm so that
-    // the compiler does not track the transfer: it would otherwise wait vmcnt(0) at every later LDS access of the
-    // same __shared__ object (no alias information inside one struct), serialising the requests.  The consumer waits
-    // with an explicit s_waitcnt vmcnt(0) before the workgroup barrier.
-    // address = uniform base (SGPR pair) + per-lane byte offset (one VGPR shared by all fields of a plane)
-    __device__ __forceinline__ void dma_b32(const void *base, unsigned byte_off, void *lds)
-    {
-      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(byte_off), "s"(base), "s"(l)
-                   : "memory");
-    }
-    // one byte per lane, zero-extended to the lane's dword in LDS
-    __device__ __forceinline__ void dma_u8(const void *base, unsigned byte_off, void *lds)
-    {
-      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(byte_off), "s"(base), "s"(l)
-                   : "memory");
-    }
+    // (global -> LDS transfers: pfm_dma.h)
     // The 8 vertex values of one nodal field of a cell are read from the nodal ring ONCE per cell and role (the
     // compiler cannot keep LDS values across the LDS-side adds of the pushes by itself), as the 4 values of the lower
     // z-face a[0..3] (index x + 2 y) and the z-derivative (upper - lower) / h_z at the same 4 positions a[4..7].
