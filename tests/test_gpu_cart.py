@@ -494,3 +494,44 @@ def test_bench_reports_the_config5_standin():
     for key in ("jacobian_ms", "residual_only_ms", "context_rebuild_ms", "jacobian_hbm_frac"):
         assert rec[key] > 0.0
     assert rec["hanging_nodes"] > 0
+
+
+def test_general_family_launch_modes_agree(tmp_path):
+    """The same 2-D assembly of a mesh with hanging nodes and the stress split in its launch modes: default (cartesian
+    overlay: patch kernel on the stream, the rest of the general family next to it), PFM_NO_PATCH=1 (general family alone, the
+    atomic class on the side stream), PFM_NO_PATCH=1 PFM_GENERAL_SEQUENTIAL=1 (one class after the other).  Rows away from
+    hanging nodes are bitwise equal between the two general-family modes (one colour class at a time writes them); everything
+    agrees to round-off.  The modes are chosen when the library is first used / the context is made: one process each."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    here = os.path.dirname(os.path.abspath(__file__))
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+        "import cases\n"
+        "from gpu_util import make_context\n"
+        "c = cases.perturbed(cases.kat_miehe_tension())  # the reference's adaptive Miehe tension mesh: hanging nodes, slit, split\n"
+        "c.params.timestep_number = 1\n"
+        "ctx = make_context(c)\n"
+        "values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)\n"
+        "np.save(sys.argv[1], np.concatenate([np.ravel(x) for x in values]))\n"
+        "np.save(sys.argv[2], res)\n"
+        "open(sys.argv[3], 'w').write(str(ctx.kernel_path))\n")
+    val, rhs, path = {}, {}, {}
+    modes = (("overlay", {}), ("general", {"PFM_NO_PATCH": "1"}), ("general_seq", {"PFM_NO_PATCH": "1", "PFM_GENERAL_SEQUENTIAL": "1"}))
+    for tag, env in modes:
+        f, g, h = tmp_path / f"{tag}.npy", tmp_path / f"{tag}_rhs.npy", tmp_path / f"{tag}.txt"
+        e = {k: v for k, v in os.environ.items() if k not in ("PFM_NO_PATCH", "PFM_GENERAL_SEQUENTIAL")}
+        e.update(env)
+        subprocess.run([sys.executable, str(script), str(f), str(g), str(h)], check=True, env=e, timeout=600)
+        val[tag], rhs[tag], path[tag] = np.load(f), np.load(g), int(open(h).read())
+    assert path["general"] == 0 and path["general_seq"] == 0 and path["overlay"] in (0, 3)
+    for tag in ("general", "overlay"):
+        assert val[tag].shape == val["general_seq"].shape
+        assert linf_scaled(val[tag], val["general_seq"]) < TOL and linf_scaled(rhs[tag], rhs["general_seq"]) < TOL
+    # side stream or not: only the entries that receive atomic adds (rows next to hanging nodes) may differ in the last bit
+    same = val["general"] == val["general_seq"]
+    assert same.mean() > 0.5
