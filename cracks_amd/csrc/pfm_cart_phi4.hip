@@ -894,7 +894,15 @@ namespace pfm
       // in the lattice table (a load inside a branch, which the compiler waits for at the join with vmcnt(0)); with the
       // transfers of the same step already in flight that wait made them synchronous (round 4: ids of the plane AND of
       // the rows first, then all requests)
-      auto plane_node = [&](int kz, bool &ok, bool &inside, int &dw) __attribute__((always_inline)) -> unsigned {
+      // single-rank box (every lattice node owned, numbered lexicographically): ids by arithmetic, no table, no load -- and
+      // therefore no wait in front of the requests (the look-up path waits for its loads there with vmcnt(0), i.e. for the
+      // copy-out stores of the previous step as well)
+      const bool all_lex = cv.owned_lex && cv.o0[0] == 0 && cv.o0[1] == 0 && cv.o0[2] == 0 && cv.o1[0] == cv.NX - 1 &&
+                           cv.o1[1] == cv.NY - 1 && cv.o1[2] == cv.NZ - 1;
+      auto lex_id = [&](int gi, int gj, int gk) __attribute__((always_inline)) -> unsigned {
+        return (unsigned)(gi + cv.NX * (gj + cv.NY * gk));
+      };
+      auto plane_node = [&](int kz, bool &ok, bool &inside, int &dw, bool lex) __attribute__((always_inline)) -> unsigned {
         int lq = lane;
         asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
         dw = 64 * role + lq;
@@ -902,6 +910,8 @@ namespace pfm
         const int gi = i0 - 1 + hn % PH, gj = j0 - 1 + hn / PH;
         inside = dw < 2 * NPH;
         ok = role < 3 && inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
+        if (lex)
+          return ok ? lex_id(gi, gj, kz) : 0u;
         return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
       };
       auto dma_plane_at = [&](unsigned n, bool ok, bool inside, int dw, int buf, int kz) __attribute__((always_inline)) {
@@ -928,14 +938,16 @@ namespace pfm
       auto dma_plane = [&](int kz, int buf) __attribute__((always_inline)) {
         bool ok, inside;
         int dw;
-        const unsigned n = plane_node(kz, ok, inside, dw);
+        const unsigned n = plane_node(kz, ok, inside, dw, false);
         dma_plane_at(n, ok, inside, dw, buf, kz);
       };
-      auto rows_node = [&](int kz, bool &ok) __attribute__((always_inline)) -> unsigned {
+      auto rows_node = [&](int kz, bool &ok, bool lex) __attribute__((always_inline)) -> unsigned {
         int lq = lane;
         asm volatile("" : "+v"(lq));
         const int gi = i0 + lq % PN, gj = j0 + lq / PN;
         ok = role == 3 && lq < NPN && gi <= cv.o1[0] && gj <= cv.o1[1];
+        if (lex)
+          return ok ? lex_id(gi, gj, kz) : 0xffffffffu;
         return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0xffffffffu;
       };
       auto dma_rows_at = [&](unsigned n, bool ok, int kz) __attribute__((always_inline)) {
@@ -963,7 +975,7 @@ namespace pfm
       };
       auto dma_rows = [&](int kz) __attribute__((always_inline)) {
         bool ok;
-        const unsigned n = rows_node(kz, ok);
+        const unsigned n = rows_node(kz, ok, false);
         dma_rows_at(n, ok, kz);
       };
 
@@ -1207,11 +1219,20 @@ namespace pfm
               // ids first (possible table look-ups and their waits), then every request of the step
               bool okp, inp, okr;
               int dwp;
-              const unsigned np_ = plane_node(ck + 2, okp, inp, dwp);
-              const unsigned nr_ = rows_node(ck + 1, okr);
-              // a use on every path: a table look-up of cart_local_id left pending where the requests are skipped would be
-              // waited for with vmcnt(0) wherever its register is written next -- at the top of the next step, behind the stores
-              asm volatile("" ::"v"(np_), "v"(nr_));
+              unsigned np_, nr_;
+              if (all_lex)
+                {
+                  np_ = plane_node(ck + 2, okp, inp, dwp, true);
+                  nr_ = rows_node(ck + 1, okr, true);
+                }
+              else
+                {
+                  np_ = plane_node(ck + 2, okp, inp, dwp, false);
+                  nr_ = rows_node(ck + 1, okr, false);
+                  // a use on every path: a table look-up of cart_local_id left pending where the requests are skipped would be
+                  // waited for with vmcnt(0) wherever its register is written next -- at the top of the next step, behind the stores
+                  asm volatile("" ::"v"(np_), "v"(nr_));
+                }
               dma_plane_at(np_, okp, inp, dwp, lo, ck + 2); // slot lo (plane ck) is dead once the entries of layer ck are done
               dma_rows_at(nr_, okr, ck + 1);
             }
