@@ -69,3 +69,24 @@ def sneddon_2d_setup() -> ProblemSetup:
                         initial_bc=lambda time: {int(d): 0.0 for d in dd}, solution0=c.sol.copy(), E_modulus=1.0,
                         timestep=1.0, max_no_timesteps=3, newton_tol=1.0e-7, max_newton_steps=50,
                         max_line_search=10, line_search_damping=0.6)
+
+
+def miehe_shear_1_setup() -> ProblemSetup:
+    """tests/miehe_shear_1.prm (direct solver, stress split, dt = 1e-3; its predictor-corrector refinement only starts when the
+    phase field drops: the first time steps run on the 256-cell mesh)."""
+    c = cases.kat_miehe_shear_1()
+    mesh, lay = c.mesh, c.layout
+    top = mesh.boundary_nodes[3]
+    dd = M.miehe_shear_dirichlet_dofs(mesh, lay)
+
+    def initial_bc(time):
+        vals = {int(d): 0.0 for d in dd}
+        for n in top:  # BoundaryShearTest, cracks.cc:838-858
+            vals[int(lay.dof(n, 0))] = -1.0 * time
+        return vals
+
+    sol0 = lay.pack(np.zeros((mesh.n_nodes, 2)), np.ones(mesh.n_nodes))
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd, initial_bc=initial_bc,
+                        solution0=sol0, E_modulus=1.0e3, timestep=1.0e-3, max_no_timesteps=10,
+                        newton_tol=1.0e-6, max_newton_steps=100, max_line_search=10, line_search_damping=0.6,
+                        compute_load=True)

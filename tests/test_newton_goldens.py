@@ -117,3 +117,34 @@ def test_sneddon_2d_on_gpu_end_to_end():
     asm = GpuAssembler(setup.mesh, setup.layout)
     assert asm.ctx.kernel_path in (0, 3)
     _check_sneddon_2d(ActiveSetDriver(setup, asm).run(n_steps=3))
+
+
+LOAD_X_SHEAR_1 = [64.911, 129.566, 193.813, 257.017]  # tests/miehe_shear_1.output, "Load x:" of steps 0..3
+
+
+def _check_miehe_shear_1(recs):
+    """Line-0 residual, energies, load and the number of Newton rows of every step; the first Newton row within 2 % (its
+    active set is decided by round-off where phi == old_phi to the last bit, see check_against_golden)."""
+    g = cases.golden()["miehe_shear_1"]["timesteps"]
+    assert len(recs) == 4
+    for rec, gg, want in zip(recs, g, LOAD_X_SHEAR_1):
+        assert rec.residual0 == pytest.approx(gg["residual0"], rel=5e-6)
+        assert rec.bulk_energy == pytest.approx(gg["bulk_energy"], rel=5e-6)
+        assert rec.crack_energy == pytest.approx(gg["crack_energy"], rel=5e-6)
+        assert rec.load == pytest.approx(want, rel=3e-6)
+        assert len(rec.newton) == len(gg["newton"])  # 4, 5, 4, 4 Newton rows as in the reference's table
+        assert rec.newton[0].residual == pytest.approx(gg["newton"][0]["residual"], rel=2e-2)
+        assert rec.newton[-1].residual < 1e-6
+
+
+def test_miehe_shear_1_first_steps_with_oracle():
+    setup = NC.miehe_shear_1_setup()
+    _check_miehe_shear_1(ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout)).run(n_steps=4))
+
+
+@pytest.mark.gpu
+def test_miehe_shear_1_first_steps_on_gpu():
+    from cracks_amd.newton import GpuAssembler
+
+    setup = NC.miehe_shear_1_setup()
+    _check_miehe_shear_1(ActiveSetDriver(setup, GpuAssembler(setup.mesh, setup.layout)).run(n_steps=4))
