@@ -192,6 +192,7 @@ class ProblemSetup:
     max_line_search: int = 10
     line_search_damping: float = 0.6
     compute_load: bool = False
+    pressure_of_time: Optional[Callable[[float], float]] = None  # func_pressure(time), cracks.cc:2145 (constant when None)
 
 
 class ActiveSetDriver:
@@ -224,6 +225,8 @@ class ActiveSetDriver:
         p.old_timestep, p.old_old_timestep = self.old_timestep, self.old_old_timestep
         p.timestep_number = self.timestep_number
         p.use_old_timestep_pf = 1 if self.use_old_timestep_pf else 0
+        if self.s.pressure_of_time is not None:
+            p.pressure = self.s.pressure_of_time(self.time)
         return p
 
     def _assemble(self, residual_only, cu):

@@ -10,16 +10,24 @@ from cracks_amd.newton import ProblemSetup
 class OracleAssembler:
     """Assembler protocol backed by the CPU oracle (tests only)."""
 
-    def __init__(self, mesh, layout):
+    def __init__(self, mesh, layout, cell_lambda=None, cell_mu=None):
         self.mesh, self.layout = mesh, layout
+        self.cell_lambda, self.cell_mu = cell_lambda, cell_mu
         self.rowptr, self.colind = M.dof_sparsity(mesh, layout)
+        if cell_lambda is not None:  # per-cell material: the energies need it too (cracks.cc:3615-3701 with 2207-2216)
+            self.functionals = self._functionals
+
+    def _functionals(self, sol, old, oldold, params):
+        p = O.PfmParams.from_buffer_copy(bytes(params))
+        return O.functionals(self.mesh, self.layout, p, sol, self.cell_lambda, self.cell_mu)
 
     def assemble(self, residual_only, sol, old, oldold, params, cu, ch):
         import scipy.sparse as sp
 
         p = O.PfmParams.from_buffer_copy(bytes(params))
         r = O.assemble(self.mesh, self.layout, p, sol, old, oldold, cu, ch, residual_only,
-                       None if residual_only else self.rowptr, None if residual_only else self.colind)
+                       None if residual_only else self.rowptr, None if residual_only else self.colind,
+                       cell_lambda=self.cell_lambda, cell_mu=self.cell_mu)
         if r.err:
             raise RuntimeError(f"oracle error {r.err}")
         A = None
@@ -90,3 +98,16 @@ def miehe_shear_1_setup() -> ProblemSetup:
                         solution0=sol0, E_modulus=1.0e3, timestep=1.0e-3, max_no_timesteps=10,
                         newton_tol=1.0e-6, max_newton_steps=100, max_line_search=10, line_search_damping=0.6,
                         compute_load=True)
+
+
+def hetero_3d_setup():
+    """tests/hetero_3d_1.prm (multiple_het: per-cell E modulus, 3-D hanging nodes, pressure 1e3 * time, iterative-solver
+    layout).  Returns (setup, cell_lambda, cell_mu)."""
+    c = cases.kat_hetero_3d()
+    mesh, lay = c.mesh, c.layout
+    dd = M.sneddon_dirichlet_dofs(mesh, lay)
+    setup = ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd,
+                         initial_bc=lambda time: {int(d): 0.0 for d in dd}, solution0=c.sol.copy(), E_modulus=1.0e4,
+                         timestep=0.01, max_no_timesteps=2, newton_tol=1.0e-6, max_newton_steps=20,
+                         max_line_search=8, line_search_damping=0.5, pressure_of_time=lambda t: 1.0e3 * t)
+    return setup, c.cell_lambda, c.cell_mu

@@ -148,3 +148,34 @@ def test_miehe_shear_1_first_steps_on_gpu():
 
     setup = NC.miehe_shear_1_setup()
     _check_miehe_shear_1(ActiveSetDriver(setup, GpuAssembler(setup.mesh, setup.layout)).run(n_steps=4))
+
+
+def _check_hetero_3d(recs):
+    """tests/hetero_3d_1.mpirun-4.output: per-cell E modulus, 3-D hanging nodes, pressure 1e3 * time.  The reference solves with
+    GMRES to a relative tolerance (its Newton residuals stall at 1e-5 ... 1e-8), the harness exactly: line-0 residuals to
+    the printed digits, energies to 1e-4, the active sets of step 1 row by row."""
+    g = cases.golden()["hetero_3d_1.mpirun-4"]["timesteps"]
+    assert len(recs) == 2
+    for rec, gg in zip(recs, g):
+        assert rec.residual0 == pytest.approx(gg["residual0"], rel=2e-6)
+        assert rec.bulk_energy == pytest.approx(gg["bulk_energy"], rel=1e-4)
+        assert rec.crack_energy == pytest.approx(gg["crack_energy"], rel=2e-5)
+        assert rec.newton[-1].residual < 1e-6
+        assert rec.newton[-1].active_set == gg["newton"][-1]["active_set"]  # 36, 520
+    assert [r.active_set for r in recs[1].newton] == [x["active_set"] for x in g[1]["newton"]]  # 839 639 534 520 520
+
+
+def test_hetero_3d_with_oracle():
+    setup, cl, cm = NC.hetero_3d_setup()
+    _check_hetero_3d(ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout, cl, cm)).run(n_steps=2))
+
+
+@pytest.mark.gpu
+def test_hetero_3d_on_gpu_end_to_end():
+    """General family in 3-D: hanging nodes, per-cell Lame coefficients, time-dependent pressure; energies by pfm_functionals."""
+    from cracks_amd.newton import GpuAssembler
+
+    setup, cl, cm = NC.hetero_3d_setup()
+    asm = GpuAssembler(setup.mesh, setup.layout, cl, cm)
+    assert asm.ctx.kernel_path == 0
+    _check_hetero_3d(ActiveSetDriver(setup, asm).run(n_steps=2))
