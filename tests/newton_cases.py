@@ -111,3 +111,49 @@ def hetero_3d_setup():
                          timestep=0.01, max_no_timesteps=2, newton_tol=1.0e-6, max_newton_steps=20,
                          max_line_search=8, line_search_damping=0.5, pressure_of_time=lambda t: 1.0e3 * t)
     return setup, c.cell_lambda, c.cell_mu
+
+
+def threepoint_setup() -> ProblemSetup:
+    """tests/threepoint_1.prm (three point bending on the reference's unstructured gmsh mesh: MappingQ1 on general
+    quadrilaterals, stress split, point constraints of cracks.cc:2626-2676 with the inhomogeneous load u_y = -time at the top
+    centre; iterative-solver layout).  Its phase-field refinement starts when phi < 0.5 somewhere: the first steps run on the
+    280-cell mesh."""
+    c = cases.kat_threepoint()
+    mesh, lay = c.mesh, c.layout
+    x, y = mesh.coords[:, 0], mesh.coords[:, 1]
+    corners = np.nonzero((np.abs(y) < 1e-10) & ((np.abs(x + 4.0) < 1e-10) | (np.abs(x - 4.0) < 1e-10)))[0]
+    top = np.nonzero((np.abs(x) < 1e-10) & (np.abs(y - 2.0) < 1e-10))[0]
+    dd = np.nonzero(c.cu.flag.astype(bool) & ~c.ch.flag.astype(bool))[0].astype(np.int64)
+
+    def initial_bc(time):
+        vals = {int(d): 0.0 for d in dd}
+        for n in corners:
+            vals[int(lay.dof(n, 2))] = 1.0  # phase field at the supports: inhomogeneity 1.0
+        for n in top:
+            vals[int(lay.dof(n, 1))] = -1.0 * time  # cracks.cc:2668-2669
+        return vals
+
+    sol0 = lay.pack(np.zeros((mesh.n_nodes, 2)), np.ones(mesh.n_nodes))
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd, initial_bc=initial_bc, solution0=sol0,
+                        E_modulus=1.0e3, timestep=5.0e-3, max_no_timesteps=8, newton_tol=1.0e-6, max_newton_steps=30,
+                        max_line_search=10, line_search_damping=0.6)
+
+
+def miehe_tension_setup() -> ProblemSetup:
+    """tests/miehe_tension_adaptive_1.prm (tension test, iterative-solver layout, no stress split; its phase-field refinement
+    starts when phi < 0.5 somewhere: the first time steps run on the 256-cell slit mesh)."""
+    c = cases.kat_miehe_tension()
+    mesh, lay = c.mesh, c.layout
+    top = mesh.boundary_nodes[3]
+    dd = M.boundary_dofs(mesh, lay, [(2, [1]), (3, [0, 1])])  # cracks.cc:2584-2599
+
+    def initial_bc(time):
+        vals = {int(d): 0.0 for d in dd}
+        for n in top:  # BoundaryTensionTest, cracks.cc:776-798
+            vals[int(lay.dof(n, 1))] = 1.0 * time
+        return vals
+
+    sol0 = lay.pack(np.zeros((mesh.n_nodes, 2)), np.ones(mesh.n_nodes))
+    return ProblemSetup(mesh=mesh, layout=lay, params=c.params, dirichlet_dofs=dd, initial_bc=initial_bc, solution0=sol0,
+                        E_modulus=1.0, timestep=2.5e-4, max_no_timesteps=32, newton_tol=1.0e-6, max_newton_steps=50,
+                        max_line_search=10, line_search_damping=0.6)

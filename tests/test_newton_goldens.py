@@ -179,3 +179,63 @@ def test_hetero_3d_on_gpu_end_to_end():
     asm = GpuAssembler(setup.mesh, setup.layout, cl, cm)
     assert asm.ctx.kernel_path == 0
     _check_hetero_3d(ActiveSetDriver(setup, asm).run(n_steps=2))
+
+
+def _check_threepoint(recs):
+    """tests/threepoint_1.mpirun=2.output, first three time steps: line-0 residuals to the printed digits; energies and the
+    Newton table of steps 0 and 1 (step 1 row by row: 317 119 76 47 40 40).  From step 2 on the active sets of the reference
+    and of any other correct implementation part ways by round-off (one dof), and the energies follow at 1e-5 ... 1e-4."""
+    g = cases.golden()["threepoint_1.mpirun=2"]["timesteps"]
+    assert len(recs) == 3
+    for rec, gg in zip(recs, g):
+        assert rec.residual0 == pytest.approx(gg["residual0"], rel=2e-6)
+        assert rec.newton[-1].residual < 1e-6
+    for rec, gg in zip(recs[:2], g):
+        assert rec.bulk_energy == pytest.approx(gg["bulk_energy"], rel=5e-6)
+        assert rec.crack_energy == pytest.approx(gg["crack_energy"], rel=5e-6)
+        assert rec.newton[-1].active_set == gg["newton"][-1]["active_set"]
+    assert [r.active_set for r in recs[1].newton] == [x["active_set"] for x in g[1]["newton"]]
+    assert recs[2].bulk_energy == pytest.approx(g[2]["bulk_energy"], rel=1e-4)
+    assert recs[2].crack_energy == pytest.approx(g[2]["crack_energy"], rel=1e-3)
+
+
+def test_threepoint_first_steps_with_oracle():
+    setup = NC.threepoint_setup()
+    _check_threepoint(ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout)).run(n_steps=3))
+
+
+@pytest.mark.gpu
+def test_threepoint_first_steps_on_gpu():
+    """General family on general quadrilaterals (MappingQ1 per q-point) with the stress split, inhomogeneous point load."""
+    from cracks_amd.newton import GpuAssembler
+
+    setup = NC.threepoint_setup()
+    _check_threepoint(ActiveSetDriver(setup, GpuAssembler(setup.mesh, setup.layout)).run(n_steps=3))
+
+
+def _check_miehe_tension(recs):
+    """tests/miehe_tension_adaptive_1.output, the time steps before its first refinement: line-0 residual, energies, the
+    number of Newton rows (4) and the empty converged active set of every step."""
+    g = cases.golden()["miehe_tension_adaptive_1"]["timesteps"]
+    assert len(recs) == 4
+    for rec, gg in zip(recs, g):
+        assert gg["cells"] == 256
+        assert rec.residual0 == pytest.approx(gg["residual0"], rel=2e-6)
+        assert rec.bulk_energy == pytest.approx(gg["bulk_energy"], rel=5e-6)
+        assert rec.crack_energy == pytest.approx(gg["crack_energy"], rel=5e-6)
+        assert len(rec.newton) == len(gg["newton"]) and rec.newton[-1].residual < 1e-6
+        assert rec.newton[-1].active_set == gg["newton"][-1]["active_set"] == 0
+        assert rec.newton[0].residual == pytest.approx(gg["newton"][0]["residual"], rel=2e-2)
+
+
+def test_miehe_tension_first_steps_with_oracle():
+    setup = NC.miehe_tension_setup()
+    _check_miehe_tension(ActiveSetDriver(setup, NC.OracleAssembler(setup.mesh, setup.layout)).run(n_steps=4))
+
+
+@pytest.mark.gpu
+def test_miehe_tension_first_steps_on_gpu():
+    from cracks_amd.newton import GpuAssembler
+
+    setup = NC.miehe_tension_setup()
+    _check_miehe_tension(ActiveSetDriver(setup, GpuAssembler(setup.mesh, setup.layout)).run(n_steps=4))
