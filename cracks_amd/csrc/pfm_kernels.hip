@@ -193,34 +193,40 @@ namespace pfm
     }
 
     // ------------------------------------------------------------ the cell kernel
-    // BH: the trial vertices b this launch integrates: -1 all of them; 0 / 1 the lower / upper half (3-D Jacobian: the 108
-    // row accumulators of a hex vertex need 374 registers -- one wave per SIMD plus accumulation-register moves; two
-    // launches with 54 accumulators each run at two waves per SIMD).  The residual and the constrained diagonals are
-    // written by the launch with BH < 0 or BH == 1 (the upper half has the registers to spare).
+    // Thread <-> (cell, test vertex a): the rows of vertex a against all trial vertices of the cell.  3-D Jacobian: the 108
+    // row accumulators of a hex vertex need 374 registers, so a hex has 32 lanes there, (a, part): part = 0..3 integrates
+    // the trial vertices 2 part, 2 part + 1 (27 accumulators).  Rounds 1-3 split the trial vertices over two LAUNCHES
+    // instead; every launch re-read the 128-byte lines of the rows for its 24-byte pieces (44 GB of fetches for 10^6
+    // cells, profiles/r04) and re-evaluated the q-point states.  Residual rows: the lanes of the last part.
     // PATCH (2-D, round 4): the workgroup is an 8 x 8 block of one refinement level's lattice (DevView::patch_cells); the
     // rows of the block's regular nodes are completed in LDS -- the four vertex lanes of the cells push in four barrier-
     // separated phases (phase = vertex index: a node receives exactly one cell per phase, the order of the adds is fixed) --
     // masked and written ONCE: no colour classes, no read-modify-write of global memory, no atomics.  Same q-loop, same
     // formulas as every other instantiation.
-    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, int BH = -1, bool RING = false /* DevView::cell_ring is set */, bool PATCH = false>
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, bool RING = false /* DevView::cell_ring is set */, bool PATCH = false>
     __global__ __launch_bounds__(256, (dim == 3 && FULL) ? 2 : 1) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
                                                               double *res_pde, double *res_tot,
                                                               int residual_only, long long class_begin, long long class_size)
     {
-      static_assert(!PATCH || (dim == 2 && !ATOMIC && BH < 0 && !RING), "the patch form exists in 2-D");
+      static_assert(!PATCH || (dim == 2 && !ATOMIC && !RING), "the patch form exists in 2-D");
       constexpr int PRW = 81 + 3 + 3; // staged row of a node: 3 row components x 9 offsets x 3 column components, residual, placeholders
       __shared__ double s_row[PATCH ? 49 * PRW : 1];
       constexpr int nv = 1 << dim, nc = dim + 1, nq = (dim == 2 ? 9 : 27), dpc = nv * nc;
-      constexpr int B0 = BH < 0 ? 0 : BH * (nv / 2), NBL = BH < 0 ? nv : nv / 2; // trial vertices [B0, B0 + NBL)
-      static_assert(BH < 0 || (FULL && !SPLIT), "the split of the trial vertices exists for the unsplit Jacobian only");
-      constexpr bool RESID = BH != 0; // this launch also integrates the residual and the own diagonal
-      constexpr int CPB = 256 / nv; // cells per workgroup
+      constexpr bool Q3 = dim == 3 && FULL && !SPLIT; // the trial vertices of a hex shared out among four lanes per test vertex
+      constexpr int NPART = Q3 ? 4 : 1, LPC = nv * NPART /* lanes per cell */, NBL = nv / NPART; // trial vertices [B0, B0 + NBL)
+      constexpr int CPB = 256 / LPC; // cells per workgroup
+      constexpr int NSLOT = Q3 ? 8 : 4; // q-points per round of the 3-D exchange buffer
       __shared__ double s_x[dim][nv][CPB];
       __shared__ double s_u[dim][nv][CPB];
       __shared__ double s_p[3][nv][CPB]; // phi, phi_old, phi_oldold
+      constexpr int QST = 50; // doubles per (q-point slot, cell) of the 3-D exchange buffer: 49 used, stride free of bank conflicts for 16-byte reads
+      __shared__ __attribute__((aligned(16))) double s_q[(dim == 3 && !SPLIT) ? NSLOT * CPB * QST : 2];
 
       const int tid = threadIdx.x;
-      const int a = tid % nv, cl0 = tid / nv;
+      const int a = tid % nv, part = Q3 ? (tid / nv) % NPART : 0, cl0 = tid / LPC;
+      const int B0 = part * NBL;
+      const bool resid_lane = part == NPART - 1;           // scatters the residual rows of vertex a
+      const bool diag_lane = (a / NBL) == part;            // holds the diagonal block K[(a,.),(a,.)]
       const int cl = cl0;
       const long long at = (long long)blockIdx.x * CPB + cl;
       bool active = at < class_size;
@@ -262,15 +268,18 @@ namespace pfm
       if (active)
         {
           A = v.conn[(long long)a * v.n_cells + cell];
-#pragma unroll
-          for (int d = 0; d < dim; ++d)
+          if (part == 0)
             {
-              s_x[d][a][cl] = v.coords[(long long)d * v.n_nodes + A];
-              s_u[d][a][cl] = v.u[d][A];
+#pragma unroll
+              for (int d = 0; d < dim; ++d)
+                {
+                  s_x[d][a][cl] = v.coords[(long long)d * v.n_nodes + A];
+                  s_u[d][a][cl] = v.u[d][A];
+                }
+              s_p[0][a][cl] = v.phi[A];
+              s_p[1][a][cl] = v.phi_old[A];
+              s_p[2][a][cl] = v.phi_oldold[A];
             }
-          s_p[0][a][cl] = v.phi[A];
-          s_p[1][a][cl] = v.phi_old[A];
-          s_p[2][a][cl] = v.phi_oldold[A];
         }
       __syncthreads();
       if (!PATCH && !active)
@@ -314,10 +323,6 @@ namespace pfm
       double Kuu[FULL ? NBL : 1][dim][dim]; // [b - B0][c][d]   trial (b,d) -> row (a,c)
       double Kpu[FULL ? NBL : 1][dim];      // [b - B0][d]      trial (b,d) -> row (a,phi)
       double Kpp[FULL ? NBL : 1];           // [b - B0]         trial (b,phi) -> row (a,phi)
-      double Kd[nc];                        // own diagonal K[(a,c),(a,c)] (needed by every launch for the mean |diagonal|)
-#pragma unroll
-      for (int c = 0; c < nc; ++c)
-        Kd[c] = 0.0;
 #pragma unroll
       for (int c = 0; c < nc; ++c)
         R[c] = 0.0;
@@ -581,6 +586,238 @@ namespace pfm
                 }
             }
         }
+      else if constexpr (dim == 3 && !SPLIT)
+        {
+          // ======================= 3-D: the q-point states are shared out among the lanes of the cell (as in the 2-D split
+          // form above, through LDS instead of DPP: a hex has 8 lanes, 49 numbers per q-point).  MappingQ1, the shape
+          // gradients and the Newton state at a q-point are the same for the eight lanes of a cell and are 60 % of the
+          // instructions of the plain loop.  A round is NSLOT q-points: lane (a, part) evaluates q-point NSLOT r + slot
+          // (phase A; Jacobian: slot = a, the four parts repeat each other; residual-only: slot = a & 3, lanes 4..7 repeat
+          // lanes 0..3 -- eight slots for 32 cells would need 100 KB of LDS) and one lane per slot leaves in s_q what the
+          // rows need of it; then the cell's lanes go through the round's q-points together (phase B), each adding to the
+          // rows of its own vertex (and, Jacobian, its own two trial vertices).  A cell's lanes sit in one wave and the LDS
+          // executes a wave's instructions in order: no barrier between the phases.
+          constexpr double GX0 = 0.5 - 0.5 * 0.7745966692414834, GX2 = 0.5 + 0.5 * 0.7745966692414834; // make_ref_tables
+          constexpr double GW0 = 5.0 / 18.0, GW1 = 8.0 / 18.0;
+          // slot layout (doubles): vertex v at 4 v: grad N_v (3), N_v;  32..: the scalars below;  stride QST
+          constexpr int O_GW = 32 /* g JxW, c_pu */, O_CDIV = 34 /* c_div, c_pp */, O_CGG = 36 /* c_gg, c_pen */, O_SP = 38 /* sigma+ (6) */, O_RP = 44 /* r_p, r_phi */, O_GPF = 46 /* grad phi (3) */;
+#pragma unroll 1
+          for (int q = 0; q < nq_run; ++q)
+            {
+              int cl = cl0;
+              asm volatile("" : "+v"(cl)); // the cell's nodal data are re-read from LDS per round, not pinned in registers
+              if ((q & (NSLOT - 1)) == 0)
+                {
+                  // ---------------- phase A: q-point qa of this lane (the idle slots of the last round repeat q-point 26)
+                  const int slot = Q3 ? a : (a & 3);
+                  const int qa = min(q + slot, nq - 1);
+                  const int qz = (qa * 57) >> 9, qr = qa - 9 * qz, qy = (qr * 11) >> 5, qx = qr - 3 * qy;
+                  const double x1 = qx == 0 ? GX0 : (qx == 1 ? 0.5 : GX2), y1 = qy == 0 ? GX0 : (qy == 1 ? 0.5 : GX2),
+                               z1 = qz == 0 ? GX0 : (qz == 1 ? 0.5 : GX2);
+                  const double wq = (qx == 1 ? GW1 : GW0) * (qy == 1 ? GW1 : GW0) * (qz == 1 ? GW1 : GW0);
+                  const double X[2] = {1.0 - x1, x1}, Y[2] = {1.0 - y1, y1}, Z[2] = {1.0 - z1, z1};
+                  double yz[2][2], xz[2][2], xy[2][2];
+#pragma unroll
+                  for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                      {
+                        yz[i][k] = Y[i] * Z[k];
+                        xz[i][k] = X[i] * Z[k];
+                        xy[i][k] = X[i] * Y[k];
+                      }
+                  auto dNl = [&](int vv, int e) __attribute__((always_inline)) {
+                    const int vx = vv & 1, vy = (vv >> 1) & 1, vz = vv >> 2;
+                    const double m = e == 0 ? yz[vy][vz] : (e == 1 ? xz[vx][vz] : xy[vx][vy]);
+                    return ((vv >> e) & 1) ? m : -m;
+                  };
+                  double J[3][3];
+#pragma unroll
+                  for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                      J[i][k] = 0.0;
+#pragma unroll
+                  for (int vv = 0; vv < 8; ++vv)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                      {
+                        const double xi = s_x[i][vv][cl];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                          J[i][k] += xi * dNl(vv, k);
+                      }
+                  double inv[3][3];
+                  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+                  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+                  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+                  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+                  const double id = 1.0 / det;
+                  inv[0][0] = c00 * id;
+                  inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id;
+                  inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+                  inv[1][0] = c01 * id;
+                  inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id;
+                  inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+                  inv[2][0] = c02 * id;
+                  inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
+                  inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+                  const double JxW = det * wq;
+                  double *const o = s_q + (slot * CPB + cl) * QST;
+                  const bool writer = Q3 ? part == 0 : a < 4;
+                  double gu[3][3], gpf[3] = {0.0, 0.0, 0.0}, pf = 0.0, pfo = 0.0, pfoo = 0.0;
+#pragma unroll
+                  for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                      gu[i][k] = 0.0;
+#pragma unroll
+                  for (int vv = 0; vv < 8; ++vv)
+                    {
+                      double gv[3];
+#pragma unroll
+                      for (int d = 0; d < 3; ++d)
+                        gv[d] = inv[0][d] * dNl(vv, 0) + inv[1][d] * dNl(vv, 1) + inv[2][d] * dNl(vv, 2);
+                      const double Nv = X[vv & 1] * yz[(vv >> 1) & 1][vv >> 2];
+                      if (writer)
+                        {
+                          *reinterpret_cast<double2 *>(o + 4 * vv) = make_double2(gv[0], gv[1]);
+                          *reinterpret_cast<double2 *>(o + 4 * vv + 2) = make_double2(gv[2], Nv);
+                        }
+                      const double ph = s_p[0][vv][cl];
+                      pf += ph * Nv;
+                      pfo += s_p[1][vv][cl] * Nv;
+                      pfoo += s_p[2][vv][cl] * Nv;
+#pragma unroll
+                      for (int d = 0; d < 3; ++d)
+                        {
+                          gpf[d] += ph * gv[d];
+#pragma unroll
+                          for (int c = 0; c < 3; ++c)
+                            gu[c][d] += s_u[c][vv][cl] * gv[d];
+                        }
+                    }
+                  // q-point state, cracks.cc:2248-2306
+                  if (monolithic)
+                    {
+                      pf = fmax(0.0, pf);
+                      pfo = fmax(0.0, pfo);
+                      pfoo = fmax(0.0, pfoo);
+                    }
+                  const double pf_minus_old_plus = fmax(0.0, pf - pfo);
+                  double pfx = pfoo + tfac * (pfo - pfoo);
+                  if (pfx <= 0.0)
+                    pfx = 0.0;
+                  if (pfx >= 1.0)
+                    pfx = 1.0;
+                  if (prm.use_old_timestep_pf)
+                    pfx = pfo;
+                  const double g = (1 - kappa) * pfx * pfx + kappa;
+                  double E[3][3], trE = 0.0, divu = 0.0;
+#pragma unroll
+                  for (int i = 0; i < 3; ++i)
+                    {
+                      divu += gu[i][i];
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        E[i][k] = 0.5 * (gu[i][k] + gu[k][i]);
+                      trE += E[i][i];
+                    }
+                  double sp[3][3], spE = 0.0; // sigma+ = lambda tr(E) I + 2 mu E, sigma- = 0 (cracks.cc:2284-2292)
+#pragma unroll
+                  for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                      {
+                        sp[i][k] = lam * trE * (i == k ? 1.0 : 0.0) + 2 * mu * E[i][k];
+                        spE += sp[i][k] * E[i][k];
+                      }
+                  if (writer)
+                    {
+                      const bool pen_on = !((pf - pfo) < 0.0); // shadowed variable, cracks.cc:2311-2315
+                      *reinterpret_cast<double2 *>(o + O_GW) = make_double2(g * JxW, 2.0 * (1 - kappa) * pf * JxW);
+                      *reinterpret_cast<double2 *>(o + O_CDIV) =
+                        make_double2(2.0 * aB1 * p * pf * JxW, (((1 - kappa) * spE + Gc / eps) - 2.0 * aB1 * p * divu) * JxW);
+                      *reinterpret_cast<double2 *>(o + O_CGG) = make_double2(Gc * eps * JxW, pen_on ? penal_fac * JxW : 0.0);
+                      *reinterpret_cast<double2 *>(o + O_SP) = make_double2(sp[0][0], sp[0][1]);
+                      *reinterpret_cast<double2 *>(o + O_SP + 2) = make_double2(sp[0][2], sp[1][1]);
+                      *reinterpret_cast<double2 *>(o + O_SP + 4) = make_double2(sp[1][2], sp[2][2]);
+                      *reinterpret_cast<double2 *>(o + O_RP) =
+                        make_double2(aB1 * p * pfx * pfx * JxW, (penal_fac * pf_minus_old_plus + (1.0 - kappa) * spE * pf - Gc / eps * (1.0 - pf) -
+                                                                 2.0 * aB1 * p * pf * divu) *
+                                                                  JxW);
+                      *reinterpret_cast<double2 *>(o + O_GPF) = make_double2(gpf[0], gpf[1]);
+                      o[O_GPF + 2] = gpf[2];
+                    }
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+              // ---------------- phase B: q-point q, rows of this lane's vertex (cracks.cc:2308-2432)
+              const double *const i = s_q + ((q & (NSLOT - 1)) * CPB + cl) * QST;
+              const double2 ga01 = *reinterpret_cast<const double2 *>(i + 4 * a), ga2n = *reinterpret_cast<const double2 *>(i + 4 * a + 2);
+              const double gNa[3] = {ga01.x, ga01.y, ga2n.x}, Na = ga2n.y;
+              const double2 s01 = *reinterpret_cast<const double2 *>(i + O_SP), s23 = *reinterpret_cast<const double2 *>(i + O_SP + 2),
+                            s45 = *reinterpret_cast<const double2 *>(i + O_SP + 4);
+              const double sp[3][3] = {{s01.x, s01.y, s23.x}, {s01.y, s23.y, s45.x}, {s23.x, s45.x, s45.y}};
+              const double2 q01 = *reinterpret_cast<const double2 *>(i + O_GW);
+              const double gw = q01.x;
+              if constexpr (FULL)
+                {
+                  const double2 q23 = *reinterpret_cast<const double2 *>(i + O_CDIV), q45 = *reinterpret_cast<const double2 *>(i + O_CGG);
+                  double LA[3], MA[3];
+#pragma unroll
+                  for (int c = 0; c < 3; ++c)
+                    {
+                      LA[c] = lam * gw * gNa[c];
+                      MA[c] = mu * gw * gNa[c];
+                    }
+                  const double mgw = mu * gw;
+                  const double cpu = q01.y * Na, cdiv = q23.x * Na, cpp = q23.y * Na, cgg = q45.x, cpen = q45.y * Na;
+#pragma unroll
+                  for (int bb = 0; bb < NBL; ++bb)
+                    {
+                      const int b = B0 + bb;
+                      const double2 gb01 = *reinterpret_cast<const double2 *>(i + 4 * b), gb2n = *reinterpret_cast<const double2 *>(i + 4 * b + 2);
+                      const double gNb[3] = {gb01.x, gb01.y, gb2n.x}, Nb = gb2n.y;
+                      double t = 0.0;
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        t += gNb[k] * gNa[k];
+#pragma unroll
+                      for (int d = 0; d < 3; ++d)
+                        {
+                          double sv = 0.0;
+#pragma unroll
+                          for (int k = 0; k < 3; ++k)
+                            sv += sp[d][k] * gNb[k];
+                          Kpu[bb][d] += cpu * sv - cdiv * gNb[d];
+#pragma unroll
+                          for (int c = 0; c < 3; ++c)
+                            Kuu[bb][c][d] += LA[c] * gNb[d] + MA[d] * gNb[c] + (c == d ? mgw * t : 0.0);
+                        }
+                      Kpp[bb] += cpen * Nb;
+                      Kpp[bb] += cpp * Nb + cgg * t;
+                    }
+                }
+              {
+                  const double2 r01 = *reinterpret_cast<const double2 *>(i + O_RP), g01 = *reinterpret_cast<const double2 *>(i + O_GPF);
+                  const double g2 = i[O_GPF + 2];
+                  const double cgg_r = i[O_CGG];
+#pragma unroll
+                  for (int c = 0; c < 3; ++c)
+                    {
+                      double t = 0.0;
+#pragma unroll
+                      for (int k = 0; k < 3; ++k)
+                        t += sp[c][k] * gNa[k];
+                      R[c] -= gw * t - r01.x * gNa[c];
+                    }
+                  const double gg = g01.x * gNa[0] + g01.y * gNa[1] + g2 * gNa[2];
+                  R[3] -= r01.y * Na + cgg_r * gg;
+                }
+            }
+        }
       else
         {
 #pragma unroll 1
@@ -829,19 +1066,6 @@ namespace pfm
                   Kpp[bb] += cpen * (pen_on ? Nb : 0.0);
                   Kpp[bb] += (cpp - cdu) * Nb + cgg * t;
                 }
-              if constexpr (BH == 1)
-                {
-                  // the lane's own diagonal entries (trial vertex a, which half of the launches does not integrate)
-                  double taa = 0.0;
-#pragma unroll
-                  for (int k = 0; k < dim; ++k)
-                    taa += gNa[k] * gNa[k];
-#pragma unroll
-                  for (int c = 0; c < dim; ++c)
-                    Kd[c] += LA[c] * gNa[c] + MA[c] * gNa[c] + mgw * taa;
-                  Kd[dim] += cpen * (pen_on ? Na : 0.0);
-                  Kd[dim] += (cpp - cdu) * Na + cgg * taa;
-                }
             }
           if constexpr (FULL && SPLIT)
             {
@@ -887,7 +1111,6 @@ namespace pfm
                 }
             }
 
-          if constexpr (RESID)
             {
           // ---- residual rows of vertex a, cracks.cc:2393-2432
 #pragma unroll
@@ -1073,7 +1296,7 @@ namespace pfm
           const unsigned fA = v.node_flags[A];
           // a cell next to the atomic class (which may be running on another stream): atomic adds, see DevView::cell_ring
           const bool ring = RING && v.cell_ring[cell] != 0;
-          if (owned && RESID)
+          if (owned && resid_lane)
             {
             double *pr[nc], *pt[nc], o_r[nc], o_t[nc];
 #pragma unroll
@@ -1120,13 +1343,10 @@ namespace pfm
                                  : vals.b[1] + (dim * off + (long long)c * deg + s_);
                 return d < dim ? vals.b[2] + (dim * off + (long long)s_ * dim + d) : vals.b[3] + (off + s_);
               };
-              double diag[nc];
-              if constexpr (BH >= 0)
-                {
+              double diag[nc]; // |diagonal| of this lane's vertex (zero in the lanes whose trial vertices do not include a)
 #pragma unroll
-                  for (int c = 0; c < nc; ++c)
-                    diag[c] = fabs(Kd[c]); // BH == 0: zero, unused
-                }
+              for (int c = 0; c < nc; ++c)
+                diag[c] = 0.0;
 #pragma unroll
               for (int bb = 0; bb < NBL; ++bb)
                 {
@@ -1134,7 +1354,7 @@ namespace pfm
                   const int B = v.conn[(long long)b * v.n_cells + cell];
                   const unsigned fQ = v.node_flags[B];
                   const int slot = (int)cs[a * nv + b];
-                  if (BH < 0 && b == a)
+                  if (b == a)
                     {
 #pragma unroll
                       for (int c = 0; c < dim; ++c)
@@ -1185,10 +1405,10 @@ namespace pfm
               for (int c = 0; c < nc; ++c)
                 dsum += diag[c];
 #pragma unroll
-              for (int m = 1; m < nv; m <<= 1)
-                dsum += __shfl_xor(dsum, m, nv);
+              for (int m = 1; m < LPC; m <<= 1)
+                dsum += __shfl_xor(dsum, m, LPC);
               const double avg = dsum / (double)dpc;
-              if (fA && owned && RESID)
+              if (fA && owned && diag_lane)
                 {
                   const int slot = (int)cs[a * nv + a];
 #pragma unroll
@@ -1212,7 +1432,7 @@ namespace pfm
 
       // residual
       const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
-      for (long long r = rb; r < (RESID ? re : rb); ++r)
+      for (long long r = rb; r < (resid_lane ? re : rb); ++r)
         {
           const int P = kA < 0 ? A : v.hn_parents[r];
           const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
@@ -1235,19 +1455,16 @@ namespace pfm
         {
           const unsigned fA = v.node_flags[A];
           double diag[nc];
-          if constexpr (BH >= 0)
-            {
 #pragma unroll
-              for (int c = 0; c < nc; ++c)
-                diag[c] = fabs(Kd[c]);
-            }
+          for (int c = 0; c < nc; ++c)
+            diag[c] = 0.0;
           // matrix rows of vertex a
 #pragma unroll
           for (int bb = 0; bb < NBL; ++bb)
             {
               const int b = B0 + bb;
               const int B = v.conn[(long long)b * v.n_cells + cell];
-              if (BH < 0 && b == a)
+              if (b == a)
                 {
 #pragma unroll
                   for (int c = 0; c < dim; ++c)
@@ -1299,10 +1516,10 @@ namespace pfm
           for (int c = 0; c < nc; ++c)
             dsum += diag[c];
 #pragma unroll
-          for (int m = 1; m < nv; m <<= 1)
-            dsum += __shfl_xor(dsum, m, nv);
+          for (int m = 1; m < LPC; m <<= 1)
+            dsum += __shfl_xor(dsum, m, LPC);
           const double avg = dsum / (double)dpc;
-          if (RESID && A < v.n_owned && !(v.row_patch && v.row_patch[A]) && (kA >= 0 || fA))
+          if (diag_lane && A < v.n_owned && !(v.row_patch && v.row_patch[A]) && (kA >= 0 || fA))
             {
               const int slot = (int)cs[a * nv + a];
 #pragma unroll
@@ -1710,7 +1927,7 @@ namespace pfm
     const bool split = (p.decompose_stress_matrix > 0 && p.timestep_number > 0);
     const dim3 grid((unsigned)n_blocks), block(256);
 #define PFM_PATCH(FULLV, SPLITV)                                                                                              \
-  hipLaunchKernelGGL((k_assemble_general<2, FULLV, SPLITV, false, -1, false, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
+  hipLaunchKernelGGL((k_assemble_general<2, FULLV, SPLITV, false, false, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
                      residual_only, 0LL, 0LL)
     if (residual_only)
       {
@@ -1748,7 +1965,8 @@ namespace pfm
     // non-zero decompose_stress_rhs without it multiplies a zero stress_term_minus.
     if (v.dim == 3 && split)
       return PFM_ERR_UNSUPPORTED;
-    const int nv = 1 << v.dim, cpb = 256 / nv;
+    // cells per workgroup: 32 lanes per hex for the 3-D Jacobian (k_assemble_general: Q3), one lane per vertex otherwise
+    const int nv = 1 << v.dim, cpb = (v.dim == 3 && !residual_only) ? 8 : 256 / nv;
     const int n_classes = (int)color_ptr.size() - 1;
     // one launch per colour class, in class order (stream order = the summation order of a row: reproducible);
     // the last class (cells with hanging vertices) adds atomically
@@ -1771,7 +1989,7 @@ namespace pfm
         hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,  \
                            residual_only, c0, cn);                                                                           \
       else if (v.cell_ring)                                                                                                  \
-        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false, -1, true>), grid, block, 0, s, v, p, vals, res_pde, \
+        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false, true>), grid, block, 0, s, v, p, vals, res_pde, \
                            res_tot, residual_only, c0, cn);                                                                  \
       else                                                                                                                   \
         hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, false>), grid, block, 0, s, v, p, vals, res_pde, res_tot, \
@@ -1801,28 +2019,7 @@ namespace pfm
               PFM_LAUNCH(3, false, false);
             else
               {
-                // two launches per class, each with half of the trial vertices (see the kernel's BH parameter)
-                if (atomic)
-                  {
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 0>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, true, 1>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                  }
-                else if (v.cell_ring)
-                  {
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 0, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 1, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                  }
-                else
-                  {
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 0>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                    hipLaunchKernelGGL((k_assemble_general<3, true, false, false, 1>), grid, block, 0, s, v, p, vals, res_pde, res_tot,
-                                       residual_only, c0, cn);
-                  }
+                PFM_LAUNCH(3, true, false);
               }
           }
 #undef PFM_LAUNCH
