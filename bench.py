@@ -323,10 +323,47 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
     record("jacobian_2d", 2, n2, False, wall, k_ms, n2 * n2, 3 * (n2 + 1) ** 2)
     a2.ctx.close()
     try:
+        out["general_family_3d"] = general_family_3d(dev, local_rank, steps)
+    except Exception as e:
+        out["general_family_3d"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
         out["config5_standin"] = config5_standin(dev, local_rank, steps)
     except Exception as e:  # a missing mesh helper must not take the other lines away
         out["config5_standin"] = {"error": f"{type(e).__name__}: {e}"}
     return out
+
+
+def general_family_3d(dev, local_rank, steps: int, n: int = 100):
+    """What a 3-D mesh with hanging nodes or general hexes costs (cracks.cc:2200-2203 with MappingQ1 at every q-point,
+    scatter through colour classes): the Sneddon box of `n`^3 hexes FORCED onto the general family
+    (`pfm_ctx_force_path(0)`; the same line as `python bench.py --n 100 --path general`)."""
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler
+
+    lp = P.build_local_problem(3, (n, n, n), P.factor_ranks(1, 3), 0)
+    h = (20.0 / n) * np.sqrt(3)
+    u, phi, po, poo, flags = synthetic_state(lp.mesh, lp.global_ids, h, 3)
+    a = Assembler(lp.mesh, blocked=True, device=local_rank, n_owned_nodes=lp.n_owned)
+    a.ctx.force_path(0)
+    a.set_params(sneddon_params(h, 3))
+    a.set_constraints(flags)
+    no = lp.n_owned
+
+    def pack(uu, pp):
+        v = np.empty(no * 4)
+        v[:no * 3] = uu[:no].reshape(-1)
+        v[no * 3:] = pp[:no]
+        return v
+
+    a.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
+    n_cells, n_dofs = n ** 3, 4 * (n + 1) ** 3
+    rec = {"workload": f"Sneddon 3D, {n}^3 hexes forced onto the general family (kernel path {a.ctx.kernel_path()})", "cells": n_cells}
+    for key, ro in (("jacobian", False), ("residual_only", True)):
+        wall, k_ms = time_mode(a, dev, ro, max(3, steps // 2), 2)
+        rec[key] = {"ms_per_call": wall, "kernel_ms": k_ms, "DoFs_per_s": n_dofs / (wall * 1e-3),
+                    "hbm_frac": algorithmic_bytes_per_cell(3, ro) * n_cells / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
+    a.ctx.close()
+    return rec
 
 
 def config5_problem(levels: int, step: int):

@@ -496,6 +496,17 @@ def test_bench_reports_the_config5_standin():
     assert rec["hanging_nodes"] > 0
 
 
+def test_bench_reports_the_general_family_3d():
+    """bench.py's `extra.general_family_3d`: a hex box forced onto the general family (what a 3-D mesh with hanging nodes
+    costs) stays on kernel path 0 and reports both assembly modes."""
+    import bench
+
+    rec = bench.general_family_3d("cuda:0", 0, steps=4, n=24)
+    assert "kernel path 0" in rec["workload"] and rec["cells"] == 24 ** 3
+    for key in ("jacobian", "residual_only"):
+        assert rec[key]["ms_per_call"] > 0.0 and rec[key]["kernel_ms"] > 0.0 and rec[key]["hbm_frac"] > 0.0
+
+
 def test_general_family_launch_modes_agree(tmp_path):
     """The same 2-D assembly of a mesh with hanging nodes and the stress split in its launch modes: default (cartesian
     overlay: patch kernel on the stream, the rest of the general family next to it), PFM_NO_PATCH=1 (general family alone, the
