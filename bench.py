@@ -357,7 +357,7 @@ def general_family_3d(dev, local_rank, steps: int, n: int = 100):
 
     a.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
     n_cells, n_dofs = n ** 3, 4 * (n + 1) ** 3
-    rec = {"workload": f"Sneddon 3D, {n}^3 hexes forced onto the general family (kernel path {a.ctx.kernel_path()})", "cells": n_cells}
+    rec = {"workload": f"Sneddon 3D, {n}^3 hexes forced onto the general family (kernel path {a.ctx.kernel_path})", "cells": n_cells}
     for key, ro in (("jacobian", False), ("residual_only", True)):
         wall, k_ms = time_mode(a, dev, ro, max(3, steps // 2), 2)
         rec[key] = {"ms_per_call": wall, "kernel_ms": k_ms, "DoFs_per_s": n_dofs / (wall * 1e-3),

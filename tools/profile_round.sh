@@ -54,6 +54,12 @@ cp $O/pmc_mix_c5/p_counter_collection.csv $O/rocprofv3_pmc_MIX_config5.csv 2>/de
 run_prof pmc_sq_c5 --pmc $SQ --output-format csv -d $O/pmc_sq_c5 -o p -- python $R/tools/bench_extra.py config5 --levels 8 --meshes 1 --world 1
 cp $O/pmc_sq_c5/p_counter_collection.csv $O/rocprofv3_pmc_SQ_config5.csv 2>/dev/null
 rm -rf $O/stats_c5 $O/pmc_mix_c5 $O/pmc_sq_c5
+# general family in 3-D (10^6 hexes forced onto it): time, instruction mix and line traffic per colour-class launch
+(cd $R && bash tools/pmc_any.sh $O/general_3d -- python $R/bench.py --n 100 --path general --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>&1 | cut -c1-240 | grep k_assemble_general > $O/general_3d_100cube_kernels.txt
+ bash tools/hbm_traffic.sh gpurun_out/$TAG/general_3d_100cube_traffic.json -- --n 100 --path general --no-cpu-baseline --no-extras --steps 3 --warmup 1 2>&1 | grep k_assemble_general >> $O/general_3d_100cube_kernels.txt
+ python bench.py --n 100 --path general --residual-only --no-cpu-baseline --no-extras --steps 5 > $O/bench_100cube_general_residual_only.json 2>/dev/null
+ rm -rf $O/general_3d gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_FETCH_SIZE)
+cd /tmp
 python - <<PY
 import csv, collections, json, re
 O = "$O"
