@@ -143,6 +143,26 @@ def test_cart_full_vanishing_degradation_uses_mean_diagonal():
     _full(c, path=1)
 
 
+@pytest.mark.parametrize("blocked", [True, False])
+def test_general_family_3d_mean_diagonal_monolithic_and_active_set(blocked):
+    """The hex kernel of the general family (32 lanes per hex, the q-point states shared out through LDS): the element's mean
+    |diagonal| for constrained rows is a sum over the lanes that hold the diagonal blocks; active-set lines, the penalisation
+    of the monolithic scheme and a box that is not a cube go through the same lanes."""
+    c = box_case(3, (6, 5, 4), -10.0, 10.0, blocked)
+    c.params.constant_k = 0.0
+    node, comp = c.layout.node_comp_of_dof()
+    is_phi = comp == 3
+    dead = c.mesh.coords[node[is_phi]][:, 0] < 0.0
+    o = c.old.copy()
+    o[np.nonzero(is_phi)[0][dead]] = 0.0
+    c.old, c.oldold = o, o.copy()
+    _full(c, path=0)
+    c = box_case(3, (7, 6, 5), (-2.0, 0.0, 0.0), (2.0, 3.0, 5.0), blocked, monolithic=True)
+    node, comp = c.layout.node_comp_of_dof()
+    c.cu = M.update_constraints(c.mesh, c.layout, M.sneddon_dirichlet_dofs(c.mesh, c.layout), np.nonzero(comp == 3)[0][::5])
+    _full(c, path=0)
+
+
 def test_cart_is_the_default_full_path_for_boxes():
     c = box_case(3, (5, 5, 5), -10.0, 10.0, True)
     ctx = make_context(c)
