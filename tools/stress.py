@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off robustness run on the GPU box: (1) 200 Jacobian assemblies of the 3-D Sneddon 216^3 bench problem must
 leave bit-identical outputs and a stable amount of free device memory; (2) 60 context create/destroy cycles on a
-40^3 box must give the memory back."""
+40^3 box must give the memory back.  `python tools/stress.py 64 general`: the same box forced onto the general family."""
 import os
 import sys
 
@@ -32,6 +32,8 @@ def main():
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 216
     a = problem(n)
+    if len(sys.argv) > 2 and sys.argv[2] == "general":  # python tools/stress.py 64 general: the colour classes of the general family
+        a.ctx.force_path(0)
     a.assemble_system(False)
     a.synchronize()
     ref = [m.clone() for m in a.system_pde_matrix] + [a.system_pde_residual.clone()]
