@@ -1564,7 +1564,7 @@ namespace pfm
     cv.tile_sel = phase;
     // next to the phase-field kernel: the same LDS allocation as that kernel (64 granules of 1280 B; 79,472 B are 63), so
     // that a slot freed by either kernel takes a workgroup of either
-    int rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde, s_phi != s ? 2048 : 0);
+    int rc = launch_cart_uu3(v, cv, p, d_values[0], s, d_scal, res_pde, s_phi != s ? 64 * 1280 : 0);
     cv.tile_sel = 0;
     if (rc || phase == 1)
       return rc;

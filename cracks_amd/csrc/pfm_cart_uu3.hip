@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include <type_traits>
 
@@ -33,6 +34,12 @@ namespace pfm
   namespace
   {
     constexpr int NNUM3 = 63;
+    // Table storage: tables in groups of eight, a cell ROW of a group = 8 tables x 9 cells = 72 doubles, i.e. the
+    // four tile rows of a half-wave (row stride 72 = 8 mod 32 doubles, 8 lanes each) tile the 32 double-banks of a
+    // ds_read_b64 lane group exactly: every table read of the node phase is conflict-free (round 5; with the
+    // [table][cell] layout of rounds 1-4, row stride 9, rows 0 and 3 of the tile shared three banks)
+    constexpr int TROW3 = 72, TLAY3 = 5 * TROW3, TGRP3 = 2 * TLAY3, TABSZ3 = 8 * TGRP3; // 5760 doubles
+    __host__ __device__ constexpr int tab_off3(int t) { return (t >> 3) * TGRP3 + (t & 7) * C3X; }
 
     __host__ __device__ constexpr int idxA3(int c, int gi, int gj) { return c * 9 + gi * 3 + gj; }
     __host__ __device__ constexpr int pair3(int lo, int hi) { return lo == 0 ? (hi == 1 ? 0 : 1) : 2; }
@@ -90,19 +97,19 @@ namespace pfm
       constexpr Vis vi = visit_of(W, V);
       constexpr int a[3] = {-vi.ex, -vi.ey, 1}, b[3] = {-vi.ex + vi.ox, -vi.ey + vi.oy, 1 + vi.oz};
       constexpr int g[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
-      const double *cell = lane_base + (vi.ey * C3X + vi.ex);
+      const double *cell = lane_base + (vi.ey * TROW3 + vi.ex); // lds_read64: single ds_read_b64s, see pfm_cart_common.h
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         {
           const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-          tv[k] = cell[idxA3(k, g[i], g[j]) * CS3];
+          tv[k] = lds_read64(cell + tab_off3(idxA3(k, g[i], g[j])));
         }
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         {
           const int lo = (p == 2) ? 1 : 0, hi = (p == 0) ? 1 : 2, e = 3 - lo - hi;
-          tv[3 + 2 * p] = cell[idxT3(p, b[lo], a[hi], g[e]) * CS3];
-          tv[4 + 2 * p] = cell[idxT3(p, a[lo], b[hi], g[e]) * CS3];
+          tv[3 + 2 * p] = lds_read64(cell + tab_off3(idxT3(p, b[lo], a[hi], g[e])));
+          tv[4 + 2 * p] = lds_read64(cell + tab_off3(idxT3(p, a[lo], b[hi], g[e])));
         }
     }
 
@@ -267,7 +274,7 @@ namespace pfm
           }
       };
       stamp(-1);
-      __shared__ double s_tab[NNUM3 * CS3];  // moment tables [number][cell]; layer 1 stored z-mirrored
+      __shared__ double s_tab[TABSZ3];       // moment tables (layout: tab_off3); layer 1 stored z-mirrored
       __shared__ double s_stage[NN3 * STG];  // staged rows [node][81]; w*g(q) [27][90] during the cell phase
       __shared__ double s_po[NH3], s_poo[NH3];
       __shared__ int s_node[NH3];
@@ -446,11 +453,12 @@ namespace pfm
             {
               const int cs = l * CL3 + ln;
               const double *wq = s_stage + cs;
-              double *out = s_tab + cs;
+              const int cyl = ln / C3X;
+              double *out = s_tab + l * TLAY3 + cyl * TROW3 + (ln - cyl * C3X);
               double w27[27];
 #pragma unroll
               for (int q = 0; q < 27; ++q)
-                w27[q] = wq[q * CS3];
+                w27[q] = lds_read64(wq + q * CS3);
               __builtin_amdgcn_sched_barrier(0);
               // ---- A^c, c = f: sum over q_c, then the two moment axes (i, j) = other axes ascending
               {
@@ -480,7 +488,7 @@ namespace pfm
                       {
                         const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
                         const int gjm = (mir && zj) ? 2 - gj : gj; // layer 1 is stored z-mirrored
-                        out[(c * 9 + gi * 3 + gjm) * CS3] = val;
+                        out[tab_off3(c * 9 + gi * 3 + gjm)] = val;
                       }
                   }
               }
@@ -517,7 +525,7 @@ namespace pfm
                           {
                             const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
                             const int gm = mz ? 2 - g : g;
-                            out[(27 + p * 12 + al * 6 + bes * 3 + gm) * CS3] = mb ? -val : val;
+                            out[tab_off3(27 + p * 12 + al * 6 + bes * 3 + gm)] = mb ? -val : val;
                           }
                       }
                   }
@@ -554,9 +562,10 @@ namespace pfm
       const bool regular_tile = (NCOL == 3) && s_any[3] == 0;
       const unsigned row_flag = s_flag[hc];
       // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
-      const double *lane_base = s_tab + (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1);
+      const double *lane_base = s_tab + (upper ? TLAY3 : 0) + (tj + 1) * TROW3 + (ti + 1);
+      const int lane_cs = (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1); // the same cell in [layer][cy][cx] order (s_lam, s_mu)
       const unsigned char *flag_own = s_flag + hc, *flag_half = s_flag + hc + (upper ? H3X * H3Y : -H3X * H3Y);
-      static_assert(NN3 * STG <= NNUM3 * CS3, "second staging buffer must fit in the table storage");
+      static_assert(NN3 * STG <= TABSZ3, "second staging buffer must fit in the table storage");
       UuCoef K;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -638,13 +647,13 @@ namespace pfm
               static_for<4>([&](auto Vv) __attribute__((always_inline)) {
                 constexpr Vis vi = visit_of(0, decltype(Vv)::value);
                 constexpr int a[3] = {-vi.ex, -vi.ey, 1};
-                const double *cell = lane_base + (vi.ey * C3X + vi.ex);
+                const double *cell = lane_base + (vi.ey * TROW3 + vi.ex);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                   {
                     const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-                    const double s4 = (cell[idxA3(k, a[i], a[j]) * CS3] + cell[idxA3(k, a[i] + 1, a[j]) * CS3]) +
-                                      (cell[idxA3(k, a[i], a[j] + 1) * CS3] + cell[idxA3(k, a[i] + 1, a[j] + 1) * CS3]);
+                    const double s4 = (lds_read64(cell + tab_off3(idxA3(k, a[i], a[j]))) + lds_read64(cell + tab_off3(idxA3(k, a[i] + 1, a[j])))) +
+                                      (lds_read64(cell + tab_off3(idxA3(k, a[i], a[j] + 1))) + lds_read64(cell + tab_off3(idxA3(k, a[i] + 1, a[j] + 1))));
                     const double mom = s4 - (s4 != 0.0 ? kv4 : 0.0); // absent cell: all tables are zero
                     const bool neg = (k == 2) ? upper : (a[k] == 0);   // sign of dN_a/dx_k (upper layer: z-mirrored tables)
                     pres[k] += neg ? -mom : mom;
@@ -685,7 +694,7 @@ namespace pfm
         if constexpr (HET)
           {
             constexpr Vis vi = visit_of(W, V);
-            const int cs = (int)(lane_base - s_tab) + (vi.ey * C3X + vi.ex);
+            const int cs = lane_cs + (vi.ey * C3X + vi.ex);
             lamv[V] = s_lam[cs];
             muv[V] = s_mu[cs];
           }
@@ -749,7 +758,7 @@ namespace pfm
   } // namespace
 
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal, double *res_pde, int lds_pad /* bytes of unused dynamic LDS: launch_cart_matrix */)
+                      const void *d_scal, double *res_pde, int lds_total /* LDS bytes per workgroup to pad to (launch_cart_matrix), 0: none */)
   {
     int rc = ensure_g1();
     if (rc)
@@ -765,15 +774,30 @@ namespace pfm
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
     static const int prio = getenv("PFM_UU_PRIO") ? atoi(getenv("PFM_UU_PRIO")) : 0; // bit 0: halo loads, 1: w*g, 2: copy-out
-#define PFM_UU3(NC, HETV, RESV) hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, lds_pad, s, v, cv, S, vals_uu, nullptr, res_pde, prio)
-    if (getenv("PFM_UU_CLK") && !il && !het && !res) // profiling only
+    // dynamic LDS on top of the kernel's own: the pair launch asks for the allocation of the phase-field kernel
+    auto own_lds = [](const void *fn) {
+      hipFuncAttributes at{};
+      return hipFuncGetAttributes(&at, fn) == hipSuccess ? (int)at.sharedSizeBytes : 0;
+    };
+#define PFM_UU3(NC, HETV, RESV)                                                                                              \
+  do                                                                                                                         \
+    {                                                                                                                        \
+      static const int own = own_lds(reinterpret_cast<const void *>(&k_cart_uu3<NC, false, HETV, RESV>));                    \
+      const int pad = lds_total > 0 ? std::max(0, lds_total - own) : 0;                                                      \
+      hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, pad, s, v, cv, S, vals_uu, nullptr, res_pde, prio); \
+    }                                                                                                                        \
+  while (0)
+    if (getenv("PFM_UU_CLK") && !il && !het) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
         const size_t nd = (size_t)xcd_grid(nb) * 8;
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr, prio);
+        if (res)
+          hipLaunchKernelGGL((k_cart_uu3<3, true, false, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, res_pde, prio);
+        else
+          hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr, prio);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[8] = {};

@@ -158,7 +158,7 @@ namespace pfm
                        const void *d_scal, double *res_pde);
   // res_pde != nullptr: the kernel also writes the displacement rows of the residual (from its matrix rows, see the kernel)
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
-                      const void *d_scal, double *res_pde, int lds_pad = 0);
+                      const void *d_scal, double *res_pde, int lds_total = 0);
   // node graph of a general mesh on the device (pfm_graph.hip)
   struct GraphScratch
   {
