@@ -90,6 +90,13 @@ namespace pfm
         }
       return sum;
     }
+    // the entries of G1 as literals (same arithmetic as make_g1, evaluated by the compiler): inside a loop a value read from
+    // c_g1 is a loop invariant that is hoisted and held -- or spilled -- across every phase of the loop body
+    constexpr double g1_gx(int q) { return q == 0 ? 0.5 - 0.5 * 0.7745966692414834 : (q == 1 ? 0.5 : 0.5 + 0.5 * 0.7745966692414834); }
+    constexpr double g1_w(int q) { return q == 1 ? 8.0 / 18.0 : 5.0 / 18.0; }
+    constexpr double g1_n(int a, int q) { return a == 0 ? 1.0 - g1_gx(q) : g1_gx(q); }
+    constexpr double g1_m(int g, int q) { return g == 0 ? g1_n(0, q) * g1_n(0, q) : (g == 1 ? g1_n(0, q) * g1_n(1, q) : g1_n(1, q) * g1_n(1, q)); }
+
     template <int J, int W>
     struct G1Sx
     {
@@ -141,6 +148,7 @@ namespace pfm
       double vww[3][3];                // vol w(a) w(b)
       double lapP[3][3], lapQ[3][3];   // Laplace moments [g_x][g_y]: in-plane part (times mbar_gz), d/dz part (times s(g_z))
       double lapM[27];                 // G_c eps sum_q w grad N_a . grad N_b by moment index g_x + 3 g_y + 9 g_z
+      double pc_res;                   // (alpha_B - 1) p / (1 - kappa): pressure part of the displacement residual (k_cart_uu3<RES>)
     };
 
     // 1-D Gauss(3) data for a RUN-TIME point index (a per-lane index into the __constant__ table would be a vector
@@ -151,8 +159,11 @@ namespace pfm
     // the same from ONE nodal field: staggered scheme (no clamping of the old fields at the q-points), where pf_extra is
     // linear in (phi_old, phi_oldold) up to its final clamp -- pw = phi_old if use_old_timestep_pf, else
     // phi_oldold + tfac (phi_old - phi_oldold), formed per node by the caller
-    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScal &S, int qz, double wg[9])
+    template <bool LIT = false /* Gauss data as literals instead of c_g1 */, class MatScalRef>
+    __device__ __forceinline__ void cell_wg_plane_lin(const double pw[8], const MatScalRef &S, int qz, double wg[9])
     {
+      auto N = [](int a, int q) __attribute__((always_inline)) { return LIT ? g1_n(a, q) : c_g1.n[a][q]; };
+      auto Wt = [](int q) __attribute__((always_inline)) { return LIT ? g1_w(q) : c_g1.w[q]; };
       const double nz1 = gauss_n1(qz), nz0 = 1.0 - nz1, wz = gauss_w(qz); // q_z is a per-lane run-time index
       double a[4];
 #pragma unroll
@@ -161,24 +172,27 @@ namespace pfm
 #pragma unroll
       for (int qy = 0; qy < 3; ++qy)
         {
-          const double a0 = c_g1.n[0][qy] * a[0] + c_g1.n[1][qy] * a[2];
-          const double a1 = c_g1.n[0][qy] * a[1] + c_g1.n[1][qy] * a[3];
+          const double a0 = N(0, qy) * a[0] + N(1, qy) * a[2];
+          const double a1 = N(0, qy) * a[1] + N(1, qy) * a[3];
 #pragma unroll
           for (int qx = 0; qx < 3; ++qx)
             {
-              double pfx = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
+              double pfx = N(0, qx) * a0 + N(1, qx) * a1;
               if (!S.use_old)
                 pfx = fmin(fmax(pfx, 0.0), 1.0);
               const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * wz) * g;
+              wg[qx + 3 * qy] = S.vol * (Wt(qx) * Wt(qy) * wz) * g;
             }
         }
     }
 
     // weights w*g(q) of one cell at the 9 q-points of one z-level (cracks.cc:2262-2277)
-    __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScal &S, int qz,
+    template <bool LIT = false, class MatScalRef>
+    __device__ __forceinline__ void cell_wg_plane(const double po[8], const double poo[8], const MatScalRef &S, int qz,
                                                   double wg[9])
     {
+      auto N = [](int a, int q) __attribute__((always_inline)) { return LIT ? g1_n(a, q) : c_g1.n[a][q]; };
+      auto Wt = [](int q) __attribute__((always_inline)) { return LIT ? g1_w(q) : c_g1.w[q]; };
       const double nz1 = gauss_n1(qz), nz0 = 1.0 - nz1, wz = gauss_w(qz);
       double a[4], b[4];
 #pragma unroll
@@ -190,15 +204,15 @@ namespace pfm
 #pragma unroll
       for (int qy = 0; qy < 3; ++qy)
         {
-          const double a0 = c_g1.n[0][qy] * a[0] + c_g1.n[1][qy] * a[2];
-          const double a1 = c_g1.n[0][qy] * a[1] + c_g1.n[1][qy] * a[3];
-          const double b0 = c_g1.n[0][qy] * b[0] + c_g1.n[1][qy] * b[2];
-          const double b1 = c_g1.n[0][qy] * b[1] + c_g1.n[1][qy] * b[3];
+          const double a0 = N(0, qy) * a[0] + N(1, qy) * a[2];
+          const double a1 = N(0, qy) * a[1] + N(1, qy) * a[3];
+          const double b0 = N(0, qy) * b[0] + N(1, qy) * b[2];
+          const double b1 = N(0, qy) * b[1] + N(1, qy) * b[3];
 #pragma unroll
           for (int qx = 0; qx < 3; ++qx)
             {
-              double pfo = c_g1.n[0][qx] * a0 + c_g1.n[1][qx] * a1;
-              double pfoo = c_g1.n[0][qx] * b0 + c_g1.n[1][qx] * b1;
+              double pfo = N(0, qx) * a0 + N(1, qx) * a1;
+              double pfoo = N(0, qx) * b0 + N(1, qx) * b1;
               if (S.monolithic)
                 {
                   pfo = fmax(0.0, pfo);
@@ -212,7 +226,7 @@ namespace pfm
               if (S.use_old)
                 pfx = pfo;
               const double g = (1 - S.kappa) * pfx * pfx + S.kappa;
-              wg[qx + 3 * qy] = S.vol * (c_g1.w[qx] * c_g1.w[qy] * wz) * g;
+              wg[qx + 3 * qy] = S.vol * (Wt(qx) * Wt(qy) * wz) * g;
             }
         }
     }
@@ -279,6 +293,7 @@ namespace pfm
       s.gc_eps = s.Gc / s.eps;
       s.aB1p2 = 2.0 * s.aB1 * s.p;
       s.lap = s.Gc * s.eps * s.vol;
+      s.pc_res = s.aB1 * s.p / (1.0 - s.kappa);
       const G1 g = make_g1();
       for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b)

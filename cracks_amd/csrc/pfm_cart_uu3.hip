@@ -21,8 +21,10 @@
 // its mirror slot oz = +1; slots with oz = 0 need one cross-half add.
 #include "pfm_internal.h"
 #include "pfm_cart_common.h"
+#include "pfm_dma.h"
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -39,7 +41,14 @@ namespace pfm
     // ds_read_b64 lane group exactly: every table read of the node phase is conflict-free (round 5; with the
     // [table][cell] layout of rounds 1-4, row stride 9, rows 0 and 3 of the tile shared three banks)
     constexpr int TROW3 = 72, TLAY3 = 5 * TROW3, TGRP3 = 2 * TLAY3, TABSZ3 = 8 * TGRP3; // 5760 doubles
-    __host__ __device__ constexpr int tab_off3(int t) { return (t >> 3) * TGRP3 + (t & 7) * C3X; }
+    // storage slot of table t: the pair tables T^xz (39..50) and T^yz (51..62) one slot up, so that slots 32..39 -- group 4,
+    // doubles [4 TGRP3, 5 TGRP3) -- hold only tables every wave has in registers after its first batch (A, T^xy) and the
+    // one unused slot: that range takes the partial sums of the residual rows while T^xz / T^yz are still being read
+    __host__ __device__ constexpr int tab_off3(int t)
+    {
+      const int sl = t + (t >= 39 ? 1 : 0);
+      return (sl >> 3) * TGRP3 + (sl & 7) * C3X;
+    }
 
     __host__ __device__ constexpr int idxA3(int c, int gi, int gj) { return c * 9 + gi * 3 + gj; }
     __host__ __device__ constexpr int pair3(int lo, int hi) { return lo == 0 ? (hi == 1 ? 0 : 1) : 2; }
@@ -91,22 +100,31 @@ namespace pfm
 
     // the 9 table values one visit needs for ALL nine (row comp, col comp) entries: A^k (k = 0..2), then per pair
     // p = (lo,hi): X_p = T^p[b_lo][a_hi][g_e], Y_p = T^p[a_lo][b_hi][g_e]  (21 FMAs from 9 LDS reads)
-    template <int W, int V>
+    // PARTS: bit 0 = A^k and the pair (x,y), bit 1 = pair (x,z), bit 2 = pair (y,z).  Row component c needs the pairs that
+    // contain c, so the march reads {A, xy, xz} for c = 0, fetches yz behind the barrier of component 0 and xz AGAIN behind
+    // the barrier of component 1 (it is not kept across component 1: 28 instead of 36 table values live, 16 registers of
+    // a budget of 128; the tables of the pairs xz, yz lie outside of what is overwritten before those reads, tab_off3)
+    template <int W, int V, int PARTS>
     __device__ __forceinline__ void uu_load_visit(const double *__restrict__ lane_base, double (&tv)[9])
     {
       constexpr Vis vi = visit_of(W, V);
       constexpr int a[3] = {-vi.ex, -vi.ey, 1}, b[3] = {-vi.ex + vi.ox, -vi.ey + vi.oy, 1 + vi.oz};
       constexpr int g[3] = {a[0] + b[0], a[1] + b[1], a[2] + b[2]};
       const double *cell = lane_base + (vi.ey * TROW3 + vi.ex); // lds_read64: single ds_read_b64s, see pfm_cart_common.h
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
+      if constexpr (PARTS & 1)
         {
-          const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-          tv[k] = lds_read64(cell + tab_off3(idxA3(k, g[i], g[j])));
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            {
+              const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
+              tv[k] = lds_read64(cell + tab_off3(idxA3(k, g[i], g[j])));
+            }
         }
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         {
+          if (!((PARTS >> p) & 1))
+            continue;
           const int lo = (p == 2) ? 1 : 0, hi = (p == 0) ? 1 : 2, e = 3 - lo - hi;
           tv[3 + 2 * p] = lds_read64(cell + tab_off3(idxT3(p, b[lo], a[hi], g[e])));
           tv[4 + 2 * p] = lds_read64(cell + tab_off3(idxT3(p, a[lo], b[hi], g[e])));
@@ -252,429 +270,585 @@ namespace pfm
     }
 
     // =====================================================================================
+    // Round 5: the workgroup MARCHES over a chunk of z-planes of its 8 x 4 tile.  The phases of a plane are those of
+    // rounds 2-4 (w*g -> moment tables of the two cell layers -> node phase / copy-out per row component), but the nodal
+    // halo is a ring of three planes in LDS and the one new plane a step needs (60 nodes, 5 fields + the flag byte, and
+    // the row offsets of the next 32 rows) is REQUESTED one plane ahead with global -> LDS transfers
+    // (global_load_lds_*, pfm_dma.h) by the three waves that have no part in the w*g phase.  The phase clock of round 4
+    // showed the halo loads of a tile (~6k cycles of global latency under the store stream + the barrier behind them,
+    // 8k of a tile's 25k cycles) fully exposed: with one tile per workgroup nothing else of that workgroup can run.
+    //   vmcnt counts loads and stores in order, so the wait for the transfers of a step is vmcnt(#stores the wave has
+    //   issued behind them) -- 18 on a regular tile (6 per row component) -- and never drains the copy-out.
+    constexpr int NHP3 = H3X * H3Y; // 60 nodes per halo plane
+
+    template <bool HET, bool RES>
+    struct UuShared
+    {
+      // landing zone of the requests for the NEXT plane (M0 addresses the first 64 KB of the workgroup's LDS: keep first)
+      double raw_po[64], raw_poo[64];  // [hn]: dwords 2 hn, 2 hn + 1 fetched by lanes 2 (hn % 32), 2 (hn % 32) + 1 of wave 5 + hn / 32
+      double raw_u[RES ? 3 : 1][64];
+      unsigned raw_flag[128];          // [2 hn]: the node's flag byte, zero-extended
+      long long raw_row[NN3];          // nadj_ptr of the next plane's rows (wave 7)
+      unsigned raw_mask[2 * NN3];      // [2 nl]: both lanes of a row fetch its mask
+      double tab[TABSZ3];              // moment tables (layout: tab_off3); layer 1 stored z-mirrored.  Dead once every wave holds
+                                       // its table values: [0, NN3 STG) = second staging buffer, behind it the partial sums of
+                                       // the residual rows (RES)
+      double stage[NN3 * STG];         // staged rows [node][81]; w*g(q) [27][90] during the cell phase
+      double po[NH3], poo[RES ? 1 : NH3]; // ring: plane p in slot (p - (kA - 1)) % 3.  RES => staggered: one combined field
+      double u[RES ? 3 * NH3 : 1];     // displacements of the halo nodes [component][slot][node]
+      double lam[HET ? CS3 : 1], mu[HET ? CS3 : 1];
+      long long rowbase[2][NN3];       // by plane parity: written for plane k + 1 while the copy-out of plane k reads its own
+      unsigned mask[2][NN3];
+      int resrow[2][RES ? NN3 : 1];
+      double pres[RES ? 3 * NN3 : 1]; // pressure part of the residual rows of the current plane [component][node]
+      unsigned char ok[NH3], flag[NH3];
+      int anyflag[3][2];               // per ring slot and request wave: some node of the plane carries a displacement flag
+      int irregular[2];                // by plane parity: some row is not a full, lattice-ordered 27-neighbour row
+    };
+    static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
+    static_assert(NN3 * STG <= 4 * TGRP3 && 2 * 8 * NN3 <= TGRP3, "second staging buffer in front of group 4, the residual sums inside it");
+    using UuSharedRes_ = UuShared<false, true>;
+    static_assert(offsetof(UuSharedRes_, tab) < 65536, "landing zone within reach of M0");
+
+    // The kernel's only argument.  Inside the march every phase re-reads what it needs from the kernel-argument segment
+    // through a pointer the compiler cannot see through (uu_args): values that are invariant over the plane loop would
+    // otherwise be hoisted in front of it and kept -- or spilled -- across all phases of a 128-register budget (the first
+    // build of the march spilled 100-230 vector and 50 scalar registers that way).
+    struct UuArgs
+    {
+      DevView v;
+      CartView cv;
+      const MatScal *Sp; // per-launch scalars in device memory (see pfm_internal.h)
+      double *vals;
+      unsigned long long *dbg;
+      double *res_pde;
+      int zc;
+    };
+    __device__ __forceinline__ const UuArgs &uu_args()
+    {
+      auto p = __builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(p));
+      return *(const UuArgs *)p;
+    }
+#define UU_ENV()                                                                                                             \
+  const UuArgs &A = uu_args();                                                                                               \
+  const DevView &v = A.v;                                                                                                    \
+  const CartView &cv = A.cv;                                                                                                 \
+  const __attribute__((address_space(4))) MatScal &S = *(const __attribute__((address_space(4))) MatScal *)A.Sp;          \
+  int t = threadIdx.x;                                                                                                       \
+  asm volatile("" : "+v"(t));                                                                                                \
+  const int lane = t & 63;                                                                                                   \
+  (void)v;                                                                                                                   \
+  (void)cv;                                                                                                                  \
+  (void)S;                                                                                                                   \
+  (void)lane
+
     template <int NCOL /* 3 blocked, 4 interleaved */, bool CLK = false /* profiling only */,
               bool HET = false /* per-cell Lame coefficients (CartView::cell_lam) */,
               bool RES = false /* also writes the displacement rows of the residual (res_pde) */>
-    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(DevView v, CartView cv, const MatScal *__restrict__ Sp, double *__restrict__ vals,
-                                                         unsigned long long *__restrict__ dbg, double *__restrict__ res_pde, int prio)
+    __global__ __launch_bounds__(NT3, 4) void k_cart_uu3(UuArgs args_in_kernarg_segment)
     {
-      const MatScal &S = *Sp; // per-launch scalars in device memory (see pfm_internal.h)
-      // wave priorities per phase (prio != 0): the halo loads, w*g and the copy-out are short instruction sequences with
-      // long latencies -- issued ahead of the co-resident workgroup's arithmetic
-      if (prio & 1)
-        __builtin_amdgcn_s_setprio(3);
+      (void)args_in_kernarg_segment;
       long long tclk = 0;
+      unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
           {
             const long long now = clock64();
-            if (threadIdx.x == 0 && phase >= 0)
-              dbg[(size_t)blockIdx.x * 8 + phase] += (unsigned long long)(now - tclk); // one slot per tile: no contention
+            if (phase >= 0)
+              acc[phase] += (unsigned long long)(now - tclk); // in registers: a global read-modify-write would measure the store drain
             tclk = now;
           }
       };
       stamp(-1);
-      __shared__ double s_tab[TABSZ3];       // moment tables (layout: tab_off3); layer 1 stored z-mirrored
-      __shared__ double s_stage[NN3 * STG];  // staged rows [node][81]; w*g(q) [27][90] during the cell phase
-      __shared__ double s_po[NH3], s_poo[NH3];
-      __shared__ int s_node[NH3];
-      __shared__ unsigned char s_flag[NH3];
-      __shared__ long long s_rowbase[NN3];
-      __shared__ unsigned s_mask[NN3]; // neighbour mask of the row (bit o: lattice offset o exists)
-      __shared__ double s_lam[HET ? CS3 : 1], s_mu[HET ? CS3 : 1]; // Lame coefficients of the tile's cells
-      __shared__ double s_u[RES ? 3 * NH3 : 1];                    // displacements of the halo nodes [component][node]
-      __shared__ double s_part[RES ? 2 * 8 * NN3 : 1];             // K u per [component & 1][wave = slot set][node]
-      __shared__ double s_pres[RES ? 3 * NN3 : 1];                 // pressure part of the residual [component][node]
-      __shared__ int s_resrow[RES ? NN3 : 1]; // local id of the tile's nodes (residual rows): looked up ONCE, before any store of the
-                                               // workgroup -- a table look-up behind the copy-out stores is a wait for them (round 4)
-      __shared__ int s_any[4]; // waves 0..2: some node of the halo carries a displacement flag; [3]: some row is not full
-      static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
+      __shared__ UuShared<HET, RES> sh;
+      double *const s_tab = sh.tab, *const s_stage = sh.stage;
+      double *const s_part = sh.tab + 4 * TGRP3; // K u per [component & 1][wave = slot set][node] (RES): see tab_off3
+      double *const s_pres = sh.pres;            // pressure part of the residual [component][node] (RES)
 
-      const int t = threadIdx.x;
-      const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1;
-      const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
-      int bid = xcd_tile_index();
-      const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr; // compact launch over the boundary tiles
-      if (listed)
-        {
-          if (bid >= cv.n_bnd_uu3)
-            return;
-          bid = cv.bnd_uu3[bid];
-        }
-      if (bid >= ntx * nty * (cv.o1[2] - cv.o0[2] + 1))
-        return; // padding of the XCD-aware grid
-      const int tix = bid % ntx, tiy = (bid / ntx) % nty, tk = bid / (ntx * nty);
-      const int i0 = cv.o0[0] + tix * T3X, j0 = cv.o0[1] + tiy * T3Y, k = cv.o0[2] + tk;
-      if (!listed && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i0 - 1, i0 + T3X) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + T3Y) ||
-                                               cart_range_has_ghost(cv, 2, k - 1, k + 1)))
-        return; // overlapped assembly: the other launch owns this tile
+      int i0, j0, kA, kB;
+      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: scalar branches between the slot sets
+      {
+        UU_ENV();
+        const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
+        const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
+        const int zc = A.zc, nch = (OWZ + zc - 1) / zc;
+        int bid = xcd_tile_index();
+        const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr; // compact launch over the boundary tiles (zc == 1)
+        if (listed)
+          {
+            if (bid >= cv.n_bnd_uu3)
+              return;
+            bid = cv.bnd_uu3[bid];
+          }
+        if (bid >= ntx * nty * nch)
+          return; // padding of the XCD-aware grid
+        const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
+        i0 = cv.o0[0] + tix * T3X;
+        j0 = cv.o0[1] + tiy * T3Y;
+        kA = cv.o0[2] + chunk * zc;
+        kB = min(kA + zc, cv.o1[2] + 1); // node planes [kA, kB)
+        if (!listed && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i0 - 1, i0 + T3X) || cart_range_has_ghost(cv, 1, j0 - 1, j0 + T3Y) ||
+                                                 cart_range_has_ghost(cv, 2, kA - 1, kA + 1)))
+          return; // overlapped assembly (zc == 1): the other launch owns this tile
 
-      // ---- phase 0: nodal halo + CSR row info (flags of the tile are collected per wave: no atomics, no init barrier)
-      stamp(0);
-      if (t < NH3)
-        {
-          const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / (H3X * H3Y);
-          const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = k - 1 + lk;
-          int n = -1;
-          double a = 0.0, b = 0.0, uu[3] = {0.0, 0.0, 0.0};
-          unsigned char f = 0;
-          if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ)
-            {
-              n = cart_local_id(cv, gi, gj, gk);
-              a = v.phi_old[n];
-              b = v.phi_oldold[n];
-              f = v.node_flags[n];
-              if constexpr (RES)
-                {
-                  uu[0] = v.u[0][n];
-                  uu[1] = v.u[1][n];
-                  uu[2] = v.u[2][n];
-                }
-              if (!S.monolithic) // one combined field is interpolated in the cell phase (cell_wg_plane_lin)
-                a = S.use_old ? a : b + S.tfac * (a - b);
-            }
-          if constexpr (RES)
-            {
-              s_u[t] = uu[0];
-              s_u[(RES ? NH3 : 0) + t] = uu[1];
-              s_u[(RES ? 2 * NH3 : 0) + t] = uu[2];
-            }
-          s_node[t] = n;
-          s_po[t] = a;
-          s_poo[t] = b;
-          s_flag[t] = f;
-          const unsigned long long any = __ballot((f & 7u) != 0);
-          if ((t & 63) == 0)
-            s_any[t >> 6] = any != 0; // waves 0..2
-        }
-      else if (t >= 256 && t < 256 + NN3)
-        {
-          const int nl = t - 256, li = nl % T3X, lj = nl / T3X;
-          const int gi = i0 + li, gj = j0 + lj;
-          long long base = -1;
-          unsigned mask = 0u;
-          if (gi <= cv.o1[0] && gj <= cv.o1[1])
-            {
-              const int r = cart_local_id(cv, gi, gj, k);
-              base = (long long)NCOL * NCOL * v.nadj_ptr[r];
-              mask = cv.nbr_mask[r];
-              if constexpr (RES)
-                s_resrow[nl] = r;
-            }
-          s_rowbase[nl] = base;
-          s_mask[nl] = mask;
-          const unsigned long long irr = __ballot(mask != 0x7ffffffu); // fewer than 27 neighbours, or not an owned node
-          if (nl == 0)
-            s_any[3] = irr != 0;
-        }
-      else if (HET && t >= 320 && t < 320 + CS3)
-        {
-          const int cs = t - 320, l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
-          const int ci = i0 - 1 + cx, cj = j0 - 1 + cy, ck = k - 1 + l;
-          double la = 0.0, mu = 0.0;
-          if (ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1 && ck >= 0 && ck < cv.NZ - 1)
-            {
-              const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
-              la = cv.cell_lam[cidx];
-              mu = cv.cell_mu[cidx];
-            }
-          s_lam[HET ? cs : 0] = la;
-          s_mu[HET ? cs : 0] = mu;
-        }
-      stamp(5); // thread 0: its own halo loads have returned and are stored
-      __syncthreads();
-      stamp(0);
-      if (prio & 2)
-        __builtin_amdgcn_s_setprio(2);
-      else if (prio)
-        __builtin_amdgcn_s_setprio(0);
-
-      // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
-      if (t < 3 * CS3)
-        {
-          const int cs = t % CS3, qz = t / CS3;
-          const int l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
-          const int h000 = cx + H3X * (cy + H3Y * l);
-          const bool valid = s_node[h000] >= 0 && s_node[h000 + 1 + H3X + H3X * H3Y] >= 0;
-          double wg[9];
-          if (valid)
-            {
-              double po[8], poo[8];
-              if (!S.monolithic)
-                {
+        // ---- prologue: nodal planes kA - 1 .. kA + 1 and the row info of plane kA through registers (one exposed round
+        // trip per chunk)
+        stamp(0);
+        if (t < NH3)
+          {
+            const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / NHP3;
+            const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = kA - 1 + lk;
+            double a = 0.0, b = 0.0, uu[3] = {0.0, 0.0, 0.0};
+            unsigned char f = 0;
+            const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ;
+            if (in)
+              {
+                const int n = cart_local_id(cv, gi, gj, gk);
+                a = v.phi_old[n];
+                b = v.phi_oldold[n];
+                f = v.node_flags[n];
+                if constexpr (RES)
+                  {
+                    uu[0] = v.u[0][n];
+                    uu[1] = v.u[1][n];
+                    uu[2] = v.u[2][n];
+                  }
+                if (!S.monolithic) // one combined field is interpolated in the cell phase (cell_wg_plane_lin)
+                  a = S.use_old ? a : b + S.tfac * (a - b);
+              }
+            if constexpr (RES)
+              {
+                sh.u[t] = uu[0];
+                sh.u[(RES ? NH3 : 0) + t] = uu[1];
+                sh.u[(RES ? 2 * NH3 : 0) + t] = uu[2];
+              }
+            else
+              sh.poo[RES ? 0 : t] = b;
+            sh.ok[t] = in;
+            sh.po[t] = a;
+            sh.flag[t] = f;
+            // flags of the three planes, per plane and per wave that holds a part of it (plane q = threads [60 q, 60 q + 60):
+            // wave 0 | waves 0, 1 | waves 1, 2): no atomics, no init barrier
+            const int lk_ = t / NHP3;
 #pragma unroll
-                  for (int b = 0; b < 8; ++b)
-                    po[b] = s_po[h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1)];
-                  cell_wg_plane_lin(po, S, qz, wg);
+            for (int q = 0; q < 3; ++q)
+              {
+                const unsigned long long any = __ballot((f & 7u) != 0 && lk_ == q);
+                const int w_first = (q * NHP3) >> 6, w_last = (q * NHP3 + NHP3 - 1) >> 6;
+                if (lane == 0 && (wave == w_first || wave == w_last))
+                  sh.anyflag[q][wave == w_first ? 0 : 1] = any != 0;
+              }
+            if (t == 0)
+              sh.anyflag[0][1] = 0; // plane 0 lies in wave 0 alone
+          }
+        else if (t >= 256 && t < 256 + NN3)
+          {
+            const int nl = t - 256, li = nl % T3X, lj = nl / T3X;
+            const int gi = i0 + li, gj = j0 + lj;
+            long long base = -1;
+            unsigned mask = 0u;
+            if (gi <= cv.o1[0] && gj <= cv.o1[1])
+              {
+                const int r = cart_local_id(cv, gi, gj, kA);
+                base = (long long)NCOL * NCOL * v.nadj_ptr[r];
+                mask = cv.nbr_mask[r];
+                if constexpr (RES)
+                  sh.resrow[0][nl] = r;
+              }
+            sh.rowbase[0][nl] = base;
+            sh.mask[0][nl] = mask;
+            const unsigned long long irr = __ballot(mask != 0x7ffffffu); // fewer than 27 neighbours, or not an owned node
+            if (nl == 0)
+              sh.irregular[0] = irr != 0;
+          }
+        stamp(7); // thread 0: its own halo loads have returned and are stored
+      }
+
+      // residual row of component c of a plane: sum of the 8 slot sets in a fixed order, constrained rows get 0
+      // (cracks.cc:2440-2456).  The sums of component c are stored BEHIND the barrier of component c (their LDS is table
+      // storage until then) and read behind the next barrier; par_row / s_row = row parity / ring slot of that plane
+      auto residual_out = [&](int c, int par_row, int s_row) __attribute__((always_inline)) {
+        if constexpr (RES)
+          {
+            UU_ENV();
+            if (t < NN3 && sh.rowbase[par_row][t] >= 0)
+              {
+                double sum = -s_pres[RES ? c * NN3 + t : 0];
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                  sum += s_part[((c & 1) * 8 + w) * NN3 + t];
+                const int li = t % T3X, lj = t / T3X;
+                const int row = sh.resrow[par_row][RES ? t : 0];
+                const bool con = (sh.flag[s_row * NHP3 + (li + 1) + H3X * (lj + 1)] >> c) & 1u;
+                const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + c : (long long)row * 3 + c;
+                A.res_pde[di] = con ? 0.0 : -sum;
+              }
+          }
+      };
+
+      int it = 0;
+#pragma unroll 1
+      for (int k = kA; k < kB; ++k, ++it)
+        {
+          // ring slots of the planes k - 1, k, k + 1
+          const int s0 = it % 3, s1 = (it + 1) % 3, s2 = (it + 2) % 3, par = it & 1;
+          const bool more = k + 1 < kB;
+          lds_barrier(); // (first plane: the prologue's planes; later: the landed plane, the last plane's residual sums)
+          stamp(0);
+          if (it > 0)
+            residual_out(2, par ^ 1, s0); // component 2 of the PREVIOUS plane: its sums were stored behind its last barrier
+          if constexpr (HET)
+            {
+              UU_ENV();
+              if (t >= 320 && t < 320 + CS3) // (in front of the requests of the same waves: its loads are waited for here)
+                {
+                  const int cs = t - 320, l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
+                  const int ci = i0 - 1 + cx, cj = j0 - 1 + cy, ck = k - 1 + l;
+                  double la = 0.0, mu = 0.0;
+                  if (ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1 && ck >= 0 && ck < cv.NZ - 1)
+                    {
+                      const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+                      la = cv.cell_lam[cidx];
+                      mu = cv.cell_mu[cidx];
+                    }
+                  sh.lam[HET ? cs : 0] = la;
+                  sh.mu[HET ? cs : 0] = mu;
+                }
+            }
+          // ---- requests for plane k + 2 (waves 5, 6: nodes [32 (wave - 5), +32) of the halo plane) and the rows of plane
+          // k + 1 (wave 7): global -> LDS, no registers; these three waves have no part in the w*g phase
+          if (more && wave >= 5)
+            {
+              UU_ENV();
+              if (wave < 7)
+                {
+                  const int kz = k + 2;
+                  const int hn = 32 * (wave - 5) + (lane >> 1);
+                  const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
+                  const bool in = hn < NHP3 && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
+                  unsigned n = in ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
+                  asm volatile("" : "+v"(n)); // a looked-up id (ghost layers) is waited for HERE, in front of the requests
+                  if (in)
+                    {
+                      const unsigned boff = 8u * n + 4u * (lane & 1);
+                      dma_b32(v.phi_old, boff, reinterpret_cast<uint32_t *>(sh.raw_po) + 64 * (wave - 5));
+                      dma_b32(v.phi_oldold, boff, reinterpret_cast<uint32_t *>(sh.raw_poo) + 64 * (wave - 5));
+                      if constexpr (RES)
+                        {
+#pragma unroll
+                          for (int c = 0; c < 3; ++c)
+                            dma_b32(v.u[c], boff, reinterpret_cast<uint32_t *>(sh.raw_u[RES ? c : 0]) + 64 * (wave - 5));
+                        }
+                      dma_u8(v.node_flags, n, sh.raw_flag + 64 * (wave - 5));
+                    }
                 }
               else
                 {
-#pragma unroll
-                  for (int b = 0; b < 8; ++b)
+                  const int nl = lane >> 1, li = nl % T3X, lj = nl / T3X;
+                  const int gi = i0 + li, gj = j0 + lj;
+                  const bool in = gi <= cv.o1[0] && gj <= cv.o1[1];
+                  unsigned r = in ? (unsigned)cart_local_id(cv, gi, gj, k + 1) : 0u;
+                  asm volatile("" : "+v"(r));
+                  if (in)
                     {
-                      const int hb = h000 + (b & 1) + H3X * ((b >> 1) & 1) + H3X * H3Y * ((b >> 2) & 1);
-                      po[b] = s_po[hb];
-                      poo[b] = s_poo[hb];
+                      dma_b32(v.nadj_ptr, 8u * r + 4u * (lane & 1), reinterpret_cast<uint32_t *>(sh.raw_row));
+                      dma_b32(cv.nbr_mask, 4u * r, sh.raw_mask);
                     }
-                  cell_wg_plane(po, poo, S, qz, wg);
                 }
             }
-          else
-            {
-#pragma unroll
-              for (int q = 0; q < 9; ++q)
-                wg[q] = 0.0;
-            }
-#pragma unroll
-          for (int q = 0; q < 9; ++q)
-            s_stage[(qz * 9 + q) * CS3 + cs] = wg[q];
-        }
-      __syncthreads();
-      stamp(1);
-      if (prio)
-        __builtin_amdgcn_s_setprio(0);
 
-      // ---- cell phase b: moment tables.  Round 3: wave <-> (family f, cell group) with the family WAVE-UNIFORM: waves
-      // 0..5 = families 0..2 x cell groups {cells 0..44 = layer 0, cells 45..89 = layer 1}, lane <-> cell.  A family is
-      // A^f plus both halves of the pair table that contracts direction f first (T^xy, T^xz for f = 0 ... see below), so
-      // that the 27 w*g values of a cell are read ONCE for 198 flops (round 2: thread <-> (cell, task), 9 tasks per cell
-      // with run-time strides: 27 reads per 65 flops, and 63 % of the VALU instructions of the phase were address
-      // arithmetic -- on this chip an integer VALU instruction costs the same 4-cycle issue slot as an FP64 FMA).
-      // Every stride, table number and the z-mirroring of layer 1 are compile-time constants per (family, layer).
-      // The arithmetic of each table entry is unchanged (bitwise identical tables).
-      // Families: f = 0: A^x, T^xy (lo = x);  f = 1: A^y, T^yz (lo = y);  f = 2: A^z, T^xz (lo = x, hi = z).
-      {
-        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-        const int ln = t & 63;
-        auto family = [&](auto Ff, auto Ll) __attribute__((always_inline)) {
-          constexpr int f = decltype(Ff)::value, l = decltype(Ll)::value;
-          constexpr bool mir = l == 1;
-          if (ln < CL3)
-            {
-              const int cs = l * CL3 + ln;
-              const double *wq = s_stage + cs;
-              const int cyl = ln / C3X;
-              double *out = s_tab + l * TLAY3 + cyl * TROW3 + (ln - cyl * C3X);
-              double w27[27];
-#pragma unroll
-              for (int q = 0; q < 27; ++q)
-                w27[q] = lds_read64(wq + q * CS3);
-              __builtin_amdgcn_sched_barrier(0);
-              // ---- A^c, c = f: sum over q_c, then the two moment axes (i, j) = other axes ascending
+          // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
+          {
+            UU_ENV();
+            if (t < 3 * CS3)
               {
-                constexpr int c = f;
-                constexpr int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
-                constexpr int si = (c == 0) ? 3 : 1;
-                constexpr int sj = (c == 2) ? 3 : 9;
-                double s9[3][3]; // [qj][qi]
-#pragma unroll
-                for (int qj = 0; qj < 3; ++qj)
-#pragma unroll
-                  for (int qi = 0; qi < 3; ++qi)
-                    {
-                      const int q0 = qi * si + qj * sj;
-                      s9[qj][qi] = (w27[q0] + w27[q0 + sc]) + w27[q0 + 2 * sc];
-                    }
-                constexpr bool zj = (c != 2); // for c = x or y the second moment axis j is z
-#pragma unroll
-                for (int gi = 0; gi < 3; ++gi)
+                const int cs = t % CS3, qz = t / CS3;
+                const int l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
+                const int hq = cx + H3X * cy;
+                const int pa = (l ? s1 : s0) * NHP3 + hq, pb = (l ? s2 : s1) * NHP3 + hq; // lower / upper nodal plane of the layer
+                const bool valid = sh.ok[pa] && sh.ok[pb + 1 + H3X];
+                double wg[9];
+                if (valid)
                   {
-                    double tq[3];
-#pragma unroll
-                    for (int qj = 0; qj < 3; ++qj)
-                      tq[qj] = s9[qj][0] * c_g1.m[gi][0] + s9[qj][1] * c_g1.m[gi][1] + s9[qj][2] * c_g1.m[gi][2];
-#pragma unroll
-                    for (int gj = 0; gj < 3; ++gj)
+                    double po[8], poo[8];
+                    if (!S.monolithic)
                       {
-                        const double val = tq[0] * c_g1.m[gj][0] + tq[1] * c_g1.m[gj][1] + tq[2] * c_g1.m[gj][2];
-                        const int gjm = (mir && zj) ? 2 - gj : gj; // layer 1 is stored z-mirrored
-                        out[tab_off3(c * 9 + gi * 3 + gjm)] = val;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                          {
+                            po[b] = sh.po[pa + (b & 1) + H3X * ((b >> 1) & 1)];
+                            po[b + 4] = sh.po[pb + (b & 1) + H3X * ((b >> 1) & 1)];
+                          }
+                        cell_wg_plane_lin<true>(po, S, qz, wg);
+                      }
+                    else
+                      {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                          {
+                            const int ha = pa + (b & 1) + H3X * ((b >> 1) & 1), hb = pb + (b & 1) + H3X * ((b >> 1) & 1);
+                            po[b] = sh.po[ha];
+                            po[b + 4] = sh.po[hb];
+                            poo[b] = sh.poo[RES ? 0 : ha];
+                            poo[b + 4] = sh.poo[RES ? 0 : hb];
+                          }
+                        cell_wg_plane<true>(po, poo, S, qz, wg);
                       }
                   }
-              }
-              // ---- T^p, both halves al = 0, 1: p = 0 (x,y) for f = 0, p = 2 (y,z) for f = 1, p = 1 (x,z) for f = 2
-              {
-                constexpr int p = (f == 0) ? 0 : (f == 1) ? 2 : 1;
-                constexpr int slo = (p == 2) ? 3 : 1;
-                constexpr int shi = (p == 0) ? 3 : 9;
-                constexpr int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
-                constexpr bool mz = mir && p == 0, mb = mir && p != 0;
-#pragma unroll
-                for (int al = 0; al < 2; ++al)
+                else
                   {
-                    const double na0 = c_g1.n[al][0], na1 = c_g1.n[al][1], na2 = c_g1.n[al][2];
-                    double t1[3][3]; // [q_e][q_hi]
 #pragma unroll
-                    for (int qe = 0; qe < 3; ++qe)
+                    for (int q = 0; q < 9; ++q)
+                      wg[q] = 0.0;
+                  }
 #pragma unroll
-                      for (int qh = 0; qh < 3; ++qh)
+                for (int q = 0; q < 9; ++q)
+                  s_stage[(qz * 9 + q) * CS3 + cs] = wg[q];
+              }
+          }
+          lds_barrier();
+          stamp(1);
+
+          // ---- cell phase b: moment tables.  Round 3: wave <-> (family f, cell group) with the family WAVE-UNIFORM: waves
+          // 0..5 = families 0..2 x cell groups {cells 0..44 = layer 0, cells 45..89 = layer 1}, lane <-> cell.  A family is
+          // A^f plus both halves of the pair table that contracts direction f first (T^xy, T^xz for f = 0 ... see below), so
+          // that the 27 w*g values of a cell are read ONCE for 198 flops (round 2: thread <-> (cell, task), 9 tasks per cell
+          // with run-time strides: 27 reads per 65 flops, and 63 % of the VALU instructions of the phase were address
+          // arithmetic -- on this chip an integer VALU instruction costs the same 4-cycle issue slot as an FP64 FMA).
+          // Every stride, table number and the z-mirroring of layer 1 are compile-time constants per (family, layer).
+          // The arithmetic of each table entry is unchanged (bitwise identical tables).
+          // Families: f = 0: A^x, T^xy (lo = x);  f = 1: A^y, T^yz (lo = y);  f = 2: A^z, T^xz (lo = x, hi = z).
+          {
+            UU_ENV();
+            auto family = [&](auto Ff, auto Ll) __attribute__((always_inline)) {
+              constexpr int f = decltype(Ff)::value, l = decltype(Ll)::value;
+              constexpr bool mir = l == 1;
+              if (lane < CL3)
+                {
+                  const int cs = l * CL3 + lane;
+                  const double *wq = s_stage + cs;
+                  const int cyl = lane / C3X;
+                  double *out = s_tab + l * TLAY3 + cyl * TROW3 + (lane - cyl * C3X);
+                  double w27[27];
+#pragma unroll
+                  for (int q = 0; q < 27; ++q)
+                    w27[q] = lds_read64(wq + q * CS3);
+                  __builtin_amdgcn_sched_barrier(0);
+                  // ---- A^c, c = f: sum over q_c, then the two moment axes (i, j) = other axes ascending
+                  {
+                    constexpr int c = f;
+                    constexpr int sc = (c == 0) ? 1 : (c == 1) ? 3 : 9;
+                    constexpr int si = (c == 0) ? 3 : 1;
+                    constexpr int sj = (c == 2) ? 3 : 9;
+                    double s9[3][3]; // [qj][qi]
+#pragma unroll
+                    for (int qj = 0; qj < 3; ++qj)
+#pragma unroll
+                      for (int qi = 0; qi < 3; ++qi)
                         {
-                          const int q0 = qh * shi + qe * se;
-                          t1[qe][qh] = (w27[q0] * na0 + w27[q0 + slo] * na1) + w27[q0 + 2 * slo] * na2;
+                          const int q0 = qi * si + qj * sj;
+                          s9[qj][qi] = (w27[q0] + w27[q0 + sc]) + w27[q0 + 2 * sc];
                         }
+                    constexpr bool zj = (c != 2); // for c = x or y the second moment axis j is z
 #pragma unroll
-                    for (int be = 0; be < 2; ++be)
+                    for (int gi = 0; gi < 3; ++gi)
                       {
-                        double t2[3];
+                        double tq[3];
 #pragma unroll
-                        for (int qe = 0; qe < 3; ++qe)
-                          t2[qe] = t1[qe][0] * c_g1.n[be][0] + t1[qe][1] * c_g1.n[be][1] + t1[qe][2] * c_g1.n[be][2];
-                        const int bes = mb ? 1 - be : be;
+                        for (int qj = 0; qj < 3; ++qj)
+                          tq[qj] = s9[qj][0] * g1_m(gi, 0) + s9[qj][1] * g1_m(gi, 1) + s9[qj][2] * g1_m(gi, 2);
 #pragma unroll
-                        for (int g = 0; g < 3; ++g)
+                        for (int gj = 0; gj < 3; ++gj)
                           {
-                            const double val = t2[0] * c_g1.m[g][0] + t2[1] * c_g1.m[g][1] + t2[2] * c_g1.m[g][2];
-                            const int gm = mz ? 2 - g : g;
-                            out[tab_off3(27 + p * 12 + al * 6 + bes * 3 + gm)] = mb ? -val : val;
+                            const double val = tq[0] * g1_m(gj, 0) + tq[1] * g1_m(gj, 1) + tq[2] * g1_m(gj, 2);
+                            const int gjm = (mir && zj) ? 2 - gj : gj; // layer 1 is stored z-mirrored
+                            out[tab_off3(c * 9 + gi * 3 + gjm)] = val;
                           }
                       }
                   }
-              }
-            }
-        };
-        using std::integral_constant;
-        switch (wv)
-          {
-            case 0: family(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
-            case 1: family(integral_constant<int, 0>{}, integral_constant<int, 1>{}); break;
-            case 2: family(integral_constant<int, 1>{}, integral_constant<int, 0>{}); break;
-            case 3: family(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
-            case 4: family(integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
-            case 5: family(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
-            default: break;
-          }
-      }
-      __syncthreads();
-      stamp(2);
-
-      // ---- node phase + copy-out.  Every wave first reads the 36 table values of its slot set (4 visits x 9) in ONE
-      // batch and keeps them in registers for all three row components: 36 LDS reads per lane instead of 84, one
-      // latency instead of a chain of them, and the tables are dead afterwards -- their LDS becomes the second staging
-      // buffer, so that the copy-out of component c overlaps the arithmetic of component c + 1 (one barrier per
-      // component instead of two).
-      const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform: scalar branches between the slot sets
-      const int lane = t & 63;
-      const bool upper = lane >= 32;
-      const int nl_lane = lane & 31;
-      const int ti = nl_lane % T3X, tj = nl_lane / T3X;
-      const int hc = (ti + 1) + H3X * ((tj + 1) + H3Y * 1);
-      const bool masked = (s_any[0] | s_any[1] | s_any[2]) != 0;
-      const bool regular_tile = (NCOL == 3) && s_any[3] == 0;
-      const unsigned row_flag = s_flag[hc];
-      // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
-      const double *lane_base = s_tab + (upper ? TLAY3 : 0) + (tj + 1) * TROW3 + (ti + 1);
-      const int lane_cs = (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1); // the same cell in [layer][cy][cx] order (s_lam, s_mu)
-      const unsigned char *flag_own = s_flag + hc, *flag_half = s_flag + hc + (upper ? H3X * H3Y : -H3X * H3Y);
-      static_assert(NN3 * STG <= TABSZ3, "second staging buffer must fit in the table storage");
-      UuCoef K;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        {
-#pragma unroll
-          for (int k = 0; k < 3; ++k)
-            K.cA[c][k] = S.cA[c][k];
-          K.cTl[c] = S.cTl[c];
-          K.cTm[c] = S.cTm[c];
-          K.gA[c] = S.ih[c] * S.ih[c];
-          K.cT[c] = S.cT[c];
-        }
-
-      auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
-        if (prio & 4)
-          __builtin_amdgcn_s_setprio(3);
-        if (regular_tile)
-          {
-            // thread <-> (node group g, element el) with el fixed: nodes g, g + 6, ..., g + 30 -- no division per
-            // position, one row-base read and one value read per node, all of them in flight before the first store (a
-            // loop pays two dependent LDS round trips of ~130 cycles per iteration); threads 486..511 idle
-            constexpr int NG = 6, NIT = (NN3 + NG - 1) / NG;
-            int tq = t;
-            asm volatile("" : "+v"(tq)); // (g, el) are recomputed per component, not kept live across the node phases
-            const int g = tq / STG, el = tq - g * STG;
-            if (g < NG)
-              {
-                long long rb[NIT];
-                double val[NIT];
-#pragma unroll
-                for (int i = 0; i < NIT; ++i)
+                  // ---- T^p, both halves al = 0, 1: p = 0 (x,y) for f = 0, p = 2 (y,z) for f = 1, p = 1 (x,z) for f = 2
                   {
-                    const int nl = min(g + NG * i, NN3 - 1);
-                    rb[i] = s_rowbase[nl];
-                    val[i] = stage[nl * STG + el];
+                    constexpr int p = (f == 0) ? 0 : (f == 1) ? 2 : 1;
+                    constexpr int slo = (p == 2) ? 3 : 1;
+                    constexpr int shi = (p == 0) ? 3 : 9;
+                    constexpr int se = (p == 0) ? 9 : (p == 1) ? 3 : 1;
+                    constexpr bool mz = mir && p == 0, mb = mir && p != 0;
+#pragma unroll
+                    for (int al = 0; al < 2; ++al)
+                      {
+                        const double na0 = g1_n(al, 0), na1 = g1_n(al, 1), na2 = g1_n(al, 2);
+                        double t1[3][3]; // [q_e][q_hi]
+#pragma unroll
+                        for (int qe = 0; qe < 3; ++qe)
+#pragma unroll
+                          for (int qh = 0; qh < 3; ++qh)
+                            {
+                              const int q0 = qh * shi + qe * se;
+                              t1[qe][qh] = (w27[q0] * na0 + w27[q0 + slo] * na1) + w27[q0 + 2 * slo] * na2;
+                            }
+#pragma unroll
+                        for (int be = 0; be < 2; ++be)
+                          {
+                            double t2[3];
+#pragma unroll
+                            for (int qe = 0; qe < 3; ++qe)
+                              t2[qe] = t1[qe][0] * g1_n(be, 0) + t1[qe][1] * g1_n(be, 1) + t1[qe][2] * g1_n(be, 2);
+                            const int bes = mb ? 1 - be : be;
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                              {
+                                const double val = t2[0] * g1_m(g, 0) + t2[1] * g1_m(g, 1) + t2[2] * g1_m(g, 2);
+                                const int gm = mz ? 2 - g : g;
+                                out[tab_off3(27 + p * 12 + al * 6 + bes * 3 + gm)] = mb ? -val : val;
+                              }
+                          }
+                      }
                   }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NIT; ++i)
-                  if (g + NG * i < NN3)
-                    vals[rb[i] + (c * STG + el)] = val[i];
-              }
-          }
-        else
-          {
-            // rows at the faces of the box / partial tiles / next to ghost columns: thread <-> (row, lattice offset o,
-            // column component); the CSR slot of offset o is its rank among the offsets that exist, or the row's
-            // permutation of that rank
-            constexpr int rowlen = 27 * NCOL;
-            for (int f = t; f < NN3 * rowlen; f += NT3)
-              {
-                const int nl = f / rowlen, e = f - nl * rowlen;
-                const int o = e / NCOL, d = e - o * NCOL;
-                const long long base = s_rowbase[nl];
-                const unsigned mask = s_mask[nl];
-                if (base < 0 || !((mask >> o) & 1u))
-                  continue;
-                int sl = __popc(mask & ((1u << o) - 1u));
-                const int deg = __popc(mask & 0x7ffffffu);
-                if (mask >> 31) // the row is not in lattice order (ghost columns behind the owned ones, bound pattern)
-                  sl = cv.row_perm[base / (NCOL * NCOL) + sl];
-                const double val = (d < 3) ? stage[nl * STG + o * 3 + d] : 0.0;
-                vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
-              }
-          }
-        if (prio & 4)
-          __builtin_amdgcn_s_setprio(0);
-      };
-
-      // RES: pressure part of the displacement residual, (alpha_B-1) p sum_q pfx^2 dN_a/dx_c JxW, from the A^c tables of
-      // the 8 cells around the node (slot set 0 visits exactly those): sum_q w g n_ai n_aj is the sum of the four moments
-      // A^c[a_i + b_i][a_j + b_j] (n_0 + n_1 = 1), and vol w pfx^2 = (w g - kappa vol w) / (1 - kappa)
-      if constexpr (RES)
-        {
-          if (wave == 0)
-            {
-              double pres[3] = {0.0, 0.0, 0.0};
-              const double kv4 = S.kappa * S.vol * 0.25;
-              static_for<4>([&](auto Vv) __attribute__((always_inline)) {
-                constexpr Vis vi = visit_of(0, decltype(Vv)::value);
-                constexpr int a[3] = {-vi.ex, -vi.ey, 1};
-                const double *cell = lane_base + (vi.ey * TROW3 + vi.ex);
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                  {
-                    const int i = (k == 0) ? 1 : 0, j = (k == 2) ? 1 : 2;
-                    const double s4 = (lds_read64(cell + tab_off3(idxA3(k, a[i], a[j]))) + lds_read64(cell + tab_off3(idxA3(k, a[i] + 1, a[j])))) +
-                                      (lds_read64(cell + tab_off3(idxA3(k, a[i], a[j] + 1))) + lds_read64(cell + tab_off3(idxA3(k, a[i] + 1, a[j] + 1))));
-                    const double mom = s4 - (s4 != 0.0 ? kv4 : 0.0); // absent cell: all tables are zero
-                    const bool neg = (k == 2) ? upper : (a[k] == 0);   // sign of dN_a/dx_k (upper layer: z-mirrored tables)
-                    pres[k] += neg ? -mom : mom;
-                  }
-              });
-              const double pc = S.aB1 * S.p / (1.0 - S.kappa);
-#pragma unroll
-              for (int k = 0; k < 3; ++k)
-                {
-                  const double pk = add_across_halves(pres[k]) * (pc * S.ih[k]);
-                  if (!upper)
-                    s_pres[RES ? k * NN3 + nl_lane : 0] = pk; // read behind the barrier of component 0 at the earliest
                 }
-            }
-        }
-      __builtin_amdgcn_sched_barrier(0); // the pressure part is finished before the table batch is requested
-      // the slot set of a wave is selected by scalar branches around the set-specific code only (table reads, the
-      // arithmetic of one row component); barriers and the copy-out are shared code (instruction cache: 8 sets x 3
-      // components x 2 mask variants of straight-line code)
-      double tv[4][9];
-      using std::integral_constant;
+            };
+            using std::integral_constant;
+            switch (wave)
+              {
+                case 0: family(integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+                case 1: family(integral_constant<int, 0>{}, integral_constant<int, 1>{}); break;
+                case 2: family(integral_constant<int, 1>{}, integral_constant<int, 0>{}); break;
+                case 3: family(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+                case 4: family(integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
+                case 5: family(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+                default: break;
+              }
+          }
+          lds_barrier();
+          stamp(2);
+
+          // ---- node phase + copy-out.  Every wave first reads the 36 table values of its slot set (4 visits x 9) in ONE
+          // batch and keeps them in registers for all three row components: 36 LDS reads per lane instead of 84, one
+          // latency instead of a chain of them, and the tables are dead afterwards -- their LDS becomes the second staging
+          // buffer, so that the copy-out of component c overlaps the arithmetic of component c + 1 (one barrier per
+          // component instead of two).
+          bool regular_tile;
+          {
+            UU_ENV();
+            const bool upper = lane >= 32;
+            const int nl_lane = lane & 31;
+            const int ti = nl_lane % T3X, tj = nl_lane / T3X;
+            const int hc2 = (ti + 1) + H3X * (tj + 1); // in-plane halo index of the node
+            // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
+            const double *lane_base = s_tab + (upper ? TLAY3 : 0) + (tj + 1) * TROW3 + (ti + 1);
+            const int lane_cs = (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1); // the same cell in [layer][cy][cx] order (s_lam, s_mu)
+            UuCoef K;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                  K.cA[c][kk] = S.cA[c][kk];
+                K.cTl[c] = S.cTl[c];
+                K.cTm[c] = S.cTm[c];
+                K.gA[c] = S.ih[c] * S.ih[c];
+                K.cT[c] = S.cT[c];
+              }
+            const bool masked = (sh.anyflag[0][0] | sh.anyflag[0][1] | sh.anyflag[1][0] | sh.anyflag[1][1] | sh.anyflag[2][0] | sh.anyflag[2][1]) != 0;
+            regular_tile = (NCOL == 3) && sh.irregular[par] == 0;
+            const int hc = s1 * NHP3 + hc2, hh = (upper ? s2 : s0) * NHP3 + hc2; // the node in its own plane / in the half's other plane
+            const unsigned row_flag = sh.flag[hc];
+            const unsigned char *flag_own = sh.flag + hc, *flag_half = sh.flag + hh;
+
+            auto copy_out = [&](int c, const double *__restrict__ stage) __attribute__((always_inline)) {
+              const long long *rowbase = sh.rowbase[par];
+              double *__restrict__ vals = A.vals;
+              if (regular_tile)
+                {
+                  // thread <-> (node group g, element el) with el fixed: nodes g, g + 6, ..., g + 30 -- no division per
+                  // position, one row-base read and one value read per node, all of them in flight before the first store (a
+                  // loop pays two dependent LDS round trips of ~130 cycles per iteration); threads 486..511 idle
+                  constexpr int NG = 6, NIT = (NN3 + NG - 1) / NG;
+                  int tq = t;
+                  asm volatile("" : "+v"(tq)); // (g, el) are recomputed per component, not kept live across the node phases
+                  const int g = tq / STG, el = tq - g * STG;
+                  if (g < NG)
+                    {
+                      long long rb[NIT];
+                      double val[NIT];
+#pragma unroll
+                      for (int i = 0; i < NIT; ++i)
+                        {
+                          const int nl = min(g + NG * i, NN3 - 1);
+                          rb[i] = rowbase[nl];
+                          val[i] = stage[nl * STG + el];
+                        }
+                      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                      for (int i = 0; i < NIT; ++i)
+                        if (g + NG * i < NN3)
+                          vals[rb[i] + (c * STG + el)] = val[i];
+                    }
+                }
+              else
+                {
+                  // rows at the faces of the box / partial tiles / next to ghost columns: thread <-> (row, lattice offset o,
+                  // column component); the CSR slot of offset o is its rank among the offsets that exist, or the row's
+                  // permutation of that rank
+                  const unsigned *rowmask = sh.mask[par];
+                  constexpr int rowlen = 27 * NCOL;
+                  for (int f = t; f < NN3 * rowlen; f += NT3)
+                    {
+                      const int nl = f / rowlen, e = f - nl * rowlen;
+                      const int o = e / NCOL, d = e - o * NCOL;
+                      const long long base = rowbase[nl];
+                      const unsigned mask = rowmask[nl];
+                      if (base < 0 || !((mask >> o) & 1u))
+                        continue;
+                      int sl = __popc(mask & ((1u << o) - 1u));
+                      const int deg = __popc(mask & 0x7ffffffu);
+                      if (mask >> 31) // the row is not in lattice order (ghost columns behind the owned ones, bound pattern)
+                        sl = cv.row_perm[base / (NCOL * NCOL) + sl];
+                      const double val = (d < 3) ? stage[nl * STG + o * 3 + d] : 0.0;
+                      vals[base + (long long)c * NCOL * deg + sl * NCOL + d] = val;
+                    }
+                }
+            };
+
+            // RES: pressure part of the displacement residual, (alpha_B-1) p sum_q pfx^2 dN_a/dx_c JxW, from the A^c tables of
+            // the 8 cells around the node (slot set 0 visits exactly those): sum_q w g n_ai n_aj is the sum of the four moments
+            // A^c[a_i + b_i][a_j + b_j] (n_0 + n_1 = 1), and vol w pfx^2 = (w g - kappa vol w) / (1 - kappa)
+            if constexpr (RES)
+              {
+                if (wave == 0)
+                  {
+                    double pres[3] = {0.0, 0.0, 0.0};
+                    const double kv4 = S.kappa * S.vol * 0.25;
+                    static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+                      constexpr Vis vi = visit_of(0, decltype(Vv)::value);
+                      constexpr int a[3] = {-vi.ex, -vi.ey, 1};
+                      const double *cell = lane_base + (vi.ey * TROW3 + vi.ex);
+#pragma unroll
+                      for (int kk = 0; kk < 3; ++kk)
+                        {
+                          const int i = (kk == 0) ? 1 : 0, j = (kk == 2) ? 1 : 2;
+                          const double s4 = (lds_read64(cell + tab_off3(idxA3(kk, a[i], a[j]))) + lds_read64(cell + tab_off3(idxA3(kk, a[i] + 1, a[j])))) +
+                                            (lds_read64(cell + tab_off3(idxA3(kk, a[i], a[j] + 1))) + lds_read64(cell + tab_off3(idxA3(kk, a[i] + 1, a[j] + 1))));
+                          const double mom = s4 - (s4 != 0.0 ? kv4 : 0.0); // absent cell: all tables are zero
+                          const bool neg = (kk == 2) ? upper : (a[kk] == 0); // sign of dN_a/dx_k (upper layer: z-mirrored tables)
+                          pres[kk] += neg ? -mom : mom;
+                        }
+                    });
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+                      {
+                        const double pk = add_across_halves(pres[kk]) * (S.pc_res * S.ih[kk]);
+                        if (!upper)
+                          s_pres[RES ? kk * NN3 + nl_lane : 0] = pk; // read behind the barrier of component 1 at the earliest
+                      }
+                  }
+              }
+            __builtin_amdgcn_sched_barrier(0); // the pressure part is finished before the table batch is requested
+            // the slot set of a wave is selected by scalar branches around the set-specific code only (table reads, the
+            // arithmetic of one row component); barriers and the copy-out are shared code (instruction cache: 8 sets x 3
+            // components x 2 mask variants of straight-line code)
+            double tv[4][9];
+            using std::integral_constant;
 #define PFM_PER_SET(STMT)                                                                                                    \
   switch (wave)                                                                                                              \
     {                                                                                                                        \
@@ -687,42 +861,31 @@ namespace pfm
       case 6: { constexpr int W = 6; STMT; } break;                                                                          \
       default: { constexpr int W = 7; STMT; } break;                                                                         \
     }
-      double lamv[4] = {0.0, 0.0, 0.0, 0.0}, muv[4] = {0.0, 0.0, 0.0, 0.0}; // HET: coefficients of the 4 visited cells
-      PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
-        constexpr int V = decltype(Vv)::value;
-        uu_load_visit<W, V>(lane_base, tv[V]);
-        if constexpr (HET)
-          {
-            constexpr Vis vi = visit_of(W, V);
-            const int cs = lane_cs + (vi.ey * C3X + vi.ex);
-            lamv[V] = s_lam[cs];
-            muv[V] = s_mu[cs];
-          }
-      }))
-      const double *u_own = s_u + (RES ? hc : 0), *u_half = s_u + (RES ? hc + (upper ? H3X * H3Y : -H3X * H3Y) : 0);
-      // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the table storage: written after the
-      // barrier of component 0, which every wave passes with its table values in registers
-      double *st0 = s_stage + nl_lane * STG, *st1 = s_tab + nl_lane * STG;
-      const int hs = upper ? 18 * 3 : 0;
-      double ku = 0.0;
-      // residual row of component c: sum of the 8 slot sets in a fixed order, constrained rows get 0 (cracks.cc:2440-2456)
-      auto residual_out = [&](int c) __attribute__((always_inline)) {
-        if constexpr (RES)
-          {
-            if (t < NN3 && s_rowbase[t] >= 0)
-              {
-                double sum = -s_pres[RES ? c * NN3 + t : 0];
-#pragma unroll
-                for (int w = 0; w < 8; ++w)
-                  sum += s_part[((c & 1) * 8 + w) * NN3 + t]; // component 2 reuses buffer 0 behind the barrier of component 1
-                const int li = t % T3X, lj = t / T3X;
-                const int row = s_resrow[RES ? t : 0];
-                const bool con = (s_flag[(li + 1) + H3X * ((lj + 1) + H3Y * 1)] >> c) & 1u;
-                const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + c : (long long)row * 3 + c;
-                res_pde[di] = con ? 0.0 : -sum;
-              }
-          }
-      };
+            double lamv[4] = {0.0, 0.0, 0.0, 0.0}, muv[4] = {0.0, 0.0, 0.0, 0.0}; // HET: coefficients of the 4 visited cells
+            PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+              constexpr int V = decltype(Vv)::value;
+              uu_load_visit<W, V, 3>(lane_base, tv[V]);
+              if constexpr (HET)
+                {
+                  constexpr Vis vi = visit_of(W, V);
+                  const int cs = lane_cs + (vi.ey * C3X + vi.ex);
+                  lamv[V] = sh.lam[HET ? cs : 0];
+                  muv[V] = sh.mu[HET ? cs : 0];
+                }
+            }))
+            const double *u_own = sh.u + (RES ? hc : 0), *u_half = sh.u + (RES ? hh : 0);
+            // buffer 0 = the w*g scratch (free since the moment phase), buffer 1 = the table storage: written after the
+            // barrier of component 0, which every wave passes with its table values in registers
+            double *st0 = s_stage + nl_lane * STG, *st1 = s_tab + nl_lane * STG;
+            const int hs = upper ? 18 * 3 : 0;
+            double ku = 0.0;
+            auto part_store = [&](int c) __attribute__((always_inline)) {
+              if constexpr (RES)
+                {
+                  if (!upper)
+                    s_part[((c & 1) * 8 + wave) * NN3 + nl_lane] = ku;
+                }
+            };
 #define PFM_COMPONENT(C, ST)                                                                                                 \
   if (masked)                                                                                                                \
     {                                                                                                                        \
@@ -733,28 +896,120 @@ namespace pfm
     {                                                                                                                        \
       PFM_PER_SET((ku = uu_row_component<W, C, false, HET, RES>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half, \
                                                                 u_own, u_half)))                                            \
-    }                                                                                                                        \
-  if (RES && !upper)                                                                                                         \
-    s_part[RES ? ((C & 1) * 8 + wave) * NN3 + nl_lane : 0] = ku;
-      PFM_COMPONENT(0, st0)
-      lds_barrier();
-      stamp(3);
-      copy_out(0, s_stage);
-      residual_out(0);
-      PFM_COMPONENT(1, st1)
-      lds_barrier();
-      stamp(4);
-      copy_out(1, s_tab);
-      residual_out(1);
-      PFM_COMPONENT(2, st0)
-      lds_barrier();
-      stamp(3);
-      copy_out(2, s_stage);
-      residual_out(2);
-      stamp(4);
+    }
+            PFM_COMPONENT(0, st0)
+            lds_barrier();
+            stamp(3);
+            PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+              uu_load_visit<W, decltype(Vv)::value, 4>(lane_base, tv[decltype(Vv)::value]); // T^yz, behind the copy-out
+            }))
+            part_store(0);
+            copy_out(0, s_stage);
+            PFM_COMPONENT(1, st1)
+            lds_barrier();
+            stamp(4);
+            PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
+              uu_load_visit<W, decltype(Vv)::value, 2>(lane_base, tv[decltype(Vv)::value]); // T^xz again
+            }))
+            residual_out(0, par, s1);
+            part_store(1);
+            copy_out(1, s_tab);
+            PFM_COMPONENT(2, st0)
+            lds_barrier();
+            stamp(5);
+            residual_out(1, par, s1);
+            part_store(2); // buffer 0 again: the reads of component 0 lie behind the last barrier
+            copy_out(2, s_stage);
 #undef PFM_COMPONENT
 #undef PFM_PER_SET
+          }
+          // ---- the requested plane k + 2 has had the whole step to arrive: into the ring slot of plane k - 1.  vmcnt counts
+          // loads and stores in order: waves 5..7 have issued at least 5 copy-out stores per row component behind their
+          // requests on a regular tile (their sixth position lies outside the tile), so vmcnt(15) waits for the requests
+          // and never for the stores of this step
+          if (more && wave >= 5)
+            {
+              if (regular_tile)
+                asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+              else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              UU_ENV();
+              const int kz = k + 2, kr = k + 1, slot = s0, parn = par ^ 1;
+              if (wave < 7)
+                {
+                  const int hn = 32 * (wave - 5) + lane;
+                  bool fl = false;
+                  if (lane < 32 && hn < NHP3)
+                    {
+                      const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
+                      const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
+                      double a = 0.0, b = 0.0;
+                      unsigned f = 0;
+                      if (in)
+                        {
+                          a = sh.raw_po[hn];
+                          b = sh.raw_poo[hn];
+                          f = sh.raw_flag[2 * hn];
+                          if (!S.monolithic)
+                            a = S.use_old ? a : b + S.tfac * (a - b);
+                        }
+                      const int d = slot * NHP3 + hn;
+                      if constexpr (RES)
+                        {
+#pragma unroll
+                          for (int c = 0; c < 3; ++c)
+                            sh.u[(RES ? c * NH3 : 0) + d] = in ? sh.raw_u[RES ? c : 0][hn] : 0.0;
+                        }
+                      else
+                        sh.poo[RES ? 0 : d] = b;
+                      sh.po[d] = a;
+                      sh.ok[d] = in;
+                      sh.flag[d] = (unsigned char)f;
+                      fl = (f & 7u) != 0;
+                    }
+                  const unsigned long long any = __ballot(fl);
+                  if (lane == 0)
+                    sh.anyflag[slot][wave - 5] = any != 0;
+                }
+              else
+                {
+                  unsigned mask = 0x7ffffffu;
+                  if (lane < NN3)
+                    {
+                      const int li = lane % T3X, lj = lane / T3X;
+                      const int gi = i0 + li, gj = j0 + lj;
+                      long long base = -1;
+                      mask = 0u;
+                      if (gi <= cv.o1[0] && gj <= cv.o1[1])
+                        {
+                          base = (long long)NCOL * NCOL * sh.raw_row[lane];
+                          mask = sh.raw_mask[2 * lane];
+                          if constexpr (RES)
+                            sh.resrow[parn][lane] = cart_local_id(cv, gi, gj, kr);
+                        }
+                      sh.rowbase[parn][lane] = base;
+                      sh.mask[parn][lane] = mask;
+                    }
+                  const unsigned long long irr = __ballot(mask != 0x7ffffffu);
+                  if (lane == 0)
+                    sh.irregular[parn] = irr != 0;
+                }
+            }
+          stamp(6);
+        }
+      if constexpr (RES)
+        {
+          lds_barrier();
+          residual_out(2, (it - 1) & 1, it % 3); // the last plane k = kB - 1: parity (it - 1) & 1, ring slot ((it - 1) + 1) % 3
+        }
+      if constexpr (CLK)
+        {
+          if (threadIdx.x == 0)
+            for (int i = 0; i < 8; ++i)
+              uu_args().dbg[(size_t)blockIdx.x * 8 + i] = acc[i];
+        }
     }
+#undef UU_ENV
   } // namespace
 
   int launch_cart_uu3(const DevView &v, const CartView &cv, const pfm_params &p, double *vals_uu, hipStream_t s,
@@ -768,12 +1023,17 @@ namespace pfm
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr;
-    const unsigned nb = listed ? (unsigned)cv.n_bnd_uu3 : (unsigned)(ntx * nty * OWZ);
+    // planes per workgroup: the interior / boundary launches of an overlapped assembly select tiles plane by plane (zc = 1:
+    // every plane through the prologue's register loads, as in rounds 1-4); otherwise chunks that fill the dispatch rounds
+    static const int zc_force = getenv("PFM_UU_ZC") ? atoi(getenv("PFM_UU_ZC")) : 0; // tuning only
+    const int zc = cv.tile_sel != 0 ? 1 : (zc_force > 0 ? std::min(zc_force, OWZ) : choose_zchunk((long long)ntx * nty, OWZ, 8, 48, 2));
+    const int nch = (OWZ + zc - 1) / zc;
+    const unsigned nb = listed ? (unsigned)cv.n_bnd_uu3 : (unsigned)(ntx * nty * nch);
     if (nb == 0)
       return PFM_OK;
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
-    static const int prio = getenv("PFM_UU_PRIO") ? atoi(getenv("PFM_UU_PRIO")) : 0; // bit 0: halo loads, 1: w*g, 2: copy-out
+    UuArgs ka{v, cv, S, vals_uu, nullptr, res_pde, zc};
     // dynamic LDS on top of the kernel's own: the pair launch asks for the allocation of the phase-field kernel
     auto own_lds = [](const void *fn) {
       hipFuncAttributes at{};
@@ -784,55 +1044,58 @@ namespace pfm
     {                                                                                                                        \
       static const int own = own_lds(reinterpret_cast<const void *>(&k_cart_uu3<NC, false, HETV, RESV>));                    \
       const int pad = lds_total > 0 ? std::max(0, lds_total - own) : 0;                                                      \
-      hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, pad, s, v, cv, S, vals_uu, nullptr, res_pde, prio); \
+      hipLaunchKernelGGL((k_cart_uu3<NC, false, HETV, RESV>), grid, block, pad, s, ka);                                      \
     }                                                                                                                        \
   while (0)
     if (getenv("PFM_UU_CLK") && !il && !het) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
+        static size_t nd_cap = 0;
         const size_t nd = (size_t)xcd_grid(nb) * 8;
-        if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
-          return PFM_ERR_HIP;
+        if (nd > nd_cap)
+          {
+            if (d_dbg)
+              (void)hipFree(d_dbg);
+            if (hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
+              return PFM_ERR_HIP;
+            nd_cap = nd;
+          }
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
+        ka.dbg = d_dbg;
         if (res)
-          hipLaunchKernelGGL((k_cart_uu3<3, true, false, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, res_pde, prio);
+          hipLaunchKernelGGL((k_cart_uu3<3, true, false, true>), grid, block, 0, s, ka);
         else
-          hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, v, cv, S, vals_uu, d_dbg, nullptr, prio);
+          hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, ka);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         unsigned long long h[8] = {};
         for (size_t i = 0; i < nd; ++i)
           h[i % 8] += hall[i];
-        const char *names[6] = {"phase0: wait at the barrier", "w*g", "moments", "load+node c0,c2 (+copy c1)", "copy c0,c2 + node c1",
-                                "phase0: own loads -> LDS"};
-        fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per tile]");
-        for (int i = 0; i < 6; ++i)
-          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / nb);
+        const char *names[8] = {"top barrier", "w*g", "moments", "tables+node c0", "copy c0+node c1", "copy c1+node c2",
+                                "copy c2+landing", "prologue loads (per chunk)"};
+        const double planes = (double)ntx * nty * OWZ;
+        fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per plane; zc=%d]", zc);
+        for (int i = 0; i < 8; ++i)
+          fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / (i == 7 ? (double)nb : planes));
         fprintf(stderr, "\n");
       }
     else if (il)
       {
         if (het)
           PFM_UU3(4, true, false); // heterogeneous material: the residual kernel runs
+        else if (res)
+          PFM_UU3(4, false, true);
         else
-          {
-            if (res)
-              PFM_UU3(4, false, true);
-            else
-              PFM_UU3(4, false, false);
-          }
+          PFM_UU3(4, false, false);
       }
     else
       {
         if (het)
           PFM_UU3(3, true, false); // heterogeneous material: the residual kernel runs
+        else if (res)
+          PFM_UU3(3, false, true);
         else
-          {
-            if (res)
-              PFM_UU3(3, false, true);
-            else
-              PFM_UU3(3, false, false);
-          }
+          PFM_UU3(3, false, false);
       }
 #undef PFM_UU3
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
