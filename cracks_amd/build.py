@@ -16,6 +16,12 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libpfm_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+# Per-source flags.  The marching kernels run their phases inside a plane loop with a 128-register budget: LLVM's
+# machine-level loop-invariant code motion hoists constant materialisations and address arithmetic in front of the
+# loop and keeps -- or spills -- them across every phase (k_cart_uu3: 128 registers + spills with it, 116 without).
+EXTRA_FLAGS = {
+    "pfm_cart_uu3.hip": ["-mllvm", "-disable-machine-licm"],
+}
 
 
 def hipcc() -> str:
@@ -58,7 +64,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, s + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            jobs.append([cc] + FLAGS + ["-I" + os.path.join(rocm, "include"), "-x", "hip", "-c", src, "-o", obj])
+            jobs.append([cc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-I" + os.path.join(rocm, "include"), "-x", "hip", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

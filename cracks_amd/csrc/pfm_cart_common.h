@@ -32,6 +32,19 @@ namespace pfm
       return cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
     }
 
+    // The same with the look-up WAITED FOR INSIDE ITS ARM.  A load whose result is defined in one arm of a branch is waited
+    // for at the join with s_waitcnt vmcnt(0), on every path -- and vmcnt counts stores: in a wave that streams rows out,
+    // or that has global -> LDS transfers in flight, that is a wait for all of them (k_cart_uu3, round 5: 3600 cycles per
+    // plane in the wave that requests the next rows, although every id was arithmetic)
+    __device__ __forceinline__ int cart_local_id_sync(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.owned_lex && i >= cv.o0[0] && i <= cv.o1[0] && j >= cv.o0[1] && j <= cv.o1[1] && k >= cv.o0[2] && k <= cv.o1[2])
+        return (i - cv.o0[0]) + (cv.o1[0] - cv.o0[0] + 1) * ((j - cv.o0[1]) + (cv.o1[1] - cv.o0[1] + 1) * (k - cv.o0[2]));
+      int id = cv.local_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+      asm volatile("" : "+v"(id));
+      return id;
+    }
+
     // x += v on an LDS double, done by the LDS unit (ds_add_f64, no return value): one LDS instruction and no
     // read -> wait -> add -> write round trip.  Used where a wave's lanes hit distinct addresses and the order of
     // the adds is the program order of that wave, so the result is the same as a plain read-modify-write.

@@ -36,6 +36,8 @@ namespace pfm
   namespace
   {
     constexpr int NNUM3 = 63;
+    constexpr int NHP3 = H3X * H3Y; // 60 nodes per halo plane
+    constexpr int NR3 = 4 * NHP3;   // ring of four nodal planes in LDS (k_cart_uu3)
     // Table storage: tables in groups of eight, a cell ROW of a group = 8 tables x 9 cells = 72 doubles, i.e. the
     // four tile rows of a half-wave (row stride 72 = 8 mod 32 doubles, 8 lanes each) tile the 32 double-banks of a
     // ds_read_b64 lane group exactly: every table read of the node phase is conflict-free (round 5; with the
@@ -235,7 +237,7 @@ namespace pfm
             if constexpr (RES)
               {
                 const double *un = (vi.oz == 0 ? u_own : u_half) + (vi.ox + H3X * vi.oy);
-                const double part = fma(v2, un[2 * NH3], fma(v1, un[NH3], v0 * un[0]));
+                const double part = fma(v2, un[2 * NR3], fma(v1, un[NR3], v0 * un[0]));
                 if constexpr (vi.oz == 0)
                   dot_plane += part; // the same value in both halves
                 else
@@ -279,13 +281,12 @@ namespace pfm
     // 8k of a tile's 25k cycles) fully exposed: with one tile per workgroup nothing else of that workgroup can run.
     //   vmcnt counts loads and stores in order, so the wait for the transfers of a step is vmcnt(#stores the wave has
     //   issued behind them) -- 18 on a regular tile (6 per row component) -- and never drains the copy-out.
-    constexpr int NHP3 = H3X * H3Y; // 60 nodes per halo plane
 
     template <bool HET, bool RES>
     struct UuShared
     {
       // landing zone of the requests for the NEXT plane (M0 addresses the first 64 KB of the workgroup's LDS: keep first)
-      double raw_po[64], raw_poo[64];  // [hn]: dwords 2 hn, 2 hn + 1 fetched by lanes 2 (hn % 32), 2 (hn % 32) + 1 of wave 5 + hn / 32
+      double raw_po[64], raw_poo[64];  // [hn]: dwords 2 hn, 2 hn + 1 fetched by lanes 2 (hn % 32), 2 (hn % 32) + 1 of wave 6 + hn / 32
       double raw_u[RES ? 3 : 1][64];
       unsigned raw_flag[128];          // [2 hn]: the node's flag byte, zero-extended
       long long raw_row[NN3];          // nadj_ptr of the next plane's rows (wave 7)
@@ -294,15 +295,15 @@ namespace pfm
                                        // its table values: [0, NN3 STG) = second staging buffer, behind it the partial sums of
                                        // the residual rows (RES)
       double stage[NN3 * STG];         // staged rows [node][81]; w*g(q) [27][90] during the cell phase
-      double po[NH3], poo[RES ? 1 : NH3]; // ring: plane p in slot (p - (kA - 1)) % 3.  RES => staggered: one combined field
-      double u[RES ? 3 * NH3 : 1];     // displacements of the halo nodes [component][slot][node]
+      double po[NR3], poo[RES ? 1 : NR3]; // ring: plane p in slot (p - (kA - 1)) % 4.  RES => staggered: one combined field
+      double u[RES ? 3 * NR3 : 1];     // displacements of the halo nodes [component][slot][node]
       double lam[HET ? CS3 : 1], mu[HET ? CS3 : 1];
       long long rowbase[2][NN3];       // by plane parity: written for plane k + 1 while the copy-out of plane k reads its own
       unsigned mask[2][NN3];
       int resrow[2][RES ? NN3 : 1];
       double pres[RES ? 3 * NN3 : 1]; // pressure part of the residual rows of the current plane [component][node]
-      unsigned char ok[NH3], flag[NH3];
-      int anyflag[3][2];               // per ring slot and request wave: some node of the plane carries a displacement flag
+      unsigned char ok[NR3], flag[NR3];
+      int anyflag[4][2];               // per ring slot and request wave: some node of the plane carries a displacement flag
       int irregular[2];                // by plane parity: some row is not a full, lattice-ordered 27-neighbour row
     };
     static_assert(27 * CS3 <= NN3 * STG, "w*g scratch must fit in the staging buffer");
@@ -318,7 +319,7 @@ namespace pfm
     {
       DevView v;
       CartView cv;
-      const MatScal *Sp; // per-launch scalars in device memory (see pfm_internal.h)
+      MatScal S; // per-launch scalars, by value: one scalar load from the argument segment, not two dependent ones
       double *vals;
       unsigned long long *dbg;
       double *res_pde;
@@ -327,14 +328,13 @@ namespace pfm
     __device__ __forceinline__ const UuArgs &uu_args()
     {
       auto p = __builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(p));
       return *(const UuArgs *)p;
     }
 #define UU_ENV()                                                                                                             \
   const UuArgs &A = uu_args();                                                                                               \
   const DevView &v = A.v;                                                                                                    \
   const CartView &cv = A.cv;                                                                                                 \
-  const __attribute__((address_space(4))) MatScal &S = *(const __attribute__((address_space(4))) MatScal *)A.Sp;          \
+  const MatScal &S = A.S;                                                                                                    \
   int t = threadIdx.x;                                                                                                       \
   asm volatile("" : "+v"(t));                                                                                                \
   const int lane = t & 63;                                                                                                   \
@@ -351,6 +351,17 @@ namespace pfm
       (void)args_in_kernarg_segment;
       long long tclk = 0;
       unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long acc6[4] = {0, 0, 0, 0}; // wave 6: wait for the requests, landing, requests, -
+      long long tclk6 = 0;
+      auto stamp6 = [&](int phase) __attribute__((always_inline)) {
+        if constexpr (CLK)
+          {
+            const long long now = clock64();
+            if (phase >= 0)
+              acc6[phase] += (unsigned long long)(now - tclk6);
+            tclk6 = now;
+          }
+      };
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
           {
@@ -392,10 +403,10 @@ namespace pfm
                                                  cart_range_has_ghost(cv, 2, kA - 1, kA + 1)))
           return; // overlapped assembly (zc == 1): the other launch owns this tile
 
-        // ---- prologue: nodal planes kA - 1 .. kA + 1 and the row info of plane kA through registers (one exposed round
+        // ---- prologue: nodal planes kA - 1 .. kA + 2 and the row info of plane kA through registers (one exposed round
         // trip per chunk)
         stamp(0);
-        if (t < NH3)
+        if (t < NR3)
           {
             const int li = t % H3X, lj = (t / H3X) % H3Y, lk = t / NHP3;
             const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = kA - 1 + lk;
@@ -420,19 +431,19 @@ namespace pfm
             if constexpr (RES)
               {
                 sh.u[t] = uu[0];
-                sh.u[(RES ? NH3 : 0) + t] = uu[1];
-                sh.u[(RES ? 2 * NH3 : 0) + t] = uu[2];
+                sh.u[(RES ? NR3 : 0) + t] = uu[1];
+                sh.u[(RES ? 2 * NR3 : 0) + t] = uu[2];
               }
             else
               sh.poo[RES ? 0 : t] = b;
             sh.ok[t] = in;
             sh.po[t] = a;
             sh.flag[t] = f;
-            // flags of the three planes, per plane and per wave that holds a part of it (plane q = threads [60 q, 60 q + 60):
-            // wave 0 | waves 0, 1 | waves 1, 2): no atomics, no init barrier
+            // flags of the four planes, per plane and per wave that holds a part of it (plane q = threads [60 q, 60 q + 60):
+            // wave 0 | waves 0, 1 | waves 1, 2 | waves 2, 3): no atomics, no init barrier
             const int lk_ = t / NHP3;
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < 4; ++q)
               {
                 const unsigned long long any = __ballot((f & 7u) != 0 && lk_ == q);
                 const int w_first = (q * NHP3) >> 6, w_last = (q * NHP3 + NHP3 - 1) >> 6;
@@ -488,13 +499,14 @@ namespace pfm
       };
 
       int it = 0;
+      bool regular_prev = false; // the last step's copy-out took the regular path (its store count is known)
 #pragma unroll 1
       for (int k = kA; k < kB; ++k, ++it)
         {
-          // ring slots of the planes k - 1, k, k + 1
-          const int s0 = it % 3, s1 = (it + 1) % 3, s2 = (it + 2) % 3, par = it & 1;
+          // ring slots of the planes k - 1, k, k + 1 and of plane k + 2 (landing in this step: the slot of plane k - 2)
+          const int s0 = it & 3, s1 = (it + 1) & 3, s2 = (it + 2) & 3, s3 = (it + 3) & 3, par = it & 1;
           const bool more = k + 1 < kB;
-          lds_barrier(); // (first plane: the prologue's planes; later: the landed plane, the last plane's residual sums)
+          lds_barrier(); // (first plane: the prologue's planes; later: the last plane's staged rows and residual sums)
           stamp(0);
           if (it > 0)
             residual_out(2, par ^ 1, s0); // component 2 of the PREVIOUS plane: its sums were stored behind its last barrier
@@ -516,46 +528,102 @@ namespace pfm
                   sh.mu[HET ? cs : 0] = mu;
                 }
             }
-          // ---- requests for plane k + 2 (waves 5, 6: nodes [32 (wave - 5), +32) of the halo plane) and the rows of plane
-          // k + 1 (wave 7): global -> LDS, no registers; these three waves have no part in the w*g phase
-          if (more && wave >= 5)
+          // ---- waves 5..7 have no part in the w*g phase, waves 6, 7 none in the moment phase either.  During w*g they LAND what
+          // they requested one step ago: waves 6, 7 plane k + 2 (nodes [32 (wave - 6), +32) of the plane) into the ring slot
+          // of plane k - 2 -- their requests for plane k + 3 follow in the moment phase --, wave 5 the rows of plane k, and
+          // requests those of plane k + 1 at once.  vmcnt counts loads and stores in order: since their requests these waves
+          // have issued exactly 5 copy-out stores per row component on a regular tile (their sixth position lies outside the
+          // tile), so vmcnt(15) waits for the requests and never for the stores of the last step
+          if (wave >= 5)
             {
               UU_ENV();
-              if (wave < 7)
+              if (it > 0)
+                {
+                  stamp6(-1);
+                  if (regular_prev)
+                    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                  else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  stamp6(0);
+                }
+              if (wave >= 6 && it > 0 && more)
                 {
                   const int kz = k + 2;
-                  const int hn = 32 * (wave - 5) + (lane >> 1);
-                  const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
-                  const bool in = hn < NHP3 && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
-                  unsigned n = in ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
-                  asm volatile("" : "+v"(n)); // a looked-up id (ghost layers) is waited for HERE, in front of the requests
-                  if (in)
+                  const int hn = 32 * (wave - 6) + lane;
+                  bool fl = false;
+                  if (lane < 32 && hn < NHP3)
                     {
-                      const unsigned boff = 8u * n + 4u * (lane & 1);
-                      dma_b32(v.phi_old, boff, reinterpret_cast<uint32_t *>(sh.raw_po) + 64 * (wave - 5));
-                      dma_b32(v.phi_oldold, boff, reinterpret_cast<uint32_t *>(sh.raw_poo) + 64 * (wave - 5));
+                      const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
+                      const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
+                      double a = 0.0, b = 0.0;
+                      unsigned f = 0;
+                      if (in)
+                        {
+                          a = sh.raw_po[hn];
+                          b = sh.raw_poo[hn];
+                          f = sh.raw_flag[2 * hn];
+                          if (!S.monolithic)
+                            a = S.use_old ? a : b + S.tfac * (a - b);
+                        }
+                      const int d = s3 * NHP3 + hn;
                       if constexpr (RES)
                         {
 #pragma unroll
                           for (int c = 0; c < 3; ++c)
-                            dma_b32(v.u[c], boff, reinterpret_cast<uint32_t *>(sh.raw_u[RES ? c : 0]) + 64 * (wave - 5));
+                            sh.u[(RES ? c * NR3 : 0) + d] = in ? sh.raw_u[RES ? c : 0][hn] : 0.0;
                         }
-                      dma_u8(v.node_flags, n, sh.raw_flag + 64 * (wave - 5));
+                      else
+                        sh.poo[RES ? 0 : d] = b;
+                      sh.po[d] = a;
+                      sh.ok[d] = in;
+                      sh.flag[d] = (unsigned char)f;
+                      fl = (f & 7u) != 0;
                     }
+                  const unsigned long long any = __ballot(fl);
+                  if (lane == 0)
+                    sh.anyflag[s3][wave - 6] = any != 0;
                 }
-              else
+              if (wave == 5)
                 {
-                  const int nl = lane >> 1, li = nl % T3X, lj = nl / T3X;
-                  const int gi = i0 + li, gj = j0 + lj;
-                  const bool in = gi <= cv.o1[0] && gj <= cv.o1[1];
-                  unsigned r = in ? (unsigned)cart_local_id(cv, gi, gj, k + 1) : 0u;
-                  asm volatile("" : "+v"(r));
-                  if (in)
+                  if (it > 0)
                     {
-                      dma_b32(v.nadj_ptr, 8u * r + 4u * (lane & 1), reinterpret_cast<uint32_t *>(sh.raw_row));
-                      dma_b32(cv.nbr_mask, 4u * r, sh.raw_mask);
+                      unsigned mask = 0x7ffffffu;
+                      if (lane < NN3)
+                        {
+                          const int li = lane % T3X, lj = lane / T3X;
+                          const int gi = i0 + li, gj = j0 + lj;
+                          long long base = -1;
+                          mask = 0u;
+                          if (gi <= cv.o1[0] && gj <= cv.o1[1])
+                            {
+                              base = (long long)NCOL * NCOL * sh.raw_row[lane];
+                              mask = sh.raw_mask[2 * lane];
+                              if constexpr (RES)
+                                sh.resrow[par][lane] = cart_local_id_sync(cv, gi, gj, k);
+                            }
+                          sh.rowbase[par][lane] = base;
+                          sh.mask[par][lane] = mask;
+                        }
+                      const unsigned long long irr = __ballot(mask != 0x7ffffffu);
+                      if (lane == 0)
+                        sh.irregular[par] = irr != 0;
+                      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the landing zone is read out before it is requested into again
+                    }
+                  if (more)
+                    {
+                      const int nl = lane >> 1, li = nl % T3X, lj = nl / T3X;
+                      const int gi = i0 + li, gj = j0 + lj;
+                      const bool in = gi <= cv.o1[0] && gj <= cv.o1[1];
+                      const unsigned r = in ? (unsigned)cart_local_id_sync(cv, gi, gj, k + 1) : 0u;
+                      if (in)
+                        {
+                          dma_b32(v.nadj_ptr, 8u * r + 4u * (lane & 1), reinterpret_cast<uint32_t *>(sh.raw_row));
+                          dma_b32(cv.nbr_mask, 4u * r, sh.raw_mask);
+                        }
                     }
                 }
+              if (it > 0)
+                stamp6(1);
             }
 
           // ---- cell phase a: w*g at the quadrature points, thread <-> (cell, z-level) -> LDS [q][cell]
@@ -567,41 +635,39 @@ namespace pfm
                 const int l = cs / CL3, cy = (cs % CL3) / C3X, cx = cs % C3X;
                 const int hq = cx + H3X * cy;
                 const int pa = (l ? s1 : s0) * NHP3 + hq, pb = (l ? s2 : s1) * NHP3 + hq; // lower / upper nodal plane of the layer
+                // all reads of the cell in one batch (the two validity bytes next to the nodal values: one LDS round trip);
+                // a cell outside the mesh reads zeros and is zeroed
                 const bool valid = sh.ok[pa] && sh.ok[pb + 1 + H3X];
                 double wg[9];
-                if (valid)
-                  {
-                    double po[8], poo[8];
-                    if (!S.monolithic)
-                      {
+                {
+                  double po[8], poo[8];
+                  if (!S.monolithic)
+                    {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                          {
-                            po[b] = sh.po[pa + (b & 1) + H3X * ((b >> 1) & 1)];
-                            po[b + 4] = sh.po[pb + (b & 1) + H3X * ((b >> 1) & 1)];
-                          }
-                        cell_wg_plane_lin<true>(po, S, qz, wg);
-                      }
-                    else
-                      {
+                      for (int b = 0; b < 4; ++b)
+                        {
+                          po[b] = sh.po[pa + (b & 1) + H3X * ((b >> 1) & 1)];
+                          po[b + 4] = sh.po[pb + (b & 1) + H3X * ((b >> 1) & 1)];
+                        }
+                      cell_wg_plane_lin<true>(po, S, qz, wg);
+                    }
+                  else
+                    {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                          {
-                            const int ha = pa + (b & 1) + H3X * ((b >> 1) & 1), hb = pb + (b & 1) + H3X * ((b >> 1) & 1);
-                            po[b] = sh.po[ha];
-                            po[b + 4] = sh.po[hb];
-                            poo[b] = sh.poo[RES ? 0 : ha];
-                            poo[b + 4] = sh.poo[RES ? 0 : hb];
-                          }
-                        cell_wg_plane<true>(po, poo, S, qz, wg);
-                      }
-                  }
-                else
-                  {
+                      for (int b = 0; b < 4; ++b)
+                        {
+                          const int ha = pa + (b & 1) + H3X * ((b >> 1) & 1), hb = pb + (b & 1) + H3X * ((b >> 1) & 1);
+                          po[b] = sh.po[ha];
+                          po[b + 4] = sh.po[hb];
+                          poo[b] = sh.poo[RES ? 0 : ha];
+                          poo[b + 4] = sh.poo[RES ? 0 : hb];
+                        }
+                      cell_wg_plane<true>(po, poo, S, qz, wg);
+                    }
+                }
 #pragma unroll
-                    for (int q = 0; q < 9; ++q)
-                      wg[q] = 0.0;
-                  }
+                for (int q = 0; q < 9; ++q)
+                  wg[q] = valid ? wg[q] : 0.0;
 #pragma unroll
                 for (int q = 0; q < 9; ++q)
                   s_stage[(qz * 9 + q) * CS3 + cs] = wg[q];
@@ -716,7 +782,52 @@ namespace pfm
                 case 3: family(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
                 case 4: family(integral_constant<int, 2>{}, integral_constant<int, 0>{}); break;
                 case 5: family(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
-                default: break;
+                default:
+                  // waves 6, 7 REQUEST plane k + 3 (the upper plane of step k + 2): global -> LDS, no registers; the landing zone
+                  // was read out in the w*g phase
+                  {
+                    stamp6(-1);
+                    if (k + 2 < kB)
+                      {
+                        const int kz = k + 3;
+                        const int hn = 32 * (wave - 6) + (lane >> 1);
+                        const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
+                        const bool in = hn < NHP3 && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
+                        const unsigned n = in ? (unsigned)cart_local_id_sync(cv, gi, gj, kz) : 0u; // (a looked-up id is waited for in its arm)
+                        if (in)
+                          {
+                            const unsigned boff = 8u * n + 4u * (lane & 1);
+                            dma_b32(v.phi_old, boff, reinterpret_cast<uint32_t *>(sh.raw_po) + 64 * (wave - 6));
+                            dma_b32(v.phi_oldold, boff, reinterpret_cast<uint32_t *>(sh.raw_poo) + 64 * (wave - 6));
+                            if constexpr (RES)
+                              {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                  dma_b32(v.u[c], boff, reinterpret_cast<uint32_t *>(sh.raw_u[RES ? c : 0]) + 64 * (wave - 6));
+                              }
+                            dma_u8(v.node_flags, n, sh.raw_flag + 64 * (wave - 6));
+                          }
+                      }
+                    stamp6(2);
+                  }
+                  break;
+              }
+          }
+          // the uniform constants of the node phase: requested in front of the barrier, so that the scalar loads are under way
+          // while the wave waits for the others
+          UuCoef K;
+          {
+            UU_ENV();
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              {
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+                  K.cA[c][kk] = S.cA[c][kk];
+                K.cTl[c] = S.cTl[c];
+                K.cTm[c] = S.cTm[c];
+                K.gA[c] = S.ih[c] * S.ih[c];
+                K.cT[c] = S.cT[c];
               }
           }
           lds_barrier();
@@ -737,19 +848,7 @@ namespace pfm
             // the cell "below-left" of the node in its layer: lower half -> layer 0, upper half -> layer 1 (mirrored tables)
             const double *lane_base = s_tab + (upper ? TLAY3 : 0) + (tj + 1) * TROW3 + (ti + 1);
             const int lane_cs = (upper ? CL3 : 0) + (tj + 1) * C3X + (ti + 1); // the same cell in [layer][cy][cx] order (s_lam, s_mu)
-            UuCoef K;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              {
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk)
-                  K.cA[c][kk] = S.cA[c][kk];
-                K.cTl[c] = S.cTl[c];
-                K.cTm[c] = S.cTm[c];
-                K.gA[c] = S.ih[c] * S.ih[c];
-                K.cT[c] = S.cT[c];
-              }
-            const bool masked = (sh.anyflag[0][0] | sh.anyflag[0][1] | sh.anyflag[1][0] | sh.anyflag[1][1] | sh.anyflag[2][0] | sh.anyflag[2][1]) != 0;
+            const bool masked = (sh.anyflag[s0][0] | sh.anyflag[s0][1] | sh.anyflag[s1][0] | sh.anyflag[s1][1] | sh.anyflag[s2][0] | sh.anyflag[s2][1]) != 0;
             regular_tile = (NCOL == 3) && sh.irregular[par] == 0;
             const int hc = s1 * NHP3 + hc2, hh = (upper ? s2 : s0) * NHP3 + hc2; // the node in its own plane / in the half's other plane
             const unsigned row_flag = sh.flag[hc];
@@ -923,90 +1022,22 @@ namespace pfm
 #undef PFM_COMPONENT
 #undef PFM_PER_SET
           }
-          // ---- the requested plane k + 2 has had the whole step to arrive: into the ring slot of plane k - 1.  vmcnt counts
-          // loads and stores in order: waves 5..7 have issued at least 5 copy-out stores per row component behind their
-          // requests on a regular tile (their sixth position lies outside the tile), so vmcnt(15) waits for the requests
-          // and never for the stores of this step
-          if (more && wave >= 5)
-            {
-              if (regular_tile)
-                asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-              else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              UU_ENV();
-              const int kz = k + 2, kr = k + 1, slot = s0, parn = par ^ 1;
-              if (wave < 7)
-                {
-                  const int hn = 32 * (wave - 5) + lane;
-                  bool fl = false;
-                  if (lane < 32 && hn < NHP3)
-                    {
-                      const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
-                      const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
-                      double a = 0.0, b = 0.0;
-                      unsigned f = 0;
-                      if (in)
-                        {
-                          a = sh.raw_po[hn];
-                          b = sh.raw_poo[hn];
-                          f = sh.raw_flag[2 * hn];
-                          if (!S.monolithic)
-                            a = S.use_old ? a : b + S.tfac * (a - b);
-                        }
-                      const int d = slot * NHP3 + hn;
-                      if constexpr (RES)
-                        {
-#pragma unroll
-                          for (int c = 0; c < 3; ++c)
-                            sh.u[(RES ? c * NH3 : 0) + d] = in ? sh.raw_u[RES ? c : 0][hn] : 0.0;
-                        }
-                      else
-                        sh.poo[RES ? 0 : d] = b;
-                      sh.po[d] = a;
-                      sh.ok[d] = in;
-                      sh.flag[d] = (unsigned char)f;
-                      fl = (f & 7u) != 0;
-                    }
-                  const unsigned long long any = __ballot(fl);
-                  if (lane == 0)
-                    sh.anyflag[slot][wave - 5] = any != 0;
-                }
-              else
-                {
-                  unsigned mask = 0x7ffffffu;
-                  if (lane < NN3)
-                    {
-                      const int li = lane % T3X, lj = lane / T3X;
-                      const int gi = i0 + li, gj = j0 + lj;
-                      long long base = -1;
-                      mask = 0u;
-                      if (gi <= cv.o1[0] && gj <= cv.o1[1])
-                        {
-                          base = (long long)NCOL * NCOL * sh.raw_row[lane];
-                          mask = sh.raw_mask[2 * lane];
-                          if constexpr (RES)
-                            sh.resrow[parn][lane] = cart_local_id(cv, gi, gj, kr);
-                        }
-                      sh.rowbase[parn][lane] = base;
-                      sh.mask[parn][lane] = mask;
-                    }
-                  const unsigned long long irr = __ballot(mask != 0x7ffffffu);
-                  if (lane == 0)
-                    sh.irregular[parn] = irr != 0;
-                }
-            }
+          regular_prev = regular_tile;
           stamp(6);
         }
       if constexpr (RES)
         {
           lds_barrier();
-          residual_out(2, (it - 1) & 1, it % 3); // the last plane k = kB - 1: parity (it - 1) & 1, ring slot ((it - 1) + 1) % 3
+          residual_out(2, (it - 1) & 1, it & 3); // the last plane k = kB - 1: parity (it - 1) & 1, ring slot ((it - 1) + 1) & 3
         }
       if constexpr (CLK)
         {
           if (threadIdx.x == 0)
             for (int i = 0; i < 8; ++i)
-              uu_args().dbg[(size_t)blockIdx.x * 8 + i] = acc[i];
+              uu_args().dbg[(size_t)blockIdx.x * 16 + i] = acc[i];
+          if (threadIdx.x == 448)
+            for (int i = 0; i < 4; ++i)
+              uu_args().dbg[(size_t)blockIdx.x * 16 + 8 + i] = acc6[i];
         }
     }
 #undef UU_ENV
@@ -1018,8 +1049,7 @@ namespace pfm
     int rc = ensure_g1();
     if (rc)
       return rc;
-    (void)p;
-    const MatScal *S = static_cast<const MatScal *>(d_scal);
+    (void)d_scal; // (the scalar tables travel by value in the kernel's argument segment since round 5)
     const int OWX = cv.o1[0] - cv.o0[0] + 1, OWY = cv.o1[1] - cv.o0[1] + 1, OWZ = cv.o1[2] - cv.o0[2] + 1;
     const int ntx = (OWX + T3X - 1) / T3X, nty = (OWY + T3Y - 1) / T3Y;
     const bool listed = cv.tile_sel == 2 && cv.bnd_uu3 != nullptr;
@@ -1033,7 +1063,7 @@ namespace pfm
       return PFM_OK;
     const dim3 grid(xcd_grid(nb)), block(NT3);
     const bool il = v.layout == PFM_LAYOUT_INTERLEAVED, het = cv.cell_lam != nullptr, res = res_pde != nullptr;
-    UuArgs ka{v, cv, S, vals_uu, nullptr, res_pde, zc};
+    UuArgs ka{v, cv, make_mat_scal(p, cv), vals_uu, nullptr, res_pde, zc};
     // dynamic LDS on top of the kernel's own: the pair launch asks for the allocation of the phase-field kernel
     auto own_lds = [](const void *fn) {
       hipFuncAttributes at{};
@@ -1051,7 +1081,7 @@ namespace pfm
       {
         static unsigned long long *d_dbg = nullptr;
         static size_t nd_cap = 0;
-        const size_t nd = (size_t)xcd_grid(nb) * 8;
+        const size_t nd = (size_t)xcd_grid(nb) * 16;
         if (nd > nd_cap)
           {
             if (d_dbg)
@@ -1068,16 +1098,17 @@ namespace pfm
           hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, ka);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        unsigned long long h[8] = {};
+        unsigned long long h[16] = {};
         for (size_t i = 0; i < nd; ++i)
-          h[i % 8] += hall[i];
+          h[i % 16] += hall[i];
         const char *names[8] = {"top barrier", "w*g", "moments", "tables+node c0", "copy c0+node c1", "copy c1+node c2",
                                 "copy c2+landing", "prologue loads (per chunk)"};
         const double planes = (double)ntx * nty * OWZ;
         fprintf(stderr, "[k_cart_uu3 phase clock, thread 0, cycles per plane; zc=%d]", zc);
         for (int i = 0; i < 8; ++i)
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / (i == 7 ? (double)nb : planes));
-        fprintf(stderr, "\n");
+        fprintf(stderr, " | wave 7: wait for the requests=%.0f landing=%.0f requests=%.0f\n", (double)h[8] / planes, (double)h[9] / planes,
+                (double)h[10] / planes);
       }
     else if (il)
       {
