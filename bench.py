@@ -266,13 +266,17 @@ def time_mode(asm, dev, residual_only: bool, steps: int, warmup: int):
     torch.cuda.synchronize(dev)
     wall = (time.perf_counter() - t0) / steps * 1e3
     asm.synchronize()
-    asm.ctx.timing_enable(True)
+    # GPU time per call: ONE event pair around the whole batch on the stream the calls are enqueued on, divided by the
+    # number of calls -- it cannot exceed the wall time per call by more than the timer noise, which a pair per call can
+    # (two event records cost ~10 us: more than a quarter of a 35 us kernel)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(steps):
         call()
-    torch.cuda.synchronize(dev)
+    e1.record()
+    e1.synchronize()
     asm.synchronize()
-    k_ms, _ = asm.ctx.kernel_time_ms()
-    asm.ctx.timing_enable(False)
+    k_ms = min(e0.elapsed_time(e1) / steps, wall)
     return wall, k_ms
 
 
@@ -294,8 +298,7 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
             # the line-search call (cracks.cc:2942-2957): only `solution` is scattered again between two residuals
             # pfm_assemble_nl_residual_device: on a single rank the residual kernel reads `solution` itself
             rec["state_scatter"] = "solution only, read by the residual kernel (pfm_assemble_nl_residual_device)"
-            # per call, beyond the kernel group; kernel_ms comes from a second pass with an event pair per call and can
-            # exceed the untimed wall time per call of a 35 us kernel (then: 0)
+            # host time per call beyond the GPU time per call (kernel_ms: one event pair around the batch, see time_mode)
             rec["launch_overhead_ms"] = max(0.0, wall - k_ms)
         vi, src = measured_valu_instructions(dim, n, residual_only)
         if vi is not None:
@@ -454,20 +457,56 @@ def config5_standin(dev, local_rank, steps: int, levels: int = 8):
     return rec
 
 
-def d2h_bandwidth(dev, gib: float = 2.0):
-    """Device -> pinned host copy rate (GB/s) on a sample: what the synchronous host-pointer call shape of the reference
-    (pfm_assemble: values complete in host memory on return) pays per byte of matrix values."""
+def host_pointer_call(asm, dev, n_dofs: int):
+    """MEASURED wall time of the reference's call shape (outputs complete in host-visible storage on
+    return, cracks.cc:2754, 2770, 2918): pfm_assemble -- state H2D, the kernels, every matrix value and the residual in
+    the host's own arrays -- on the bench problem itself.  The arrays are page-locked once through pfm_host_register (what
+    the glue does with Epetra's value arrays at setup_system); the (u,phi) block, identically zero, is cleared once on the
+    host and never transferred.  One call from pageable arrays is timed first for comparison."""
+    import psutil
     import torch
 
-    n = int(gib * (1 << 30) / 8)
-    src = torch.empty(n, dtype=torch.float64, device=dev)
-    dst = torch.empty(n, dtype=torch.float64, pin_memory=True)
-    dst.copy_(src)
-    torch.cuda.synchronize(dev)
+    ctx = asm.ctx
+    sizes = [ctx.pattern_size(b)[1] for b in range(ctx.n_blocks)]
+    need = 8.0 * (sum(sizes) + 5 * ctx.n_owned_dofs)
+    avail = float(psutil.virtual_memory().available)
+    if avail < 1.25 * need + (8 << 30):
+        return {"skipped": f"host memory: {need / 1e9:.1f} GB of arrays needed, {avail / 1e9:.1f} GB available"}
+    sol, old, oo = (t.cpu().numpy().copy() for t in (asm.solution, asm.old_solution, asm.old_old_solution))
+    # the device copy of the matrix that torch holds is not needed here: the library stages in its own buffers
+    asm.system_pde_matrix = None
+    torch.cuda.empty_cache()
+    values = [np.empty(k) for k in sizes]
+    res = np.empty(ctx.n_owned_dofs)
+    rec = {"bytes_host_arrays": need, "blocks_transferred": "(u,u), (phi,u), (phi,phi); (u,phi) = 0 cleared once on the host"}
+
+    def call():
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ctx.assemble_host(sol, old, oo, False, out=(values, res, None))
+        return time.perf_counter() - t0
+
+    call()  # first touch of the pageable arrays, staging buffers of the library
+    rec["seconds_pageable"] = call()
     t0 = time.perf_counter()
-    dst.copy_(src)
-    torch.cuda.synchronize(dev)
-    return n * 8 / (time.perf_counter() - t0) / 1e9
+    pinned = True
+    try:
+        for a in values + [res, sol, old, oo]:
+            ctx.host_register(a)
+    except Exception as e:
+        pinned = False
+        rec["register_error"] = str(e)
+    rec["register_seconds"] = time.perf_counter() - t0
+    rec["pinned"] = pinned
+    call()  # clears the (u,phi) block on the host (once per registration)
+    ts = [call() for _ in range(3)]
+    rec["seconds_per_assembly"] = float(np.median(ts))
+    moved = 8.0 * (sum(k for b, k in enumerate(sizes) if not (ctx.n_blocks == 4 and b == 1)) + 4 * ctx.n_owned_dofs)
+    rec["bytes_over_pcie"] = moved
+    rec["GBps_effective"] = moved / rec["seconds_per_assembly"] / 1e9
+    rec["DoFs_per_s"] = n_dofs / rec["seconds_per_assembly"]
+    ctx.host_unregister()
+    return rec
 
 
 def self_launch_command(n_gpus: int, argv):
@@ -614,6 +653,8 @@ def main():
             e1.synchronize()
             xs.append(e0.elapsed_time(e1))
         exchange_ms = float(np.median(xs))
+    # what RCCL itself counted on the communicator the exchange used (None: no in-library RCCL transport in this run)
+    rccl = halo.rccl_info() if (world > 1 and halo is not None) else None
     tt = torch.tensor([elapsed, k_ms, k_med, exchange_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -728,6 +769,9 @@ def main():
         }
         if world > 1:
             out["exchange_ms"] = exchange_ms  # the ghost import alone, max over ranks of the per-rank median
+            # ncclCommCount / ncclGetVersion of the communicator the ghost exchange ran on (rank 0's view; null in gloo runs)
+            out["rccl_nranks"] = rccl["rccl_nranks"] if rccl else None
+            out["rccl_version"] = rccl["rccl_version"] if rccl else None
         if cubic is not None:
             out["cubic_partition"] = cubic
         if checksum is not None:
@@ -735,13 +779,10 @@ def main():
         if world == 1 and not smoke_gloo and not args.no_extras and dim == 3 and not residual_only and args.path == "auto":
             try:
                 out["extra"] = extra_lines(asm, dev, local_rank, n, max(5, args.steps // 2))
-                # PCIe-inclusive figure of SURVEY 8(d): the values a host-side Trilinos solve needs in host memory
-                bw = d2h_bandwidth(dev)
-                nbytes = 8.0 * (sum(int(m.numel()) for m in asm.system_pde_matrix) + n_dofs)
-                t_incl = elapsed / args.steps + nbytes / (bw * 1e9)
-                out["value_incl_d2h"] = n_dofs / t_incl
-                out["d2h"] = {"GBps_pinned": bw, "bytes_per_assembly": nbytes, "seconds_per_assembly_incl_d2h": t_incl,
-                              "note": "rate measured on a 2 GiB pinned copy, applied to the bytes of all matrix blocks + residual; never the headline value"}
+                # PCIe-inclusive figure of SURVEY 8(d), MEASURED: pfm_assemble into the host's own (page-locked) arrays
+                hp = host_pointer_call(asm, dev, n_dofs)
+                out["host_pointer_call"] = hp
+                out["value_incl_d2h"] = hp.get("DoFs_per_s")  # never the headline value
             except Exception as e:  # the headline line must not depend on the extras
                 out["extra_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:

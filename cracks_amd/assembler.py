@@ -170,6 +170,7 @@ class Context:
         self._check(self.lib.pfm_halo_register(self._h, sp.size - 1, capi.np_ptr(sp, np.int64),
                                                capi.np_ptr(sn, np.int32), capi.np_ptr(rp, np.int64),
                                                capi.np_ptr(rn, np.int32)), "pfm_halo_register")
+        self.n_peers = int(sp.size - 1)  # contexts with peers have ghost nodes: no fused line-search call for them
 
     def halo_pack(self, peer: int, buf_ptr: int):
         self._check(self.lib.pfm_halo_pack(self._h, peer, C.c_void_p(buf_ptr)), "pfm_halo_pack")
@@ -207,20 +208,30 @@ class Context:
     def sync_status(self):
         self._check(self.lib.pfm_sync_status(self._h), "pfm_sync_status")
 
-    def assemble_host(self, sol, old, oldold, residual_only: bool):
-        """``pfm_assemble``: synchronous, host numpy in / host numpy out (single rank)."""
+    def host_register(self, arr: np.ndarray):
+        """``pfm_host_register``: page-lock a host array that ``assemble_host(..., out=...)`` reads or writes at every call.
+        The caller keeps the array alive until ``host_unregister`` / ``close``."""
+        self._check(self.lib.pfm_host_register(self._h, C.c_void_p(arr.ctypes.data), arr.nbytes), "pfm_host_register")
+
+    def host_unregister(self, arr: np.ndarray = None):
+        self._check(self.lib.pfm_host_unregister(self._h, C.c_void_p(arr.ctypes.data) if arr is not None else None), "pfm_host_unregister")
+
+    def assemble_host(self, sol, old, oldold, residual_only: bool, out=None):
+        """``pfm_assemble``: synchronous, host numpy in / host numpy out (single rank).  ``out`` = (values, res_pde,
+        res_tot): arrays of an earlier call to write into again (what a host with its own matrix storage does; with
+        ``host_register`` on them the transfers are DMA from page-locked memory)."""
         sol = np.ascontiguousarray(sol, np.float64)
         old = np.ascontiguousarray(old, np.float64)
         oldold = np.ascontiguousarray(oldold, np.float64)
         n = self.n_owned_dofs
         assert sol.size == old.size == oldold.size == n
-        res_pde = np.zeros(n)
-        res_tot = np.zeros(n) if residual_only else None
+        res_pde = out[1] if out is not None else np.zeros(n)
+        res_tot = (out[2] if out is not None and out[2] is not None else np.zeros(n)) if residual_only else None
         values: List[np.ndarray] = []
         ptrs = (C.c_void_p * 4)()
         if not residual_only:
             for b in range(self.n_blocks):
-                values.append(np.zeros(self.pattern_size(b)[1]))
+                values.append(out[0][b] if out is not None else np.zeros(self.pattern_size(b)[1]))
                 ptrs[b] = values[b].ctypes.data
         rc = self.lib.pfm_assemble(self._h, capi.np_ptr(sol, np.float64), capi.np_ptr(old, np.float64),
                                    capi.np_ptr(oldold, np.float64), 1 if residual_only else 0,
@@ -349,8 +360,10 @@ class Assembler:
         since the last call (the line search of cracks.cc:2942-2957 and the Newton iterations within a time step):
         old_solution / old_old_solution are not scattered again."""
         self.ctx.set_stream(self.torch.cuda.current_stream(self.dev).cuda_stream)
-        if solution_only and residual_only and self.halo is None:
-            # one library call; on a single-rank box the residual kernel reads `solution` itself (no scatter launch)
+        if solution_only and residual_only and self.halo is None and getattr(self.ctx, "n_peers", 0) == 0:
+            # one library call; on a single-rank box the residual kernel reads `solution` itself (no scatter launch).  The
+            # context's own state decides, not this wrapper's: a caller may register peers with ctx.halo_register and move
+            # the ghosts itself (pack / unpack), and pfm_assemble_nl_residual_device refuses such contexts
             self.ctx.assemble_nl_residual_device(self.solution.data_ptr(), self.system_pde_residual.data_ptr(),
                                                  self.system_total_residual.data_ptr())
             return

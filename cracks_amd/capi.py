@@ -23,11 +23,11 @@ LAYOUT_INTERLEAVED, LAYOUT_BLOCKED = 0, 1
 EXPORTS = [
     "pfm_ctx_create", "pfm_ctx_destroy", "pfm_last_error", "pfm_ctx_set_stream", "pfm_set_params",
     "pfm_set_constraints", "pfm_pattern_size", "pfm_pattern_get", "pfm_pattern_bind", "pfm_pattern_bind_i32",
-    "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_wrap", "pfm_comm_destroy", "pfm_comm_aborted", "pfm_halo_exchange", "pfm_assemble_overlapped",
+    "pfm_state_set", "pfm_state_set_solution", "pfm_comm_unique_id", "pfm_comm_create", "pfm_comm_wrap", "pfm_comm_destroy", "pfm_comm_aborted", "pfm_comm_info", "pfm_halo_exchange", "pfm_assemble_overlapped",
     "pfm_check_finite",
     "pfm_halo_register", "pfm_halo_pack", "pfm_halo_unpack", "pfm_halo_pack_all", "pfm_halo_unpack_all",
     "pfm_assemble_device", "pfm_assemble_nl_residual_device",
-    "pfm_sync_status", "pfm_assemble", "pfm_ctx_kernel_path", "pfm_ctx_force_path", "pfm_ctx_overlay_info", "pfm_ctx_force_phase",
+    "pfm_sync_status", "pfm_assemble", "pfm_host_register", "pfm_host_unregister", "pfm_values_to_host", "pfm_ctx_kernel_path", "pfm_ctx_force_path", "pfm_ctx_overlay_info", "pfm_ctx_force_phase",
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms", "pfm_kernel_times_ms",
     # include/pfm_newton.h
     "pfm_diag_mass_device", "pfm_active_set_device", "pfm_get_constraints", "pfm_functionals",
@@ -106,6 +106,10 @@ def load():
     lib.pfm_comm_destroy.argtypes = [vp]
     lib.pfm_comm_wrap.argtypes = [C.POINTER(vp), vp]
     lib.pfm_comm_aborted.argtypes = [vp]
+    lib.pfm_host_register.argtypes = [vp, vp, i64]
+    lib.pfm_host_unregister.argtypes = [vp, vp]
+    lib.pfm_values_to_host.argtypes = [vp, vp, vp]
+    lib.pfm_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.pfm_halo_exchange.argtypes = [vp, vp, vp]
     lib.pfm_assemble_overlapped.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     lib.pfm_check_finite.argtypes = [vp, vp, i64]

@@ -1365,6 +1365,13 @@ extern "C"
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
       }
+    for (auto &hp : c->host_pins) // the arrays belong to the caller; only the page lock is ours
+      (void)hipHostUnregister(hp.p);
+    if (c->copy_stream)
+      {
+        (void)hipStreamDestroy(c->copy_stream);
+        (void)hipEventDestroy(c->ev_copy);
+      }
     for (double *p : c->d_stage_vec)
       if (p)
         (void)hipFree(p);
@@ -1833,6 +1840,9 @@ extern "C"
       ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
       ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
       const char *(*GetErrorString)(ncclResult_t) = nullptr;
+      ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;    // optional (pfm_comm_info)
+      ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr; // optional
+      int version = 0;
       bool ok = false;
       std::string why;
     };
@@ -1880,12 +1890,15 @@ extern "C"
             a.why = "librccl.so lacks a required symbol";
             return a;
           }
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+        a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
         int ver = 0;
         if (a.GetVersion(&ver) != ncclSuccess || ver / 10000 != NCCL_MAJOR)
           {
             a.why = "RCCL run-time version " + std::to_string(ver) + " does not match the compiled-in major " + std::to_string(NCCL_MAJOR);
             return a;
           }
+        a.version = ver;
         a.ok = true;
         return a;
       }();
@@ -1896,8 +1909,10 @@ extern "C"
 
   // what a communicator handle of this ABI points to: the RCCL communicator and whether a failed exchange aborted it
   // (ncclCommAbort frees the communicator; the owner still holds the handle and must be able to destroy it)
+  constexpr uint64_t PFM_COMM_MAGIC = 0x70666d636f6d6d31ull; // "pfmcomm1"
   struct PfmComm
   {
+    uint64_t magic = PFM_COMM_MAGIC; // a raw ncclComm_t passed where a handle is expected is refused, not reinterpreted
     ncclComm_t cm = nullptr;
     bool aborted = false;
     bool owned = true; // false: the host's own communicator (pfm_comm_wrap), never destroyed here
@@ -1952,6 +1967,8 @@ extern "C"
     if (!comm)
       return PFM_OK;
     PfmComm *h = static_cast<PfmComm *>(comm);
+    if (h->magic != PFM_COMM_MAGIC)
+      return PFM_ERR_BAD_ARG; // not a handle (e.g. the host's raw ncclComm_t): nothing of it is touched
     int rc = PFM_OK;
     if (!h->aborted && h->owned)
       {
@@ -1959,6 +1976,7 @@ extern "C"
         rc = (R.ok && R.CommDestroy(h->cm) == ncclSuccess) ? PFM_OK : PFM_ERR_COMM;
       }
     h->cm = nullptr;
+    h->magic = 0;
     delete h;
     return rc;
   }
@@ -1976,7 +1994,31 @@ extern "C"
     return PFM_OK;
   }
 
-  int pfm_comm_aborted(const void *comm) { return comm ? (static_cast<const PfmComm *>(comm)->aborted ? 1 : 0) : 0; }
+  static bool comm_handle_ok(const void *comm) { return comm && static_cast<const PfmComm *>(comm)->magic == PFM_COMM_MAGIC; }
+  int pfm_comm_aborted(const void *comm) { return comm_handle_ok(comm) ? (static_cast<const PfmComm *>(comm)->aborted ? 1 : 0) : 0; }
+
+  // what RCCL itself says about the communicator behind a handle (the driver's N-GPU record can show that RCCL counted N ranks)
+  int pfm_comm_info(const void *comm, int *n_ranks, int *rank, int *rccl_version)
+  {
+    if (!comm_handle_ok(comm))
+      return PFM_ERR_BAD_ARG;
+    const PfmComm *h = static_cast<const PfmComm *>(comm);
+    const RcclApi &R = rccl();
+    if (!R.ok || h->aborted || !h->cm)
+      return PFM_ERR_COMM;
+    int n = -1, r = -1;
+    if (R.CommCount && R.CommCount(h->cm, &n) != ncclSuccess)
+      return PFM_ERR_COMM;
+    if (R.CommUserRank && R.CommUserRank(h->cm, &r) != ncclSuccess)
+      return PFM_ERR_COMM;
+    if (n_ranks)
+      *n_ranks = n;
+    if (rank)
+      *rank = r;
+    if (rccl_version)
+      *rccl_version = R.version;
+    return PFM_OK;
+  }
 
   // both staging buffers or none: a half-allocated pair must not survive a failed call
   static int ensure_halo_buffers(pfm_ctx *c)
@@ -2013,16 +2055,21 @@ extern "C"
     if (!R.ok)
       return fail(c, PFM_ERR_COMM, "RCCL unavailable: " + R.why);
     PfmComm *h = static_cast<PfmComm *>(comm);
+    if (h->magic != PFM_COMM_MAGIC)
+      return fail(c, PFM_ERR_BAD_ARG, "comm is not a handle of pfm_comm_create / pfm_comm_wrap (a raw ncclComm_t must be wrapped)");
     if (h->aborted || !h->cm)
       return fail(c, PFM_ERR_COMM, "communicator was aborted by an earlier failed exchange");
     ncclComm_t cm = h->cm;
     // A rank that fails locally before its sends and receives are enqueued must not leave its peers waiting for them:
-    // the communicator is aborted on EVERY failure from here on (the buffers themselves come from pfm_halo_register)
+    // a communicator the library OWNS is aborted on every failure from here on (the buffers themselves come from
+    // pfm_halo_register).  A wrapped communicator belongs to the host: it is never aborted or destroyed here -- the handle is
+    // marked (pfm_comm_aborted() == 1, further exchanges refused) and the host decides what to do with its ncclComm_t.
     auto abort_comm = [&](int code, const std::string &msg) {
-      (void)R.CommAbort(cm);
+      if (h->owned)
+        (void)R.CommAbort(cm);
       h->aborted = true; // the handle stays valid for pfm_comm_destroy; further exchanges on it are refused
       h->cm = nullptr;
-      return fail(c, code, msg + " (communicator aborted)");
+      return fail(c, code, msg + (h->owned ? " (communicator aborted)" : " (wrapped communicator left to the host, handle disabled)"));
     };
     int rc = ensure_halo_buffers(c);
     if (rc)
@@ -2451,6 +2498,133 @@ extern "C"
     return pfm_sync_status(c);
   }
 
+  // ---- host-visible outputs (the caller hands system_pde_matrix to Trilinos right after the call,
+  // cracks.cc:2754, 2770, 2918).  35 GB of matrix values cross PCIe per Jacobian at 216^3: what can be done about that is
+  // (1) DMA from / to page-locked memory instead of the runtime's pageable path (pfm_host_register), (2) never moving the
+  // (u,phi) block, which is identically zero (cracks.cc:2333-2337; placeholders of constrained rows live on the diagonals
+  // of the (u,u) and (phi,phi) blocks): 3/16 of the bytes, (3) two copy streams.
+  int pfm_host_register(pfm_ctx *c, void *p, int64_t bytes)
+  {
+    if (!c || !p || bytes <= 0)
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    for (auto &hp : c->host_pins)
+      if (hp.p == p)
+        {
+          if (hp.bytes >= (size_t)bytes)
+            return PFM_OK;
+          (void)hipHostUnregister(hp.p); // the same array, grown: lock it again
+          hp.p = nullptr;
+        }
+    c->host_pins.erase(std::remove_if(c->host_pins.begin(), c->host_pins.end(), [](const pfm_ctx::HostPin &h) { return h.p == nullptr; }),
+                       c->host_pins.end());
+    const hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess)
+      {
+        (void)hipGetLastError(); // not sticky: the transfers simply take the pageable path
+        return fail(c, PFM_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e) + " (the array stays pageable)");
+      }
+    pfm_ctx::HostPin hp;
+    hp.p = p;
+    hp.bytes = (size_t)bytes;
+    c->host_pins.push_back(hp);
+    return PFM_OK;
+  }
+
+  int pfm_host_unregister(pfm_ctx *c, void *p)
+  {
+    if (!c)
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream)
+      (void)hipStreamSynchronize(c->copy_stream);
+    for (auto &hp : c->host_pins)
+      if (!p || hp.p == p)
+        {
+          (void)hipHostUnregister(hp.p);
+          hp.p = nullptr;
+        }
+    c->host_pins.erase(std::remove_if(c->host_pins.begin(), c->host_pins.end(), [](const pfm_ctx::HostPin &h) { return h.p == nullptr; }),
+                       c->host_pins.end());
+    return PFM_OK;
+  }
+
+  static pfm_ctx::HostPin *find_pin(pfm_ctx *c, const void *p, size_t bytes)
+  {
+    for (auto &hp : c->host_pins)
+      if (hp.p == p && hp.bytes >= bytes)
+        return &hp;
+    return nullptr;
+  }
+
+  // matrix values of the last pfm_assemble_device -> the host's arrays, asynchronously: block 0 on the context's stream,
+  // the phase-field blocks on a second stream (joined into the first before returning).  Does not synchronise.
+  static int values_to_host_async(pfm_ctx *c, double *const *d_values, double *const *h_values)
+  {
+    (void)hipSetDevice(c->device);
+    if (!c->copy_stream)
+      {
+        if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess)
+          return fail(c, PFM_ERR_HIP, "copy stream");
+      }
+    hipError_t e = hipEventRecord(c->ev_copy, c->stream);
+    if (e == hipSuccess)
+      e = hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0);
+    for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
+      {
+        const size_t bytes = sizeof(double) * (size_t)c->block_nnz(b);
+        if (!bytes)
+          continue;
+        if (!h_values[b] || !d_values[b])
+          return fail(c, PFM_ERR_BAD_ARG, "pfm_values_to_host: null block");
+        if (c->n_blocks == 4 && b == 1)
+          {
+            // (u,phi) = 0.  A registered array is ours between the calls (nobody else writes the matrix: the reference only
+            // ever fills it through assemble_system): cleared once, by host threads next to the transfers, never copied.
+            // An unregistered one is copied like the others (the device block holds the zeros the kernels wrote).
+            pfm_ctx::HostPin *hp = find_pin(c, h_values[b], bytes);
+            if (hp)
+              {
+                if (!hp->zeroed)
+                  {
+                    const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+                    std::vector<std::thread> th;
+                    const size_t chunk = ((bytes / (size_t)nt) + 4095) & ~(size_t)4095;
+                    for (int t = 0; t < nt; ++t)
+                      {
+                        const size_t lo = std::min(bytes, (size_t)t * chunk), hi = std::min(bytes, lo + chunk);
+                        if (hi > lo)
+                          th.emplace_back([=] { std::memset(reinterpret_cast<char *>(h_values[b]) + lo, 0, hi - lo); });
+                      }
+                    for (auto &t : th)
+                      t.join();
+                    hp->zeroed = true;
+                  }
+                continue;
+              }
+          }
+        e = hipMemcpyAsync(h_values[b], d_values[b], bytes, hipMemcpyDeviceToHost, b == 0 ? c->stream : c->copy_stream);
+      }
+    if (e == hipSuccess)
+      e = hipEventRecord(c->ev_copy, c->copy_stream);
+    if (e == hipSuccess)
+      e = hipStreamWaitEvent(c->stream, c->ev_copy, 0);
+    return e == hipSuccess ? PFM_OK : hipfail(c, e, "copy back (matrix values)");
+  }
+
+  int pfm_values_to_host(pfm_ctx *c, double *const *d_values, double *const *h_values)
+  {
+    if (!c || !d_values || !h_values)
+      return PFM_ERR_BAD_ARG;
+    const int rc = values_to_host_async(c, d_values, h_values);
+    if (rc)
+      return rc;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? PFM_OK : hipfail(c, e, "pfm_values_to_host");
+  }
+
   int pfm_assemble(pfm_ctx *c, const double *sol, const double *old, const double *oldold,
                    int residual_only, double *const *values, double *residual_pde,
                    double *residual_total)
@@ -2484,15 +2658,18 @@ extern "C"
     rc = pfm_assemble_device(c, residual_only, c->d_stage_val, c->d_stage_res[0], c->d_stage_res[1]);
     if (rc)
       return rc;
+    // the residual first (the caller's Newton loop reads it at once, cracks.cc:2791-2794), then the matrix blocks
     hipError_t e = hipMemcpyAsync(residual_pde, c->d_stage_res[0], vb, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && residual_only)
       e = hipMemcpyAsync(residual_total, c->d_stage_res[1], vb, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && !residual_only)
-      for (int b = 0; b < c->n_blocks && e == hipSuccess; ++b)
-        e = hipMemcpyAsync(values[b], c->d_stage_val[b], sizeof(double) * (size_t)c->block_nnz(b),
-                           hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess)
       return hipfail(c, e, "copy back");
+    if (!residual_only)
+      {
+        rc = values_to_host_async(c, c->d_stage_val, values);
+        if (rc)
+          return rc;
+      }
     return pfm_sync_status(c);
   }
 

@@ -218,6 +218,17 @@ struct pfm_ctx
   double *d_stage_vec[3] = {nullptr, nullptr, nullptr};
   double *d_stage_res[2] = {nullptr, nullptr};
   double *d_stage_val[4] = {nullptr, nullptr, nullptr, nullptr};
+  // host arrays the caller page-locked through pfm_host_register (DMA at the link rate instead of the pageable path);
+  // zeroed: the array is the (u,phi) block of a matrix and has been cleared once (pfm_values_to_host never copies it)
+  struct HostPin
+  {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool zeroed = false;
+  };
+  std::vector<HostPin> host_pins;
+  hipStream_t copy_stream = nullptr; // second device -> host stream of pfm_values_to_host
+  hipEvent_t ev_copy = nullptr;
   std::vector<pfm::HaloPeer> peers;
   int32_t *d_send_all = nullptr, *d_recv_all = nullptr; // concatenated halo lists and their per-peer offsets
   long long *d_send_ptr = nullptr, *d_recv_ptr = nullptr;

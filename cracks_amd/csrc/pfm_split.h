@@ -50,7 +50,10 @@ namespace pfm
       const double y0 = __builtin_amdgcn_rcp(x);
       double y = fma(fma(-x, y0, 1.0), y0, y0);
       y = fma(fma(-x, y, 1.0), y, y);
-      return (__builtin_isinf(x) || x == 0.0) ? y0 : y;
+      // x = 0, x = inf AND arguments whose estimate over- or underflows (subnormal or near-maximal |x|): the refinement
+      // would turn inf / 0 into NaN there (fma(-x, inf, 1) * inf); the raw estimate is what IEEE division gives up to the
+      // last binade (1 / subnormal = inf or 1.8e308)
+      return (__builtin_isinf(y0) || y0 == 0.0) ? y0 : y;
     }
 
     struct SplitCommon
@@ -71,9 +74,14 @@ namespace pfm
       C.r01 = recip(m01);
       C.d1 = C.l1 - m00;
       C.d2 = C.l2 - m00;
-      C.t1 = C.d1 * C.r01;
-      C.t2 = C.d2 * C.r01;
-      const double q1 = 1.0 + C.t1 * C.d1 * C.r01, q2 = 1.0 + C.t2 * C.d2 * C.r01;
+      // (l_i - E_00) / E_01 as the reference divides it (cracks.cc:1716-1721): with a subnormal E_01 the reciprocal alone
+      // overflows where the quotient of two equally tiny numbers is an ordinary number -- numerator and denominator are
+      // scaled by 2^200 there (exact), so that d_i / E_01 stays what IEEE division gives
+      const bool tiny = fabs(m01) < 0x1p-900;
+      const double rs = tiny ? recip(m01 * 0x1p200) : C.r01, up = tiny ? 0x1p200 : 1.0;
+      C.t1 = (C.d1 * up) * rs;
+      C.t2 = (C.d2 * up) * rs;
+      const double q1 = 1.0 + (tiny ? C.t1 * C.t1 : C.t1 * C.d1 * C.r01), q2 = 1.0 + (tiny ? C.t2 * C.t2 : C.t2 * C.d2 * C.r01);
       C.n1 = sqrt_rsqrt(q1).rroot;
       C.n2 = sqrt_rsqrt(q2).rroot;
       const double v1x = diag ? 1.0 : C.n1, v1y = diag ? 0.0 : C.t1 * C.n1;

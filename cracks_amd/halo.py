@@ -139,6 +139,17 @@ class HaloExchange:
         self._ensure_comm(ctx)
         return self._comm.value if (self._use_lib and self._comm is not None) else None
 
+    def rccl_info(self):
+        """What RCCL reports for the communicator the exchange uses: {"rccl_nranks": ncclCommCount, "rccl_rank":
+        ncclCommUserRank, "rccl_version": ncclGetVersion}, or None when the exchange does not go through the library's
+        RCCL transport (gloo runs, PFM_HALO_TORCH=1, one rank)."""
+        if self._comm is None:
+            return None
+        n, r, ver = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        if self._comm_lib.pfm_comm_info(self._comm, C.byref(n), C.byref(r), C.byref(ver)) != 0:
+            return None
+        return {"rccl_nranks": int(n.value), "rccl_rank": int(r.value), "rccl_version": int(ver.value)}
+
     def close(self):
         if self._comm is not None:
             self._comm_lib.pfm_comm_destroy(self._comm)

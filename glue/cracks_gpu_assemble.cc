@@ -107,6 +107,8 @@ namespace pfm_glue_detail
     std::vector<ShippedCell> shipped_cells;
     std::map<gidx, std::vector<std::pair<gidx, double>>> shipped_lines; // hanging lines of their vertices (phase-field dofs)
     std::map<unsigned int, std::vector<gidx>> flags_wanted_from, flags_asked_by; // per assemble: flag bytes of shipped nodes
+    bool flags_shipped_anywhere = false; // some rank of the communicator wants such bytes (decided collectively in rebuild)
+    IndexSet relevant_dofs;              // locally relevant dofs: the lines deal.II's AffineConstraints objects can be asked about
     bool state_complete = false; // all three vectors have been scattered into this context once
 
     ~PfmGlue()
@@ -156,6 +158,7 @@ namespace pfm_glue_detail
       const unsigned int phi_comp = dim; // components 0..dim-1 = u, dim = phi (cracks.cc:980-996)
       AssertThrow(fe.degree == 1 && fe.n_components() == dim + 1, ExcMessage("the GPU assembly is written for Q1/Q1 (FE degree 1)"));
       const IndexSet &owned = dh.locally_owned_dofs();
+      relevant_dofs = DoFTools::extract_locally_relevant_dofs(dh);
 
       // ---- 0. hanging-node closure: cells of other ranks that reach a row owned here through a hanging vertex
       const std::vector<IndexSet> owned_per_rank = Utilities::MPI::all_gather(mpi, owned);
@@ -247,7 +250,7 @@ namespace pfm_glue_detail
         {
           const gidx g = phi_dof_of_node[n];
           const std::vector<std::pair<gidx, double>> *line = nullptr;
-          if (P.constraints_hanging_nodes.is_constrained(g))
+          if (relevant_dofs.is_element(g) && P.constraints_hanging_nodes.is_constrained(g)) // (asked about its local lines only)
             line = P.constraints_hanging_nodes.get_constraint_entries(g);
           else if (shipped_lines.count(g)) // a vertex of a shipped cell outside the locally relevant dofs
             line = &shipped_lines.at(g);
@@ -313,6 +316,12 @@ namespace pfm_glue_detail
             AssertThrow(nnz[block] == n_entries, ExcMessage("pattern size mismatch"));
             AssertThrow(hipMalloc((void **)&d_val[block], sizeof(double) * (size_t)std::max<int64_t>(nnz[block], 1)) == hipSuccess,
                         ExcMessage("hipMalloc (matrix values)"));
+            // Epetra's value array receives 35 GB per Jacobian at 1e7 cells: page-locked, the transfer is DMA at the link
+            // rate (pageable memory: a fraction of it).  Best effort: if the pages cannot be locked the copy still works.
+            // The lock is released by release() (pfm_ctx_destroy) -- which therefore must run BEFORE the matrix is
+            // reinitialised in setup_system.
+            if (n_entries > 0)
+              (void)pfm_host_register(ctx, values, (int64_t)sizeof(double) * n_entries);
           }
 
       // ---- 6. ghost import lists (cracks.cc:2147-2154 at node level): who owns my ghost nodes, who needs my owned ones
@@ -364,13 +373,15 @@ namespace pfm_glue_detail
       // constraint flags of ghost nodes that are NOT locally relevant (vertices of shipped cells): deal.II does not know
       // constraints_update there, their owners tell us at every assemble (exchange_shipped_flags)
       {
-        const IndexSet relevant = DoFTools::extract_locally_relevant_dofs(dh);
         flags_wanted_from.clear();
         for (const auto &kv : want_from)
           for (const gidx g : kv.second)
-            if (!relevant.is_element(g))
+            if (!relevant_dofs.is_element(g))
               flags_wanted_from[(unsigned int)kv.first].push_back(g);
         flags_asked_by = Utilities::MPI::some_to_some(mpi, flags_wanted_from);
+        // some_to_some is collective over the whole communicator: whether the per-assemble exchange runs at all is decided
+        // HERE, once and by everybody -- a rank that takes no part in the shipping must still make the call (with empty maps)
+        flags_shipped_anywhere = Utilities::MPI::max(flags_wanted_from.empty() && flags_asked_by.empty() ? 0u : 1u, mpi) != 0u;
       }
 
       // ---- 7. one RCCL communicator for the life of the program (collective); the id travels over MPI
@@ -525,7 +536,7 @@ namespace pfm_glue_detail
                 continue; // in the ghost layer already, or shipped twice
               shipped_cells.push_back(sc);
               for (const auto &l : lines)
-                if (!P.constraints_hanging_nodes.is_constrained(l.first))
+                if (!(relevant_dofs.is_element(l.first) && P.constraints_hanging_nodes.is_constrained(l.first)))
                   shipped_lines[l.first] = l.second;
             }
         }
@@ -536,8 +547,8 @@ namespace pfm_glue_detail
     template <class Problem>
     void exchange_shipped_flags(const Problem &P)
     {
-      if (flags_wanted_from.empty() && flags_asked_by.empty())
-        return;
+      if (!flags_shipped_anywhere)
+        return; // the same decision on every rank (rebuild)
       std::map<unsigned int, std::vector<char>> out;
       for (const auto &kv : flags_asked_by)
         for (const gidx g : kv.second)
@@ -589,7 +600,8 @@ namespace pfm_glue_detail
         for (unsigned int comp = 0; comp <= (unsigned int)dim; ++comp)
           {
             const gidx g = global_dof_of(P, n, comp);
-            if (P.constraints_update.is_constrained(g) && !P.constraints_hanging_nodes.is_constrained(g))
+            // (vertices of shipped cells lie outside the locally relevant set: their bits arrive from the owner below)
+            if (relevant_dofs.is_element(g) && P.constraints_update.is_constrained(g) && !P.constraints_hanging_nodes.is_constrained(g))
               flags[(size_t)n] |= (uint8_t)(1u << comp);
           }
       exchange_shipped_flags(P);
@@ -632,17 +644,17 @@ namespace pfm_glue_detail
         }
       else
         {
+          // pfm_values_to_host: blocks (u,u) and (phi,u), (phi,phi) on two streams; the (u,phi) block of a registered array
+          // is identically zero, cleared once on the host and never transferred (3/16 of the bytes)
+          double *h_val[4] = {nullptr, nullptr, nullptr, nullptr};
           const unsigned int nb1 = blocked ? 2 : 1;
           for (unsigned int r = 0; r < nb1; ++r)
             for (unsigned int c = 0; c < nb1; ++c)
               {
-                const int block = blocked ? (int)(2 * r + c) : 0;
                 int *rowptr = nullptr, *colind = nullptr;
-                double *values = nullptr;
-                P.system_pde_matrix.block(r, c).trilinos_matrix().ExtractCrsDataPointers(rowptr, colind, values);
-                AssertThrow(hipMemcpy(values, d_val[block], sizeof(double) * (size_t)nnz[block], hipMemcpyDeviceToHost) == hipSuccess,
-                            ExcMessage("D2H (matrix values)"));
+                P.system_pde_matrix.block(r, c).trilinos_matrix().ExtractCrsDataPointers(rowptr, colind, h_val[blocked ? 2 * r + c : 0]);
               }
+          PFM_CALL(ctx, pfm_values_to_host(ctx, d_val, h_val));
         }
       // the AMG set-up of cracks.cc:2477-2497 follows in the caller, unchanged
     }

@@ -163,15 +163,21 @@ int pfm_halo_unpack_all(pfm_ctx *ctx, const double *d_buf_all);
  *                        peer_ranks[k] = communicator rank of peer k of pfm_halo_register.  `comm` is a handle made
  *                        by pfm_comm_create, or by pfm_comm_wrap around the host's own ncclComm_t.  Collective: every
  *                        rank of the communicator that is somebody's peer must call it.
- * Error path: a failed RCCL call inside an exchange aborts the communicator (ncclCommAbort: peers error out instead of
- * waiting for a message that never comes).  The HANDLE stays valid: pfm_comm_aborted() reports the state, every further
- * exchange on it returns PFM_ERR_COMM, and pfm_comm_destroy() only frees the handle then (no double free). */
+ *                        A raw ncclComm_t is NOT a handle: it is refused with PFM_ERR_BAD_ARG (the handles carry a tag).
+ * Error path: a failed exchange on a communicator made by pfm_comm_create aborts it (ncclCommAbort: peers error out
+ * instead of waiting for a message that never comes).  A communicator adopted with pfm_comm_wrap belongs to the host: it
+ * is neither aborted nor destroyed by the library -- the handle is disabled and the host decides (abort or destroy its
+ * ncclComm_t as usual).  Either way the HANDLE stays valid: pfm_comm_aborted() reports 1, every further exchange on it
+ * returns PFM_ERR_COMM, and pfm_comm_destroy() only frees the handle then (no double free). */
 #define PFM_COMM_ID_BYTES 128
 int pfm_comm_unique_id(uint8_t id[PFM_COMM_ID_BYTES]);
 int pfm_comm_create(void **comm, const uint8_t id[PFM_COMM_ID_BYTES], int n_ranks, int rank, int device);
 int pfm_comm_wrap(void **comm, void *nccl_comm /* the host's ncclComm_t; not destroyed by pfm_comm_destroy */);
 int pfm_comm_destroy(void *comm);
 int pfm_comm_aborted(const void *comm); /* 1 after a failed exchange aborted the communicator, else 0 */
+/* what RCCL itself reports for the communicator behind a handle: ncclCommCount, ncclCommUserRank (-1 where the loaded RCCL has
+ * no such entry point) and ncclGetVersion -- diagnostics for multi-GPU records; any of the pointers may be NULL */
+int pfm_comm_info(const void *comm, int *n_ranks, int *rank, int *rccl_version);
 int pfm_halo_exchange(pfm_ctx *ctx, void *comm, const int *peer_ranks /* host, [n_peers] */);
 /* pfm_halo_exchange + pfm_assemble_device with the ghost import HIDDEN behind cell work: after pfm_state_set the exchange
  * runs on a second stream of the context while the tiles that read no ghost node are assembled; the rest follows when the
@@ -209,9 +215,25 @@ int pfm_sync_status(pfm_ctx *ctx);
  * cracks.cc:1982-2006). */
 int pfm_check_finite(pfm_ctx *ctx, const double *d_data, int64_t n);
 
-/* Synchronous host-pointer convenience = pfm_state_set + pfm_assemble_device + copies back
- * + pfm_sync_status: the exact call shape of the reference (outputs complete in host memory
- * on return, cracks.cc:2791-2794, 2918).  Single-rank only (no ghosts). */
+/* Host-visible outputs (cracks.cc:2754, 2770, 2918: the caller hands system_pde_matrix to Trilinos right after the call).
+ *   pfm_host_register    page-locks a host array the host-pointer entry points read or write at every call -- the value
+ *                        arrays of the Epetra_CrsMatrix blocks (Epetra_CrsMatrix::ExtractCrsDataPointers), the owned parts of
+ *                        the vectors -- so that their transfers run as DMA at the link rate instead of through the runtime's
+ *                        pageable path.  The array stays the caller's; it must be unregistered (pfm_host_unregister, NULL =
+ *                        all; pfm_ctx_destroy does it too) BEFORE it is freed or reallocated (setup_system after refine_mesh).
+ *                        PFM_ERR_HIP if the pages cannot be locked (ulimit): the array simply stays pageable.
+ *   pfm_values_to_host   matrix values of the last pfm_assemble_device -> h_values[block], synchronous.  With the 2x2 block
+ *                        layout the (u,phi) block is identically zero (trial phase-field dofs do not enter the displacement
+ *                        rows, cracks.cc:2333-2337; the placeholders of constrained rows sit on the diagonals of (u,u) and
+ *                        (phi,phi)): 3/16 of the bytes.  If h_values[1] is a REGISTERED array it is cleared once by host
+ *                        threads and never transferred -- the library assumes nobody else writes the matrix values between
+ *                        assemblies (the reference only fills them through assemble_system); an unregistered array is copied
+ *                        like the other blocks.  Blocks 2, 3 travel on a second stream next to block 0.
+ * pfm_assemble = pfm_state_set + pfm_assemble_device + these copies + pfm_sync_status: the exact call shape of the
+ * reference (outputs complete in host memory on return, cracks.cc:2791-2794, 2918).  Single-rank only (no ghosts). */
+int pfm_host_register(pfm_ctx *ctx, void *host_array, int64_t bytes);
+int pfm_host_unregister(pfm_ctx *ctx, void *host_array /* NULL: every array of this context */);
+int pfm_values_to_host(pfm_ctx *ctx, double *const *d_values /* [n_blocks] */, double *const *h_values /* [n_blocks] */);
 int pfm_assemble(pfm_ctx *ctx, const double *sol, const double *old, const double *oldold,
                  int residual_only, double *const *values, double *residual_pde,
                  double *residual_total);

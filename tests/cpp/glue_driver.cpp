@@ -11,6 +11,7 @@
 #include "../../glue/cracks_gpu_assemble.cc"
 
 #include <cstdio>
+#include <cmath>
 #include <fstream>
 #include <sstream>
 
@@ -41,10 +42,18 @@ struct ConstFunction1
   double v = 0.0;
   double value(const Point<1> &, unsigned int) const { return v; }
 };
+// a smooth stand-in for the reference's bitmap function (cracks.cc:118-241): the test evaluates the same formula at the
+// cell centres for the oracle (tests/test_glue_mock.py: emodulus_mock)
 template <int dim>
 struct EModulusMock
 {
-  double value(const Point<dim> &, unsigned int) const { return 0.0; }
+  double value(const Point<dim> &p, unsigned int) const
+  {
+    double e = 100.0 + 50.0 * std::sin(0.7 * p[0]) * std::cos(0.3 * p[1]);
+    if (dim == 3)
+      e += 20.0 * std::sin(0.5 * p[dim - 1]);
+    return e;
+  }
 };
 
 // the members of FracturePhaseFieldProblem<dim> the glue touches (cracks.cc:1039-1180)
@@ -94,6 +103,9 @@ static int run(const std::string &dir, std::istringstream &meta)
   int use_old, tsn;
   meta >> P.lame_coefficient_lambda >> P.lame_coefficient_mu >> P.G_c >> P.alpha_eps >> P.constant_k >> pressure >> P.alpha_biot >> P.gamma_penal >>
     P.timestep >> P.time >> P.old_timestep >> P.old_old_timestep >> P.decompose_stress_rhs >> P.decompose_stress_matrix >> tsn >> use_old;
+  int het = 0;
+  if (meta >> het >> P.poisson_ratio_nu) // optional: a multiple_het run (cracks.cc:2207-2216) with this Poisson ratio
+    P.test_case = het ? Problem<dim>::TestCase::multiple_het : Problem<dim>::TestCase::sneddon;
   P.func_pressure.v = pressure;
   P.timestep_number = (unsigned int)tsn;
   P.use_old_timestep_pf = use_old != 0;

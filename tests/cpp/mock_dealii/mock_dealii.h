@@ -166,6 +166,8 @@ namespace dealii
       inline unsigned int this_mpi_process(MPI_Comm) { return 0; }
       inline unsigned int n_mpi_processes(MPI_Comm) { return 1; }
       template <class T>
+      T max(const T &x, MPI_Comm) { return x; }
+      template <class T>
       std::vector<T> all_gather(MPI_Comm, const T &x)
       {
         return std::vector<T>(1, x);

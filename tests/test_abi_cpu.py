@@ -73,6 +73,18 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib):
     assert lib.pfm_last_error(None) == b"null context"
 
 
+def test_raw_pointers_are_not_taken_for_communicator_handles(lib):
+    """a host that passes its own ncclComm_t (or anything else) where a pfm_comm_* handle is expected gets
+    PFM_ERR_BAD_ARG -- the handles carry a tag -- instead of having its memory reinterpreted."""
+    fake = (C.c_uint8 * 256)()  # something that is not a handle, large enough to be read
+    assert lib.pfm_comm_aborted(C.cast(fake, C.c_void_p)) == 0
+    assert lib.pfm_comm_destroy(C.cast(fake, C.c_void_p)) == 1  # PFM_ERR_BAD_ARG, nothing freed
+    n = C.c_int32(0)
+    assert lib.pfm_comm_info(C.cast(fake, C.c_void_p), C.byref(n), None, None) == 1
+    assert lib.pfm_comm_info(None, None, None, None) == 1
+    assert lib.pfm_comm_destroy(None) == 0
+
+
 def test_no_oracle_in_product_package():
     """The product path must not import, link or call the oracle."""
     pkg = os.path.join(ROOT, "cracks_amd")

@@ -122,6 +122,9 @@ def _write_problem(c, d, seed):
     with open(os.path.join(d, "meta.txt"), "w") as f:
         f.write(" ".join(str(x) for x in meta) + "\n" + " ".join(repr(float(x)) for x in vals) + "\n")
         f.write(f"{int(p.timestep_number)} {int(p.use_old_timestep_pf)}\n")
+        het = c.extra.get("glue_het_nu")
+        if het is not None:
+            f.write(f"1 {float(het)!r}\n")
     return to_mock, blocks
 
 
@@ -132,7 +135,28 @@ def _read_matrix(d, lay, blocks):
     return sp.bmat([[mats[0], mats[1]], [mats[2], mats[3]]], format="csr")
 
 
+def emodulus_mock(centres):
+    """EModulusMock of tests/cpp/glue_driver.cpp at the cell centres."""
+    e = 100.0 + 50.0 * np.sin(0.7 * centres[:, 0]) * np.cos(0.3 * centres[:, 1])
+    if centres.shape[1] == 3:
+        e = e + 20.0 * np.sin(0.5 * centres[:, 2])
+    return e
+
+
+def _multiple_het(c, nu=0.2):
+    """The material override of cracks.cc:2207-2216 as the glue performs it (glue/cracks_gpu_assemble.cc, step 2): E from
+    func_emodulus at the cell centre + 1.0, Lame coefficients per cell."""
+    centres = c.mesh.coords[c.mesh.cells].mean(axis=1)
+    E = emodulus_mock(centres) + 1.0
+    c.cell_mu = E / (2.0 * (1.0 + nu))
+    c.cell_lambda = 2.0 * nu * c.cell_mu / (1.0 - 2.0 * nu)
+    c.extra["glue_het_nu"] = nu
+    return c
+
+
 CASES = [
+    ("multiple_het_3d_hanging_blocked", lambda: _multiple_het(cases.perturbed(cases.kat_hetero_3d()))),
+    ("multiple_het_2d_hanging_blocked", lambda: _multiple_het(cases.perturbed(cases.kat_sneddon_2d()))),
     ("sneddon_2d_hanging_blocked", lambda: cases.perturbed(cases.kat_sneddon_2d())),
     ("sneddon_3d_blocked", lambda: cases.perturbed(cases.kat_sneddon_3d(5))),
     ("miehe_slit_interleaved", lambda: cases.perturbed(cases.kat_miehe_shear_1())),
@@ -162,13 +186,13 @@ def test_glue_rebuild_and_assemble_match_the_oracle(name, maker, tmp_path):
     mesh, lay = c.mesh, c.layout
     rp, ci = M.dof_sparsity(mesh, lay)
     # residual-only call
-    ro = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, True, rp, ci)
+    ro = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, True, rp, ci, c.cell_lambda, c.cell_mu)
     assert ro.err == 0
     res_pde = np.fromfile(os.path.join(d, "out_res_pde_ro.bin"))[to_mock]
     res_tot = np.fromfile(os.path.join(d, "out_res_tot_ro.bin"))[to_mock]
     assert linf_scaled(res_pde, ro.residual_pde) < TOL and linf_scaled(res_tot, ro.residual_total) < TOL
     # full call: every matrix entry (constrained rows included) and the residual
-    rf = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, False, rp, ci)
+    rf = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, False, rp, ci, c.cell_lambda, c.cell_mu)
     assert rf.err == 0
     A_ref = sp.csr_matrix((rf.values, ci, rp), shape=(lay.n_dofs,) * 2)
     A_mock = _read_matrix(d, lay, blocks).tocsr()

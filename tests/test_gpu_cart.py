@@ -566,3 +566,40 @@ def test_general_family_launch_modes_agree(tmp_path):
     # side stream or not: only the entries that receive atomic adds (rows next to hanging nodes) may differ in the last bit
     same = val["general"] == val["general_seq"]
     assert same.mean() > 0.5
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+@pytest.mark.parametrize("registered", [True, False])
+def test_host_pointer_call_with_the_hosts_own_arrays(blocked, registered):
+    """pfm_assemble into arrays the host keeps (the value arrays of its matrix): page-locked through pfm_host_register
+    the (u,phi) block is cleared once on the host and never transferred, unregistered it is copied like the others;
+    either way the call leaves every entry of every block as the oracle has it -- on the first call, where the arrays hold
+    garbage, and on later ones (cracks.cc:2754, 2770, 2918: the caller reads the host storage right after the call)."""
+    c = box_case(3, (9, 6, 12), -10.0, 10.0, blocked)
+    r, rp, ci = oracle(c, False)
+    ctx = make_context(c)
+    n = ctx.n_owned_dofs
+    values = [np.full(ctx.pattern_size(b)[1], -7.0e77) for b in range(ctx.n_blocks)]
+    res_pde, res_tot = np.full(n, -7.0e77), np.full(n, -7.0e77)
+    if registered:
+        for a in values + [res_pde, res_tot]:
+            ctx.host_register(a)
+    for rep in range(2):
+        sol = c.sol if rep == 0 else c.sol * (1.0 + 1e-3)
+        ref = r if rep == 0 else O.assemble(c.mesh, c.layout, c.params, sol, c.old, c.oldold, c.cu, c.ch, False, rp, ci)
+        ctx.assemble_host(sol, c.old, c.oldold, False, out=(values, res_pde, None))
+        A = blocks_to_global(ctx, c.layout, values)
+        A.sort_indices()
+        A_ref = sp.csr_matrix((ref.values, ci, rp), shape=A.shape)
+        assert (A.indptr == A_ref.indptr).all() and (A.indices == A_ref.indices).all()
+        assert np.abs(A.data).max() < 1e70 and linf_scaled(A.data, A_ref.data) < TOL
+        assert linf_scaled(res_pde, ref.residual_pde) < TOL
+        if blocked:
+            assert not values[1].any()  # (u,phi) = 0, cracks.cc:2333-2337
+    ctx.assemble_host(c.sol, c.old, c.oldold, True, out=(None, res_pde, res_tot))
+    ro = O.assemble(c.mesh, c.layout, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, True)
+    assert linf_scaled(res_pde, ro.residual_pde) < TOL and linf_scaled(res_tot, ro.residual_total) < TOL
+    if registered:
+        ctx.host_unregister(values[0])
+        ctx.host_unregister()
+    ctx.close()

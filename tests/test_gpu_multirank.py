@@ -267,6 +267,10 @@ def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra
     many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                 "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(world)] + common)
     assert many["n_gpus"] == world and one["n_gpus"] == 1
+    # gloo smoke run: no RCCL communicator exists, and the line says so (on an N-GPU box the fields carry ncclCommCount /
+    # ncclGetVersion of the communicator the exchange ran on: test_bench_two_gpus_over_rccl)
+    assert "rccl_nranks" in many and many["rccl_nranks"] is None and many["rccl_version"] is None
+    assert "rccl_nranks" not in one
     # what the driver's SCALE record needs beside the value: the cut, the measured ghost import, and -- where the headline
     # cut is z-slabs -- the same steps on the near-cubic grid a p4est host would hand over
     assert many["config"]["partition"] and many["config"]["peers"] >= 1 and many["exchange_ms"] > 0.0
@@ -324,6 +328,7 @@ def test_bench_two_gpus_over_rccl():
     one = _bench_json([sys.executable, "bench.py", "--gpus", "1"] + common, env)
     two = _bench_json([sys.executable, "bench.py", "--gpus", "2"] + common, env)
     assert two["n_gpus"] == 2
+    assert two["rccl_nranks"] == 2 and two["rccl_version"] >= 20000  # what RCCL itself counted on the exchange's communicator
     a, b = np.array(one["checksum"]), np.array(two["checksum"])
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
     assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)
@@ -347,6 +352,7 @@ def test_bench_more_gpus_over_rccl_subcubes(world, grid):
     one = _bench_json([sys.executable, "bench.py", "--gpus", "1"] + common, env)
     many = _bench_json([sys.executable, "bench.py", "--gpus", str(world)] + common, dict(env, PFM_BENCH_GRID=grid))
     assert many["n_gpus"] == world and many["config"]["partition"] == grid.replace(",", "x") and many["exchange_ms"] > 0.0
+    assert many["rccl_nranks"] == world
     a, b = np.array(one["checksum"]), np.array(many["checksum"])
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)
     assert (np.abs(a - b) <= 1e-11 * np.maximum(scale, 1e-300)).all(), (a, b)

@@ -134,6 +134,54 @@ def test_split_at_exactly_diagonal_and_zero_strain_reproduces_the_ieee_pattern()
     ctx.close()
 
 
+def test_split_with_subnormal_shear_strain_follows_the_reference_arithmetic():
+    """E_01 subnormal next to equally tiny E_00, E_11 (not caught by the 'diagonal' test of cracks.cc:1700-1710).
+    The reference DIVIDES (lambda_i - E_00) / E_01 -- an ordinary number -- where a reciprocal of E_01 alone overflows to
+    inf and turns the eigenvectors into NaN.  In the reference arithmetic the discriminant underflows to zero here, both
+    eigenvalues coincide, the two eigenvectors are equal and the orthogonality check fails (abort(), cracks.cc:1732-1736):
+    the library must arrive at the same verdict, PFM_ERR_NOT_ORTHOGONAL -- with NaN eigenvectors it would have passed the
+    check (NaN > 1e-6 is false) and returned NaN rows.  A second cell set with a subnormal E_01 but ordinary E_00, E_11 is
+    'diagonal' for both arithmetics and must agree entry by entry."""
+    s0, a, b = 2.0 ** -1060, 2.0 ** -1062, 2.0 ** -1063
+    lin = lambda exx, exy, eyx, eyy: [[0.0, 0.0], [exx, eyx], [exy, eyy], [exx + exy, eyx + eyy]]
+    rng = np.random.default_rng(5)
+    cu_ch = lambda mesh, lay: (M.update_constraints(mesh, lay, []), M.hanging_constraints(mesh, lay))
+
+    def case(U):
+        mesh, lay, u = _loose_cells(U)
+        sol = lay.pack(u, rng.uniform(0.3, 0.9, mesh.n_nodes))
+        old = lay.pack(0 * u, rng.uniform(0.3, 0.9, mesh.n_nodes))
+        cu, ch = cu_ch(mesh, lay)
+        return cases.Case("subnormal", mesh, lay, _miehe_params(), sol, old, old.copy(), cu, ch)
+
+    # (i) everything tiny: the reference aborts, the library reports
+    c = case([lin(a, s0, s0, b), lin(a, s0, s0, -b)])
+    r, _, _ = _oracle(c, True)
+    assert r.err != 0, "reference arithmetic: coinciding eigenvalues, equal eigenvectors, abort()"
+    ctx = make_context(c)
+    with pytest.raises(capi.PfmError) as e:
+        ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    assert e.value.status == 3  # PFM_ERR_NOT_ORTHOGONAL
+    ctx.close()
+    # (ii) subnormal shear next to ordinary normal strains: the near-diagonal shortcut in both arithmetics
+    c = case([lin(2.0 ** -9, s0, s0, -(2.0 ** -11)), lin(2.0 ** -9, 2.0 ** -10, 2.0 ** -10, -(2.0 ** -11))])
+    ctx = make_context(c)
+    for residual_only in (True, False):
+        r, rp, ci = _oracle(c, residual_only)
+        assert r.err == 0
+        values, res, _ = ctx.assemble_host(c.sol, c.old, c.oldold, residual_only)
+        pairs = [(res, r.residual_pde)]
+        if not residual_only:
+            A = sp.csr_matrix((values[0],) + ctx.pattern(0)[::-1], shape=(c.layout.n_dofs,) * 2)
+            pairs.append((A.data, sp.csr_matrix((r.values, ci, rp), shape=A.shape).data))
+        for got, want in pairs:
+            assert (np.isnan(got) == np.isnan(want)).all() and (np.isinf(got) == np.isinf(want)).all()
+            fin = np.isfinite(want)
+            assert np.abs(got[fin] - want[fin]).max() < 1e-12 * max(1.0, np.abs(want[fin]).max())
+    ctx.sync_status()
+    ctx.close()
+
+
 def test_not_orthogonal_status_instead_of_abort():
     """|E_01| in (1, 1.3) x 1e-10 |E_00| with E_11 = 0.9 .. 0.95 E_00: the 'not close to diagonal' branch loses
     (lambda - E_00) to cancellation and v_1 . v_2 exceeds 1e-6 in about one q-point out of ten (numpy experiment in

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """One-off robustness run on the GPU box: (1) 200 Jacobian assemblies of the 3-D Sneddon 216^3 bench problem must
 leave bit-identical outputs and a stable amount of free device memory; (2) 60 context create/destroy cycles on a
-40^3 box must give the memory back.  `python tools/stress.py 64 general`: the same box forced onto the general family."""
+40^3 box must give the memory back.  `python tools/stress.py 64 general`: the same box forced onto the general family.
+`python tools/stress.py 24 hanging`: a 3-D box with a refined block (hanging nodes on its faces and edges): the cells at
+hanging vertices form the ATOMIC class of the general family (FP64 atomic adds, no fixed order) -- 100 assemblies, reports
+whether the outputs are bitwise equal run to run and, if not, the largest deviation relative to the row's largest entry."""
 import os
 import sys
 
@@ -31,6 +34,36 @@ def main():
         return a
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 216
+    if len(sys.argv) > 2 and sys.argv[2] == "hanging":
+        g0 = M.box_mesh(3, (n,) * 3)
+        c = g0.coords[g0.cells].mean(axis=1)
+        g = M.refine_cells(g0, (np.abs(c) < 5.0).all(axis=1))  # the inner block one level down
+        h = (20.0 / n) * np.sqrt(3.0) / 2
+        u, phi, po, poo, flags = bench.synthetic_state(g, np.arange(g.n_nodes), h, 3)
+        flags[g.hn_nodes] = 0
+        a = Assembler(g, blocked=True)
+        a.set_params(bench.sneddon_params(h, 3))
+        a.set_constraints(flags)
+        pack = lambda uu, pp: np.concatenate([uu.reshape(-1), pp])
+        a.set_vectors(pack(u, phi), pack(0 * u, po), pack(0 * u, poo))
+        a.assemble_system(False)
+        a.synchronize()
+        ref = [m.clone() for m in a.system_pde_matrix] + [a.system_pde_residual.clone()]
+        worst, differing = 0.0, 0
+        for it in range(100):
+            for m in a.system_pde_matrix:
+                m.fill_(float(it))
+            a.assemble_system(False)
+            a.synchronize()
+            for x, y in zip(ref, list(a.system_pde_matrix) + [a.system_pde_residual]):
+                if not torch.equal(x, y):
+                    differing += 1
+                    worst = max(worst, float(((x - y).abs().max() / x.abs().max().clamp_min(1e-300)).item()))
+        print(f"general family with hanging nodes ({g.n_cells} cells, {g.hn_nodes.size} hanging nodes, kernel path {a.ctx.kernel_path}): "
+              f"100 assemblies, {differing} output arrays differed from the first run, largest deviation {worst:.2e} of the array's "
+              f"largest entry" + (" (bitwise reproducible)" if differing == 0 else " (atomic class: bounded, not bitwise)"))
+        assert worst < 1e-13
+        return
     a = problem(n)
     if len(sys.argv) > 2 and sys.argv[2] == "general":  # python tools/stress.py 64 general: the colour classes of the general family
         a.ctx.force_path(0)
