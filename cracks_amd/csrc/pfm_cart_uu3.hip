@@ -194,23 +194,48 @@ namespace pfm
       return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
     }
 
-    // row component C of slot set W for both half-waves, from the cached table values: 28 FMAs, the cross-half adds of
+    // lower half-wave: x[l] + x[l + 32]; upper half-wave: y[l - 32] + y[l] -- the sums over the two cell layers of TWO values
+    // for the price of one (two lane swaps + one add): each half keeps the sum it stages
+    __device__ __forceinline__ double pair_sum_across_halves(double x, double y)
+    {
+      const auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+      return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    }
+    // staged position (in slots) of slot sl of set W with oz <= 0
+    __host__ __device__ constexpr int slot_pos_of(int W, int sl)
+    {
+      for (int v = 0; v < 4; ++v)
+        {
+          const Vis vi = visit_of(W, v);
+          if (vi.slot == sl)
+            return (vi.ox + 1) + 3 * (vi.oy + 1) + 9 * (vi.oz + 1);
+        }
+      return -1;
+    }
+
+    // row component C of slot set W for both half-waves, from the cached table values: 28 FMAs, the cross-half sums of
     // the oz = 0 slots, the constraint masks, 3 staged values per slot.  stage_half = the lane's staged row shifted by 18
     // slots for the upper half (a slot with oz = -1 completed by the lower half is slot o_lo, its mirror completed by the
-    // upper half is o_lo + 18); oz = 0 slots are summed over the halves and stored by both (same value, same address).
+    // upper half is o_lo + 18).  The entries of the oz = 0 slots are the sums of both halves' parts: they are summed in
+    // PAIRS (round 5: pair_sum_across_halves; the phase clock showed the set of the four oz = 0 corner slots -- twelve
+    // single sums of five instructions each per component -- 1.7k cycles behind the barrier of a phase whose lightest sets
+    // need 0.6k), the lower half stages the first entry of a pair and the upper half the second.
     // RES: also returns (in every lane of the node) this slot set's part of  sum_j K[(node,C),(j,d)] u_(j,d)  over the
     // UNMASKED entries -- the displacement residual is  R_u = (alpha_B-1) p sum_q pfx^2 dN/dx_C JxW - K_uu u  for the
-    // unsplit law (sigma+ is linear in u; cracks.cc:2393-2410 against 2340-2368)
+    // unsplit law (sigma+ is linear in u; cracks.cc:2393-2410 against 2340-2368); the products are formed with each half's
+    // own part and summed once
     template <int W, int C, bool MASKED, bool HET, bool RES>
     __device__ __forceinline__ double uu_row_component(const double (&tv)[4][9], const UuCoef &K, const double (&lamv)[4],
                                                        const double (&muv)[4], double *__restrict__ stage_row,
-                                                       double *__restrict__ stage_half, unsigned row_flag,
+                                                       double *__restrict__ stage_half, bool upper, unsigned row_flag,
                                                        const unsigned char *__restrict__ flag_own,
                                                        const unsigned char *__restrict__ flag_half,
                                                        const double *__restrict__ u_own, const double *__restrict__ u_half)
     {
-      double dot_plane = 0.0, dot_half = 0.0;
+      double dot = 0.0;
       constexpr int NS = nslots_of(W);
+      constexpr bool PLANE = (W == 0 || W == 2 || W == 3 || W == 6); // the slots of the set have oz = 0
       double val[NS][3];
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl)
@@ -227,21 +252,11 @@ namespace pfm
         constexpr Vis vi = visit_of(W, V);
         if constexpr (vi.last)
           {
-            double v0 = val[vi.slot][0], v1 = val[vi.slot][1], v2 = val[vi.slot][2];
-            if constexpr (vi.oz == 0)
-              {
-                v0 = add_across_halves(v0);
-                v1 = add_across_halves(v1);
-                v2 = add_across_halves(v2);
-              }
+            double &v0 = val[vi.slot][0], &v1 = val[vi.slot][1], &v2 = val[vi.slot][2];
             if constexpr (RES)
               {
                 const double *un = (vi.oz == 0 ? u_own : u_half) + (vi.ox + H3X * vi.oy);
-                const double part = fma(v2, un[2 * NR3], fma(v1, un[NR3], v0 * un[0]));
-                if constexpr (vi.oz == 0)
-                  dot_plane += part; // the same value in both halves
-                else
-                  dot_half += part;
+                dot += fma(v2, un[2 * NR3], fma(v1, un[NR3], v0 * un[0]));
               }
             if constexpr (MASKED)
               {
@@ -255,18 +270,39 @@ namespace pfm
                 if (rcon || (cf & 4u))
                   v2 = (rcon && centre && C == 2) ? v2 : 0.0;
               }
-            constexpr int o_lo = (vi.ox + 1) + 3 * (vi.oy + 1) + 9 * (vi.oz + 1);
-            double *dst = (vi.oz == 0 ? stage_row : stage_half) + o_lo * 3;
-            dst[0] = v0;
-            dst[1] = v1;
-            dst[2] = v2;
+            if constexpr (!PLANE)
+              {
+                constexpr int o_lo = (vi.ox + 1) + 3 * (vi.oy + 1) + 9 * (vi.oz + 1);
+                double *dst = stage_half + o_lo * 3;
+                dst[0] = v0;
+                dst[1] = v1;
+                dst[2] = v2;
+              }
           }
       });
-      if constexpr (RES)
+      if constexpr (PLANE)
         {
-          constexpr bool has_half = !(W == 0 || W == 2 || W == 3 || W == 6);
-          return has_half ? add_across_halves(dot_half) : dot_plane;
+          if constexpr (NS == 1)
+            {
+              constexpr int o = slot_pos_of(W, 0);
+              double *dst = stage_row + o * 3;
+              dst[upper ? 1 : 0] = pair_sum_across_halves(val[0][0], val[0][1]);
+              dst[2] = add_across_halves(val[0][2]); // both halves: the same value to the same address
+            }
+          else
+            {
+              constexpr int delta = slot_pos_of(W, 1) - slot_pos_of(W, 0);
+              static_assert(NS == 2 || slot_pos_of(W, NS - 1) - slot_pos_of(W, NS - 2) == delta, "one stride for all slot pairs of a set");
+              double *dst = stage_row + (upper ? delta * 3 : 0);
+#pragma unroll
+              for (int sp = 0; sp < NS / 2; ++sp)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  dst[slot_pos_of(W, 2 * sp) * 3 + k] = pair_sum_across_halves(val[2 * sp][k], val[2 * sp + 1][k]);
+            }
         }
+      if constexpr (RES)
+        return add_across_halves(dot);
       else
         return 0.0;
     }
@@ -351,7 +387,18 @@ namespace pfm
       (void)args_in_kernarg_segment;
       long long tclk = 0;
       unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      unsigned long long acc6[4] = {0, 0, 0, 0}; // wave 6: wait for the requests, landing, requests, -
+      unsigned long long acc6[4] = {0, 0, 0, 0}; // wave 7: wait for the requests, landing, requests, -
+      unsigned long long accc[4] = {0, 0, 0, 0}; // per wave, component 1: copy-out of component 0 | arithmetic | wait at the barrier
+      long long tclkc = 0;
+      auto stampc = [&](int phase) __attribute__((always_inline)) {
+        if constexpr (CLK)
+          {
+            const long long now = clock64();
+            if (phase >= 0)
+              accc[phase] += (unsigned long long)(now - tclkc);
+            tclkc = now;
+          }
+      };
       long long tclk6 = 0;
       auto stamp6 = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK)
@@ -988,12 +1035,12 @@ namespace pfm
 #define PFM_COMPONENT(C, ST)                                                                                                 \
   if (masked)                                                                                                                \
     {                                                                                                                        \
-      PFM_PER_SET((ku = uu_row_component<W, C, true, HET, RES>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half, \
+      PFM_PER_SET((ku = uu_row_component<W, C, true, HET, RES>(tv, K, lamv, muv, ST, ST + hs, upper, row_flag, flag_own, flag_half, \
                                                                u_own, u_half)))                                             \
     }                                                                                                                        \
   else                                                                                                                       \
     {                                                                                                                        \
-      PFM_PER_SET((ku = uu_row_component<W, C, false, HET, RES>(tv, K, lamv, muv, ST, ST + hs, row_flag, flag_own, flag_half, \
+      PFM_PER_SET((ku = uu_row_component<W, C, false, HET, RES>(tv, K, lamv, muv, ST, ST + hs, upper, row_flag, flag_own, flag_half, \
                                                                 u_own, u_half)))                                            \
     }
             PFM_COMPONENT(0, st0)
@@ -1002,10 +1049,14 @@ namespace pfm
             PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
               uu_load_visit<W, decltype(Vv)::value, 4>(lane_base, tv[decltype(Vv)::value]); // T^yz, behind the copy-out
             }))
+            stampc(-1);
             part_store(0);
             copy_out(0, s_stage);
+            stampc(0);
             PFM_COMPONENT(1, st1)
+            stampc(1);
             lds_barrier();
+            stampc(2);
             stamp(4);
             PFM_PER_SET(static_for<4>([&](auto Vv) __attribute__((always_inline)) {
               uu_load_visit<W, decltype(Vv)::value, 2>(lane_base, tv[decltype(Vv)::value]); // T^xz again
@@ -1034,10 +1085,18 @@ namespace pfm
         {
           if (threadIdx.x == 0)
             for (int i = 0; i < 8; ++i)
-              uu_args().dbg[(size_t)blockIdx.x * 16 + i] = acc[i];
+              uu_args().dbg[(size_t)blockIdx.x * 32 + i] = acc[i];
           if (threadIdx.x == 448)
             for (int i = 0; i < 4; ++i)
-              uu_args().dbg[(size_t)blockIdx.x * 16 + 8 + i] = acc6[i];
+              uu_args().dbg[(size_t)blockIdx.x * 32 + 8 + i] = acc6[i];
+          if (threadIdx.x == 0)
+            for (int i = 0; i < 4; ++i)
+              uu_args().dbg[(size_t)blockIdx.x * 32 + 12 + i] = accc[i];
+          if ((threadIdx.x & 63) == 0) // every wave: copy-out and arithmetic of component 1
+            {
+              uu_args().dbg[(size_t)blockIdx.x * 32 + 16 + 2 * (threadIdx.x >> 6)] = accc[0];
+              uu_args().dbg[(size_t)blockIdx.x * 32 + 17 + 2 * (threadIdx.x >> 6)] = accc[1];
+            }
         }
     }
 #undef UU_ENV
@@ -1081,7 +1140,7 @@ namespace pfm
       {
         static unsigned long long *d_dbg = nullptr;
         static size_t nd_cap = 0;
-        const size_t nd = (size_t)xcd_grid(nb) * 16;
+        const size_t nd = (size_t)xcd_grid(nb) * 32;
         if (nd > nd_cap)
           {
             if (d_dbg)
@@ -1098,9 +1157,9 @@ namespace pfm
           hipLaunchKernelGGL((k_cart_uu3<3, true>), grid, block, 0, s, ka);
         std::vector<unsigned long long> hall(nd);
         (void)hipMemcpy(hall.data(), d_dbg, nd * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        unsigned long long h[16] = {};
+        unsigned long long h[32] = {};
         for (size_t i = 0; i < nd; ++i)
-          h[i % 16] += hall[i];
+          h[i % 32] += hall[i];
         const char *names[8] = {"top barrier", "w*g", "moments", "tables+node c0", "copy c0+node c1", "copy c1+node c2",
                                 "copy c2+landing", "prologue loads (per chunk)"};
         const double planes = (double)ntx * nty * OWZ;
@@ -1109,6 +1168,12 @@ namespace pfm
           fprintf(stderr, " %s=%.0f", names[i], (double)h[i] / (i == 7 ? (double)nb : planes));
         fprintf(stderr, " | wave 7: wait for the requests=%.0f landing=%.0f requests=%.0f\n", (double)h[8] / planes, (double)h[9] / planes,
                 (double)h[10] / planes);
+        fprintf(stderr, "[k_cart_uu3 phase clock] wave 0, component 1: copy-out of component 0=%.0f arithmetic=%.0f barrier=%.0f\n", (double)h[12] / planes,
+                (double)h[13] / planes, (double)h[14] / planes);
+        fprintf(stderr, "[k_cart_uu3 phase clock] component 1 per wave (copy-out of component 0 / arithmetic):");
+        for (int w = 0; w < 8; ++w)
+          fprintf(stderr, " W%d %.0f/%.0f", w, (double)h[16 + 2 * w] / planes, (double)h[17 + 2 * w] / planes);
+        fprintf(stderr, "\n");
       }
     else if (il)
       {
