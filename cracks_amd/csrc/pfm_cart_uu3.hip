@@ -579,18 +579,22 @@ namespace pfm
           // they requested one step ago: waves 6, 7 plane k + 2 (nodes [32 (wave - 6), +32) of the plane) into the ring slot
           // of plane k - 2 -- their requests for plane k + 3 follow in the moment phase --, wave 5 the rows of plane k, and
           // requests those of plane k + 1 at once.  vmcnt counts loads and stores in order: since their requests these waves
-          // have issued exactly 5 copy-out stores per row component on a regular tile (their sixth position lies outside the
-          // tile), so vmcnt(15) waits for the requests and never for the stores of the last step
+          // have issued a known number of copy-out stores on a regular tile (copy_out), so vmcnt(that number) waits for the
+          // requests and never for the stores of the last step
           if (wave >= 5)
             {
               UU_ENV();
               if (it > 0)
                 {
                   stamp6(-1);
-                  if (regular_prev)
-                    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                  else
+                  // stores of this wave since its requests, on a regular tile: at least 2 per row component in waves 5, 6
+                  // (their third position lies outside the tile), 3 in wave 7 (two pair stores, the single values)
+                  if (!regular_prev)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                  else if (wave == 7)
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                  else
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                   stamp6(0);
                 }
               if (wave >= 6 && it > 0 && more)
@@ -906,29 +910,43 @@ namespace pfm
               double *__restrict__ vals = A.vals;
               if (regular_tile)
                 {
-                  // thread <-> (node group g, element el) with el fixed: nodes g, g + 6, ..., g + 30 -- no division per
-                  // position, one row-base read and one value read per node, all of them in flight before the first store (a
-                  // loop pays two dependent LDS round trips of ~130 cycles per iteration); threads 486..511 idle
-                  constexpr int NG = 6, NIT = (NN3 + NG - 1) / NG;
+                  // Round 5: 16-byte stores.  A workgroup's copy-out is bound by how fast the CU's store path takes
+                  // instructions (tools/microbench/stw.hip: ~16 cycles per 512-byte instruction, 1.45x the bytes per cycle
+                  // with 16 bytes per lane), and since the barrier of a component waits for the copy-out of the last one in
+                  // EVERY wave, that time is on the critical path of the plane (phase clock: 1.3k of the 3.4k cycles of a
+                  // component).  thread <-> (node group g < 12, element pair ep < 40): nodes g, g + 12, g + 24, the pairs
+                  // (2 ep, 2 ep + 1) of their 81 staged values; threads 480..511: the 81st value of node t - 480.  No
+                  // division per position, every read in flight before the first store.
+                  struct __attribute__((packed, aligned(8))) D2
+                  {
+                    double a, b;
+                  };
+                  constexpr int NG = 12, NIT = 3;
                   int tq = t;
-                  asm volatile("" : "+v"(tq)); // (g, el) are recomputed per component, not kept live across the node phases
-                  const int g = tq / STG, el = tq - g * STG;
-                  if (g < NG)
+                  asm volatile("" : "+v"(tq)); // (g, ep) are recomputed per component, not kept live across the node phases
+                  if (tq < NG * 40)
                     {
+                      const int g = tq / 40, ep = tq - g * 40;
                       long long rb[NIT];
-                      double val[NIT];
+                      D2 val[NIT];
 #pragma unroll
                       for (int i = 0; i < NIT; ++i)
                         {
                           const int nl = min(g + NG * i, NN3 - 1);
                           rb[i] = rowbase[nl];
-                          val[i] = stage[nl * STG + el];
+                          val[i].a = lds_read64(stage + nl * STG + 2 * ep);
+                          val[i].b = lds_read64(stage + nl * STG + 2 * ep + 1);
                         }
                       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                       for (int i = 0; i < NIT; ++i)
                         if (g + NG * i < NN3)
-                          vals[rb[i] + (c * STG + el)] = val[i];
+                          *reinterpret_cast<D2 *>(vals + rb[i] + (c * STG + 2 * ep)) = val[i];
+                    }
+                  else
+                    {
+                      const int nl = tq - NG * 40;
+                      vals[rowbase[nl] + (c * STG + STG - 1)] = stage[nl * STG + STG - 1];
                     }
                 }
               else
