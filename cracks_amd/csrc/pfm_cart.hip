@@ -76,6 +76,7 @@ namespace pfm
       // uniform constants of residual_cell_poly, formed on the host so that they arrive in scalar registers
       double ih[3], vol, vih[3], geih[3]; // 1 / h_k, h_x h_y h_z, vol / h_k, G_c eps vol / h_k^2
       double c_g, c_pd, c_r2, c_r3;       // 1 - kappa, (alpha_B - 1) p, -2 (alpha_B - 1) p, G_c / eps
+      double c_pdg, c_pdk;                // c_pd / c_g, c_pd kappa / c_g: the pressure term through the moments of g (residual_cell_poly)
     };
 
     Scal make_scal(const pfm_params &prm, const CartView &cv, int dim)
@@ -111,6 +112,8 @@ namespace pfm
         }
       s.c_g = 1.0 - s.kappa;
       s.c_pd = s.aB1 * s.p;
+      s.c_pdg = s.c_pd / s.c_g;
+      s.c_pdk = s.c_pd * s.kappa / s.c_g;
       s.c_r2 = -2.0 * s.aB1 * s.p;
       s.c_r3 = s.Gc / s.eps;
       return s;
@@ -578,7 +581,7 @@ namespace pfm
     __device__ __forceinline__ void residual_cell_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const Scal &S,
                                                        double lam, double mu, double (&M)[2][2][2][4])
     {
-      const double c_g = S.c_g, c_pd = S.c_pd, c_r2 = S.c_r2, c_r3 = S.c_r3, vol = S.vol;
+      const double c_g = S.c_g, c_r2 = S.c_r2, c_r3 = S.c_r3, vol = S.vol;
       const double(&ih)[3] = S.ih;
       const double(&vih)[3] = S.vih;
       auto load8 = [&](int f, double (&a)[8]) __attribute__((always_inline)) {
@@ -590,7 +593,11 @@ namespace pfm
         M[psi & 1][(psi >> 1) & 1][psi >> 2][c] += x;
       };
       // ---------------- discrete moments of pfx^2 (HP) and of g (Hg) against t^p s^q r^r, p, q, r = 0..2
-      double Hg[27], HP8[8]; // HP8: the moments of pfx^2 against the multilinear monomials (pressure term)
+      // The pressure term -(alpha_B-1) p pfx^2 delta_ck needs the moments of pfx^2 against the multilinear monomials: they are
+      // those of g, H_g[m] = c_g H_P[m] + kappa I_m, so the term is (c_pd / c_g)(kappa I_m - H_g[m]) -- folded into the
+      // constant coefficient of sigma_cc below.  (Round 4 kept the eight H_P next to H_g: 16 of the 22 registers the
+      // kernel spilled, each reload a scratch load and a vmcnt(0) in the middle of the evaluation.)
+      double Hg[27];
       {
         double W[8];
         load8(4, W); // LIN: the combined old field (load_plane)
@@ -638,8 +645,6 @@ namespace pfm
           const double hp = GqWt<0, rp>::v * A2[pp + 3 * qp] + GqWt<1, rp>::v * A2[pp + 3 * qp + 9] + GqWt<2, rp>::v * A2[pp + 3 * qp + 18];
           constexpr double Im = GqMom<pp>::v * GqMom<qp>::v * GqMom<rp>::v;
           Hg[m] = fma(c_g, hp, S.kappa * Im);
-          if constexpr (pp < 2 && qp < 2 && rp < 2)
-            HP8[pp + 2 * qp + 4 * rp] = hp;
         });
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -717,7 +722,12 @@ namespace pfm
                 }
             });
             if constexpr (c == k)
-              val = fma(-c_pd, HP8[midx], val); // - (alpha_B - 1) p pfx^2 delta_ck
+              {
+                // - (alpha_B - 1) p pfx^2 delta_ck = (c_pd / c_g) (kappa I - H_g) against the monomial midx
+                constexpr int m0 = pow_of(0, midx);
+                constexpr double Im0 = GqMom<m0 % 3>::v * GqMom<(m0 / 3) % 3>::v * GqMom<m0 / 9>::v;
+                val = fma(-S.c_pdg, Hg[m0], fma(S.c_pdk, Im0, val));
+              }
             Madd(std::integral_constant<int, (1 << k) | midx>{}, Cc, vih[k] * val);
           });
         });
@@ -862,49 +872,69 @@ namespace pfm
       const double ihx = 1.0 / cv.h[0], ihy = 1.0 / cv.h[1], ihz = 1.0 / cv.h[2];
       const double vol = cv.h[0] * cv.h[1] * cv.h[2];
 
-      auto load_plane = [&](int kz, int buf) __attribute__((always_inline)) {
-        for (int idx = t; idx < RHX * RHY; idx += RTX * RTY)
-          {
-            const int hx = idx % RHX, hy = idx / RHX;
-            const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
-            double val[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
-              {
-                const int n = cart_local_id3(cv, gi, gj, kz);
-                if (v.fused_solution) // kernel argument: uniform branch.  Single rank: every node is an owned node
-                  {
-                    const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
-                    const double *su = v.fused_solution + (il ? 4LL * n : 3LL * n);
-                    val[0] = su[0];
-                    val[1] = su[1];
-                    val[2] = su[2];
-                    val[3] = il ? su[3] : v.fused_solution[3LL * v.n_owned + n];
-                    // the node state is what pfm_state_set_solution would have left: every node is written once, by the
-                    // tile and z-chunk that own it
-                    if (hx >= 1 && hx <= RNX && hy >= 1 && hy <= RNY && kz >= kA && kz < kB)
-                      {
-                        v.u[0][n] = val[0];
-                        v.u[1][n] = val[1];
-                        v.u[2][n] = val[2];
-                        v.phi[n] = val[3];
-                      }
-                  }
-                else
-                  {
-                    val[0] = v.u[0][n];
-                    val[1] = v.u[1][n];
-                    val[2] = v.u[2][n];
-                    val[3] = v.phi[n];
-                  }
-                val[4] = v.phi_old[n];
-                val[5] = v.phi_oldold[n];
-                if constexpr (LIN)
-                  val[4] = S.use_old ? val[4] : val[5] + S.tfac * (val[4] - val[5]);
-              }
+      // nodal plane kz -> ring slot buf.  The 17 x 17 halo nodes are 289 > 256 threads: threads 0..32 fetch a second node.  Both
+      // fetches are in flight before the first LDS store (round 5; as a loop the second fetch started after the first one's
+      // values had arrived: two global round trips in wave 0 -- behind which the whole workgroup waits at the barrier of
+      // every step)
+      auto fetch_node = [&](int kz, int idx, double (&val)[6], int &n_pub) __attribute__((always_inline)) {
+        const int hx = idx % RHX, hy = idx / RHX;
+        const int gi = i0 - 1 + hx, gj = j0 - 1 + hy;
 #pragma unroll
-            for (int f = 0; f < (LIN ? 5 : 6); ++f)
-              s_U[buf][f][idx] = val[f];
+        for (int f = 0; f < 6; ++f)
+          val[f] = 0.0;
+        n_pub = -1;
+        if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
+          {
+            const int n = cart_local_id3(cv, gi, gj, kz);
+            if (v.fused_solution) // kernel argument: uniform branch.  Single rank: every node is an owned node
+              {
+                const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
+                const double *su = v.fused_solution + (il ? 4LL * n : 3LL * n);
+                val[0] = su[0];
+                val[1] = su[1];
+                val[2] = su[2];
+                val[3] = il ? su[3] : v.fused_solution[3LL * v.n_owned + n];
+                // the node state is what pfm_state_set_solution would have left: every node is written once, by the
+                // tile and z-chunk that own it (publish_node, behind the fetches)
+                if (hx >= 1 && hx <= RNX && hy >= 1 && hy <= RNY && kz >= kA && kz < kB)
+                  n_pub = n;
+              }
+            else
+              {
+                val[0] = v.u[0][n];
+                val[1] = v.u[1][n];
+                val[2] = v.u[2][n];
+                val[3] = v.phi[n];
+              }
+            val[4] = v.phi_old[n];
+            val[5] = v.phi_oldold[n];
           }
+      };
+      auto store_node = [&](int buf, int idx, double (&val)[6], int n_pub) __attribute__((always_inline)) {
+        if (n_pub >= 0)
+          {
+            v.u[0][n_pub] = val[0];
+            v.u[1][n_pub] = val[1];
+            v.u[2][n_pub] = val[2];
+            v.phi[n_pub] = val[3];
+          }
+        if constexpr (LIN)
+          val[4] = S.use_old ? val[4] : val[5] + S.tfac * (val[4] - val[5]);
+#pragma unroll
+        for (int f = 0; f < (LIN ? 5 : 6); ++f)
+          s_U[buf][f][idx] = val[f];
+      };
+      auto load_plane = [&](int kz, int buf) __attribute__((always_inline)) {
+        static_assert(RHX * RHY <= 2 * RTX * RTY, "two nodes per thread at most");
+        double va[6], vb[6];
+        int na, nb = -1;
+        const int ib = t + RTX * RTY;
+        fetch_node(kz, t, va, na);
+        if (ib < RHX * RHY)
+          fetch_node(kz, ib, vb, nb);
+        store_node(buf, t, va, na);
+        if (ib < RHX * RHY)
+          store_node(buf, ib, vb, nb);
       };
 
       // Accumulators in the moment basis of the trilinear test functions: along every direction index 0 stands for
