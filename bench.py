@@ -338,6 +338,10 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
     except Exception as e:
         out["general_family_3d"] = {"error": f"{type(e).__name__}: {e}"}
     try:
+        out["overlay_3d"] = overlay_3d(dev, local_rank, steps)
+    except Exception as e:
+        out["overlay_3d"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
         out["config5_standin"] = config5_standin(dev, local_rank, steps)
     except Exception as e:  # a missing mesh helper must not take the other lines away
         out["config5_standin"] = {"error": f"{type(e).__name__}: {e}"}
@@ -373,6 +377,45 @@ def general_family_3d(dev, local_rank, steps: int, n: int = 100):
         wall, k_ms = time_mode(a, dev, ro, max(3, steps // 2), 2)
         rec[key] = {"ms_per_call": wall, "kernel_ms": k_ms, "DoFs_per_s": n_dofs / (wall * 1e-3),
                     "hbm_frac": algorithmic_bytes_per_cell(3, ro) * n_cells / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
+    a.ctx.close()
+    return rec
+
+
+def overlay_3d(dev, local_rank, steps: int, n: int = 84):
+    """A 3-D AMR mesh (cracks.cc:3895-4163 refine_mesh is dimension independent; tests/hetero_3d_1.prm): the Sneddon box
+    of `n`^3 hexes with its inner half refined once -- hanging nodes on the faces and edges of the block.  The regular rows
+    of both refinement levels are written by the cartesian row-owner kernels on the level lattices (kernel path 3), the
+    general family keeps the cells at hanging nodes, level seams and the boundary; next to it the same mesh through the
+    general family alone (`pfm_ctx_force_path(0)`)."""
+    from cracks_amd import mesh as M
+    from cracks_amd.assembler import Assembler
+
+    t0 = time.perf_counter()
+    g0 = M.box_mesh(3, (n,) * 3)
+    cc = g0.coords[g0.cells].mean(axis=1)
+    mesh = M.refine_cells(g0, (np.abs(cc) < 5.0).all(axis=1))
+    t_mesh = time.perf_counter() - t0
+    h = (20.0 / n) * np.sqrt(3.0) / 2
+    u, phi, po, poo, flags = synthetic_state(mesh, np.arange(mesh.n_nodes), h, 3)
+    flags[mesh.hn_nodes] = 0
+    a = Assembler(mesh, blocked=True, device=local_rank)
+    a.set_params(sneddon_params(h, 3))
+    a.set_constraints(flags)
+    pack = lambda uu, pp: np.concatenate([uu.reshape(-1), pp])
+    a.set_vectors(pack(u, phi), pack(0 * u, po), pack(0 * u, poo))
+    rows, general_cells = a.ctx.overlay_info()
+    rec = {"workload": f"Sneddon 3D, {n}^3 hexes with the inner half refined once: {mesh.n_cells} cells, {mesh.n_nodes} nodes, "
+                       f"{mesh.hn_nodes.size} hanging nodes", "cells": mesh.n_cells, "kernel_path": a.ctx.kernel_path,
+           "regular_rows": rows, "regular_row_fraction": rows / mesh.n_nodes, "cells_left_to_the_general_family": general_cells,
+           "ctx_create_s": round(a.ctx.create_seconds, 3), "mesh_build_s_python": round(t_mesh, 1)}
+    n_dofs = 4 * mesh.n_nodes
+    for tag, path in (("overlay", None), ("general_family_alone", 0)):
+        if path is not None:
+            a.ctx.force_path(path)
+        for key, ro in (("jacobian", False), ("residual_only", True)):
+            wall, k_ms = time_mode(a, dev, ro, max(3, steps // 2), 2)
+            rec[f"{tag}_{key}"] = {"ms_per_call": wall, "kernel_ms": k_ms, "ns_per_cell": 1e6 * k_ms / mesh.n_cells, "DoFs_per_s": n_dofs / (wall * 1e-3),
+                                   "hbm_frac": algorithmic_bytes_per_cell(3, ro) * mesh.n_cells / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None}
     a.ctx.close()
     return rec
 

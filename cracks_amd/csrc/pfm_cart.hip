@@ -883,9 +883,9 @@ namespace pfm
         for (int f = 0; f < 6; ++f)
           val[f] = 0.0;
         n_pub = -1;
-        if (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ)
+        const int n = (gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ) ? cart_local_id3(cv, gi, gj, kz) : -1;
+        if (n >= 0) // (-1 inside the lattice: a level lattice of the 3-D overlay has no node there)
           {
-            const int n = cart_local_id3(cv, gi, gj, kz);
             if (v.fused_solution) // kernel argument: uniform branch.  Single rank: every node is an owned node
               {
                 const bool il = v.layout == PFM_LAYOUT_INTERLEAVED;
@@ -1159,9 +1159,12 @@ namespace pfm
                 }
             }
           __syncthreads();
-          if (emit && node_ok)
+          // (CartView::row_of_box: the rows of this launch; -1 = the row belongs to the general family)
+          const int row = (emit && node_ok) ? (cv.row_of_box ? cv.row_of_box[(i0 + cx) + (long long)cv.NX * ((j0 + cy) + (long long)cv.NY * ck)]
+                                                             : cart_local_id3(cv, i0 + cx, j0 + cy, ck))
+                                            : -1;
+          if (row >= 0)
             {
-              const int row = cart_local_id3(cv, i0 + cx, j0 + cy, ck);
               const unsigned fl = v.node_flags[row];
 #pragma unroll
               for (int c = 0; c < 4; ++c)

@@ -45,6 +45,24 @@ namespace pfm
       return id;
     }
 
+    // row of lattice node (i,j,k) in this launch, -1: none (CartView::row_of_box)
+    __device__ __forceinline__ int cart_row_id(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.row_of_box)
+        return cv.row_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+      return cart_local_id(cv, i, j, k);
+    }
+    __device__ __forceinline__ int cart_row_id_sync(const CartView &cv, int i, int j, int k)
+    {
+      if (cv.row_of_box)
+        {
+          int id = cv.row_of_box[i + (long long)cv.NX * (j + (long long)cv.NY * k)];
+          asm volatile("" : "+v"(id));
+          return id;
+        }
+      return cart_local_id_sync(cv, i, j, k);
+    }
+
     // x += v on an LDS double, done by the LDS unit (ds_add_f64, no return value): one LDS instruction and no
     // read -> wait -> add -> write round trip.  Used where a wave's lanes hit distinct addresses and the order of
     // the adds is the program order of that wave, so the result is the same as a plain read-modify-write.

@@ -912,7 +912,9 @@ namespace pfm
         ok = role < 3 && inside && kz >= 0 && kz < cv.NZ && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY;
         if (lex)
           return ok ? lex_id(gi, gj, kz) : 0u;
-        return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0u;
+        const int id = ok ? cart_local_id(cv, gi, gj, kz) : -1;
+        ok = id >= 0; // (a level lattice of the 3-D overlay holds -1 where the level has no node: neutral values)
+        return ok ? (unsigned)id : 0u;
       };
       auto dma_plane_at = [&](unsigned n, bool ok, bool inside, int dw, int buf, int kz) __attribute__((always_inline)) {
         if (role < 3)
@@ -948,7 +950,9 @@ namespace pfm
         ok = role == 3 && lq < NPN && gi <= cv.o1[0] && gj <= cv.o1[1];
         if (lex)
           return ok ? lex_id(gi, gj, kz) : 0xffffffffu;
-        return ok ? (unsigned)cart_local_id(cv, gi, gj, kz) : 0xffffffffu;
+        const int id = ok ? cart_row_id(cv, gi, gj, kz) : -1; // (CartView::row_of_box: -1 = not a row of this launch)
+        ok = id >= 0;
+        return (unsigned)id;
       };
       auto dma_rows_at = [&](unsigned n, bool ok, int kz) __attribute__((always_inline)) {
         const int par = kz & 1;
@@ -1102,8 +1106,8 @@ namespace pfm
                             {
                               // rare path (a constrained row next to a cell with a vanishing diagonal): straight from memory
                               const int id = cart_local_id(cv, cio + (b & 1), cjo + ((b >> 1) & 1), ck + (b >> 2));
-                              po[b] = v.phi_old[id];
-                              poo[b] = v.phi_oldold[id];
+                              po[b] = id >= 0 ? v.phi_old[id] : 0.0; // (-1: no node of this level's lattice, 3-D overlay)
+                              poo[b] = id >= 0 ? v.phi_oldold[id] : 0.0;
                             }
                         }
                       // sum_{a,c} K_uu[(a,c),(a,c)] = sum_k (sum_c cA[c][k]) 2 sum_q w g mu(q_i) mu(q_j), mu = m_00 + m_11

@@ -327,6 +327,7 @@ namespace pfm
       unsigned raw_flag[128];          // [2 hn]: the node's flag byte, zero-extended
       long long raw_row[NN3];          // nadj_ptr of the next plane's rows (wave 7)
       unsigned raw_mask[2 * NN3];      // [2 nl]: both lanes of a row fetch its mask
+      int raw_rid[NN3];                // the row ids themselves (-1: no row of this launch)
       double tab[TABSZ3];              // moment tables (layout: tab_off3); layer 1 stored z-mirrored.  Dead once every wave holds
                                        // its table values: [0, NN3 STG) = second staging buffer, behind it the partial sums of
                                        // the residual rows (RES)
@@ -459,10 +460,11 @@ namespace pfm
             const int gi = i0 - 1 + li, gj = j0 - 1 + lj, gk = kA - 1 + lk;
             double a = 0.0, b = 0.0, uu[3] = {0.0, 0.0, 0.0};
             unsigned char f = 0;
-            const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ;
+            bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && gk >= 0 && gk < cv.NZ;
+            const int n = in ? cart_local_id(cv, gi, gj, gk) : -1;
+            in = n >= 0; // (a level lattice of the overlay holds -1 where the level has no node)
             if (in)
               {
-                const int n = cart_local_id(cv, gi, gj, gk);
                 a = v.phi_old[n];
                 b = v.phi_oldold[n];
                 f = v.node_flags[n];
@@ -506,9 +508,9 @@ namespace pfm
             const int gi = i0 + li, gj = j0 + lj;
             long long base = -1;
             unsigned mask = 0u;
-            if (gi <= cv.o1[0] && gj <= cv.o1[1])
+            const int r = (gi <= cv.o1[0] && gj <= cv.o1[1]) ? cart_row_id(cv, gi, gj, kA) : -1;
+            if (r >= 0)
               {
-                const int r = cart_local_id(cv, gi, gj, kA);
                 base = (long long)NCOL * NCOL * v.nadj_ptr[r];
                 mask = cv.nbr_mask[r];
                 if constexpr (RES)
@@ -599,29 +601,23 @@ namespace pfm
                 }
               if (wave >= 6 && it > 0 && more)
                 {
-                  const int kz = k + 2;
                   const int hn = 32 * (wave - 6) + lane;
                   bool fl = false;
                   if (lane < 32 && hn < NHP3)
                     {
-                      const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
-                      const bool in = gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
-                      double a = 0.0, b = 0.0;
-                      unsigned f = 0;
-                      if (in)
-                        {
-                          a = sh.raw_po[hn];
-                          b = sh.raw_poo[hn];
-                          f = sh.raw_flag[2 * hn];
-                          if (!S.monolithic)
-                            a = S.use_old ? a : b + S.tfac * (a - b);
-                        }
+                      // (absent nodes: the requesting lanes left zeros and the marker bit 8 of the flag word)
+                      double a = sh.raw_po[hn], b = sh.raw_poo[hn];
+                      unsigned f = sh.raw_flag[2 * hn];
+                      const bool in = (f & 0x100u) == 0;
+                      f &= 0xffu;
+                      if (!S.monolithic)
+                        a = S.use_old ? a : b + S.tfac * (a - b);
                       const int d = s3 * NHP3 + hn;
                       if constexpr (RES)
                         {
 #pragma unroll
                           for (int c = 0; c < 3; ++c)
-                            sh.u[(RES ? c * NR3 : 0) + d] = in ? sh.raw_u[RES ? c : 0][hn] : 0.0;
+                            sh.u[(RES ? c * NR3 : 0) + d] = sh.raw_u[RES ? c : 0][hn];
                         }
                       else
                         sh.poo[RES ? 0 : d] = b;
@@ -641,17 +637,11 @@ namespace pfm
                       unsigned mask = 0x7ffffffu;
                       if (lane < NN3)
                         {
-                          const int li = lane % T3X, lj = lane / T3X;
-                          const int gi = i0 + li, gj = j0 + lj;
-                          long long base = -1;
-                          mask = 0u;
-                          if (gi <= cv.o1[0] && gj <= cv.o1[1])
-                            {
-                              base = (long long)NCOL * NCOL * sh.raw_row[lane];
-                              mask = sh.raw_mask[2 * lane];
-                              if constexpr (RES)
-                                sh.resrow[par][lane] = cart_local_id_sync(cv, gi, gj, k);
-                            }
+                          const long long off = sh.raw_row[lane];
+                          const long long base = off < 0 ? -1 : (long long)NCOL * NCOL * off;
+                          mask = sh.raw_mask[2 * lane];
+                          if constexpr (RES)
+                            sh.resrow[par][lane] = sh.raw_rid[lane];
                           sh.rowbase[par][lane] = base;
                           sh.mask[par][lane] = mask;
                         }
@@ -664,13 +654,20 @@ namespace pfm
                     {
                       const int nl = lane >> 1, li = nl % T3X, lj = nl / T3X;
                       const int gi = i0 + li, gj = j0 + lj;
-                      const bool in = gi <= cv.o1[0] && gj <= cv.o1[1];
-                      const unsigned r = in ? (unsigned)cart_local_id_sync(cv, gi, gj, k + 1) : 0u;
-                      if (in)
+                      const int rid = (gi <= cv.o1[0] && gj <= cv.o1[1]) ? cart_row_id_sync(cv, gi, gj, k + 1) : -1;
+                      const unsigned r = (unsigned)rid;
+                      if (rid >= 0)
                         {
                           dma_b32(v.nadj_ptr, 8u * r + 4u * (lane & 1), reinterpret_cast<uint32_t *>(sh.raw_row));
                           dma_b32(cv.nbr_mask, 4u * r, sh.raw_mask);
                         }
+                      else
+                        {
+                          reinterpret_cast<uint32_t *>(sh.raw_row)[lane] = 0xffffffffu; // -1: no row of this launch
+                          sh.raw_mask[lane] = 0u;
+                        }
+                      if (!(lane & 1))
+                        sh.raw_rid[nl] = rid;
                     }
                 }
               if (it > 0)
@@ -843,8 +840,24 @@ namespace pfm
                         const int kz = k + 3;
                         const int hn = 32 * (wave - 6) + (lane >> 1);
                         const int gi = i0 - 1 + hn % H3X, gj = j0 - 1 + hn / H3X;
-                        const bool in = hn < NHP3 && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
-                        const unsigned n = in ? (unsigned)cart_local_id_sync(cv, gi, gj, kz) : 0u; // (a looked-up id is waited for in its arm)
+                        bool in = hn < NHP3 && gi >= 0 && gi < cv.NX && gj >= 0 && gj < cv.NY && kz >= 0 && kz < cv.NZ;
+                        const int id = in ? cart_local_id_sync(cv, gi, gj, kz) : -1; // (a looked-up id is waited for in its arm)
+                        in = id >= 0;
+                        const unsigned n = (unsigned)id;
+                        if (!in && hn < NHP3)
+                          {
+                            // no such node (outside the mesh / not a node of this level): the lane writes the neutral values itself
+                            const int dw = 64 * (wave - 6) + lane;
+                            reinterpret_cast<uint32_t *>(sh.raw_po)[dw] = 0u;
+                            reinterpret_cast<uint32_t *>(sh.raw_poo)[dw] = 0u;
+                            if constexpr (RES)
+                              {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                  reinterpret_cast<uint32_t *>(sh.raw_u[RES ? c : 0])[dw] = 0u;
+                              }
+                            sh.raw_flag[dw] = 0x100u; // bit 8: absent
+                          }
                         if (in)
                           {
                             const unsigned boff = 8u * n + 4u * (lane & 1);

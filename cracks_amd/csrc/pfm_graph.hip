@@ -217,4 +217,53 @@ namespace pfm
       (void)hipFree(sc.inc);
     sc = GraphScratch{};
   }
+
+  // ---- cartesian overlay of a general 3-D mesh (round 5): row tables of one refinement level's lattice --------------------
+  // node_at / row_at: node id / row id per lattice point of the level's box (-1: none).  For every row r of the level:
+  // nbr_mask[r] = all 27 offsets exist, the row is not in lattice order (bit 31); row_perm[nadj_ptr[r] + o] = CSR slot of
+  // the node at lattice offset o in the CURRENT order of the node-graph row (pfm_ctx_create: ascending local id;
+  // pfm_pattern_bind: the caller's).  A row that is not a plain 27-neighbour row of the level raises the status word.
+  namespace
+  {
+    __global__ void k_overlay3_rows(const int32_t *__restrict__ node_at, const int32_t *__restrict__ row_at, int NX, int NY, int NZ,
+                                    const long long *__restrict__ nadj_ptr, const int32_t *__restrict__ nadj, uint32_t *__restrict__ nbr_mask,
+                                    uint8_t *__restrict__ row_perm, int *__restrict__ bad)
+    {
+      const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (p >= (long long)NX * NY * NZ)
+        return;
+      const int r = row_at[p];
+      if (r < 0)
+        return;
+      const int i = (int)(p % NX), j = (int)((p / NX) % NY), k = (int)(p / ((long long)NX * NY));
+      const long long base = nadj_ptr[r];
+      const int deg = (int)(nadj_ptr[r + 1] - base);
+      bool ok = deg == 27 && i > 0 && i < NX - 1 && j > 0 && j < NY - 1 && k > 0 && k < NZ - 1;
+      for (int o = 0; o < 27 && ok; ++o)
+        {
+          const int q = node_at[(i + o % 3 - 1) + (long long)NX * ((j + (o / 3) % 3 - 1) + (long long)NY * (k + o / 9 - 1))];
+          int slot = -1;
+          for (int t = 0; t < 27; ++t)
+            if (nadj[base + t] == q)
+              slot = t;
+          ok = q >= 0 && slot >= 0;
+          if (ok)
+            row_perm[base + o] = (uint8_t)slot;
+        }
+      nbr_mask[r] = ok ? 0x87ffffffu : 0u;
+      if (!ok)
+        atomicAdd(bad, 1);
+    }
+  } // namespace
+
+  int launch_overlay3_rows(const int32_t *d_node_at, const int32_t *d_row_at, int NX, int NY, int NZ, const long long *d_nadj_ptr,
+                           const int32_t *d_nadj, uint32_t *d_nbr_mask, uint8_t *d_row_perm, int *d_bad, hipStream_t s)
+  {
+    const long long n = (long long)NX * NY * NZ;
+    if (n == 0)
+      return PFM_OK;
+    hipLaunchKernelGGL(k_overlay3_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_node_at, d_row_at, NX, NY, NZ, d_nadj_ptr, d_nadj,
+                       d_nbr_mask, d_row_perm, d_bad);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
 } // namespace pfm

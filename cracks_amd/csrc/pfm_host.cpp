@@ -929,6 +929,309 @@ namespace
     c->patch_slots_valid = false;
   }
 
+  // ---- cartesian overlay of a general 3-D mesh (round 5) -------------------------------------------------------------------
+  // The same classification as in 2-D (plan_patches2d), with the row-owner kernels of the CARTESIAN family as the "patch
+  // kernel": every cell that is an exact axis-parallel box belongs to the lattice of its size (a refinement level); a node
+  // is REGULAR when it is owned, neither hanging nor a parent, has exactly eight incident cells, all of one level and at
+  // the eight lattice positions around it, and none of the 27 lattice nodes around it is hanging -- its rows are then the
+  // plain 27-point rows of a uniform box of that level.  Per level one lattice (CartView) over the bounding box of its
+  // regular nodes plus a one-node halo: node_at = the node at each lattice point (-1: none of this level), row_at = the
+  // regular nodes.  k_cart_uu3 / k_cart_phi4 / k_cart_residual3 run on it as on a box and write exactly the rows of row_at;
+  // cells that do not exist at a lattice position contribute only to rows that are not regular, i.e. to nothing that is
+  // written.  The general family keeps the cells that touch any other row (reduced colour lists) and skips the regular rows.
+  struct Level3
+  {
+    double h[3] = {0, 0, 0};
+    long long lo[3] = {0, 0, 0}; // lattice position of the box's first node
+    int dims[3] = {0, 0, 0};     // nodes of the box
+    std::vector<int32_t> node_at, row_at;
+    std::vector<double> lam, mu; // per lattice cell (heterogeneous material), else empty
+    int64_t n_rows = 0;
+  };
+  struct PatchPlan3
+  {
+    std::vector<uint8_t> regular, hang;
+    std::vector<int32_t> rows_general;
+    std::vector<Level3> levels;
+    int64_t n_regular = 0;
+  };
+  PatchPlan3 plan_patches3d(const pfm_mesh_desc *m, const std::vector<int32_t> &hn_index)
+  {
+    PatchPlan3 pl;
+    const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
+    const int64_t NC = m->n_cells;
+    if (m->dim != 3 || NC == 0 || getenv("PFM_NO_PATCH"))
+      return pl;
+    const double *X = m->coords;
+    double xmin[3] = {X[0], X[1], X[2]}, xmax[3] = {X[0], X[1], X[2]};
+    for (int32_t n = 0; n < N; ++n)
+      for (int d = 0; d < 3; ++d)
+        {
+          xmin[d] = std::min(xmin[d], X[3 * (size_t)n + d]);
+          xmax[d] = std::max(xmax[d], X[3 * (size_t)n + d]);
+        }
+    const double tol = 1e-9 * std::max(xmax[0] - xmin[0], std::max(xmax[1] - xmin[1], xmax[2] - xmin[2]));
+    double amax = 0.0;
+    for (int d = 0; d < 3; ++d)
+      amax = std::max(amax, std::max(std::fabs(xmin[d]), std::fabs(xmax[d])));
+    const double geo_tol = 16.0 * 2.220446049250313e-16 * amax;
+    struct Lv
+    {
+      double h[3];
+    };
+    std::vector<Lv> lv;
+    std::vector<int8_t> cell_level((size_t)NC, -1);
+    std::vector<long long> cpos((size_t)NC * 3, 0);
+    for (int64_t k = 0; k < NC; ++k)
+      {
+        const int32_t *cn = m->cell_nodes + 8 * k;
+        const double *p0 = X + 3 * (size_t)cn[0], *p7 = X + 3 * (size_t)cn[7];
+        const double h[3] = {p7[0] - p0[0], p7[1] - p0[1], p7[2] - p0[2]};
+        bool box = h[0] > tol && h[1] > tol && h[2] > tol;
+        // an axis-parallel box in deal.II's vertex order, up to the rounding of the vertex positions (the kernels take
+        // J = diag(h)): the midpoints a refinement creates are means of 2, 4 or 8 parents and agree only to a few ulp
+        // unless the coordinates are dyadic
+        for (int a = 0; a < 8 && box; ++a)
+          {
+            const double *pa = X + 3 * (size_t)cn[a];
+            box = std::fabs(pa[0] - ((a & 1) ? p7[0] : p0[0])) <= geo_tol && std::fabs(pa[1] - ((a & 2) ? p7[1] : p0[1])) <= geo_tol &&
+                  std::fabs(pa[2] - ((a & 4) ? p7[2] : p0[2])) <= geo_tol;
+          }
+        if (!box)
+          continue;
+        int L = -1;
+        for (size_t l = 0; l < lv.size(); ++l)
+          if (std::fabs(lv[l].h[0] - h[0]) <= 1e-9 * h[0] && std::fabs(lv[l].h[1] - h[1]) <= 1e-9 * h[1] && std::fabs(lv[l].h[2] - h[2]) <= 1e-9 * h[2])
+            L = (int)l;
+        if (L < 0)
+          {
+            if (lv.size() >= 100)
+              continue;
+            lv.push_back(Lv{{h[0], h[1], h[2]}});
+            L = (int)lv.size() - 1;
+          }
+        bool on = true;
+        for (int d = 0; d < 3; ++d)
+          {
+            const double f = (p0[d] - xmin[d]) / lv[L].h[d];
+            const long long i = std::llround(f);
+            on = on && std::fabs(f - (double)i) <= 1e-6;
+            cpos[3 * (size_t)k + d] = i;
+          }
+        if (on)
+          cell_level[k] = (int8_t)L;
+      }
+    if (lv.empty())
+      return pl;
+    // incident cells per node: count, common level, the 8 cells by the vertex the node is of them
+    std::vector<uint8_t> n_inc((size_t)N, 0), is_parent((size_t)N, 0);
+    std::vector<int8_t> node_level((size_t)N, -2);
+    std::vector<int32_t> inc((size_t)N * 8, -1);
+    for (int64_t k = 0; k < NC; ++k)
+      for (int a = 0; a < 8; ++a)
+        {
+          const int32_t n = m->cell_nodes[8 * k + a];
+          if (n_inc[n] < 255)
+            ++n_inc[n];
+          const int8_t L = cell_level[k];
+          node_level[n] = (node_level[n] == -2) ? L : (node_level[n] == L ? L : (int8_t)-1);
+          inc[(size_t)n * 8 + a] = (inc[(size_t)n * 8 + a] == -1) ? (int32_t)k : -2;
+        }
+    if (m->n_hanging > 0)
+      for (int64_t j = 0; j < m->hn_ptr[m->n_hanging]; ++j)
+        is_parent[m->hn_parents[j]] = 1;
+    auto hanging = [&](int32_t n) { return !hn_index.empty() && hn_index[n] >= 0; };
+    std::vector<uint8_t> regular((size_t)N, 0);
+    std::vector<long long> npos((size_t)N * 3, 0);
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        if (n_inc[n] != 8 || node_level[n] < 0 || hanging(n) || is_parent[n])
+          continue;
+        bool ok = true;
+        const int32_t k7 = inc[(size_t)n * 8 + 0]; // the cell of which n is vertex 0 sits AT the node's lattice position
+        ok = k7 >= 0;
+        long long pn[3] = {0, 0, 0};
+        if (ok)
+          for (int d = 0; d < 3; ++d)
+            pn[d] = cpos[3 * (size_t)k7 + d];
+        for (int a = 0; a < 8 && ok; ++a)
+          {
+            const int32_t k = inc[(size_t)n * 8 + a];
+            ok = k >= 0;
+            if (!ok)
+              break;
+            // the cell of which n is vertex a lies at pn - (a_x, a_y, a_z)
+            ok = cpos[3 * (size_t)k] == pn[0] - (a & 1) && cpos[3 * (size_t)k + 1] == pn[1] - ((a >> 1) & 1) && cpos[3 * (size_t)k + 2] == pn[2] - (a >> 2);
+            for (int b = 0; b < 8 && ok; ++b)
+              ok = !hanging(m->cell_nodes[8 * (size_t)k + b]);
+          }
+        if (ok)
+          {
+            regular[n] = 1;
+            for (int d = 0; d < 3; ++d)
+              npos[3 * (size_t)n + d] = pn[d];
+          }
+      }
+    // per level: the box of its regular nodes + halo, the tables
+    static const long long max_table = getenv("PFM_OVERLAY3_MAX_TABLE") ? atoll(getenv("PFM_OVERLAY3_MAX_TABLE")) : 400000000LL;
+    static const long long min_rows = getenv("PFM_OVERLAY3_MIN_ROWS") ? atoll(getenv("PFM_OVERLAY3_MIN_ROWS")) : 64;
+    for (size_t L = 0; L < lv.size(); ++L)
+      {
+        long long lo[3] = {LLONG_MAX, LLONG_MAX, LLONG_MAX}, hi[3] = {LLONG_MIN, LLONG_MIN, LLONG_MIN};
+        int64_t cnt = 0;
+        for (int32_t n = 0; n < NO; ++n)
+          if (regular[n] && node_level[n] == (int8_t)L)
+            {
+              ++cnt;
+              for (int d = 0; d < 3; ++d)
+                {
+                  lo[d] = std::min(lo[d], npos[3 * (size_t)n + d]);
+                  hi[d] = std::max(hi[d], npos[3 * (size_t)n + d]);
+                }
+            }
+        const double vol = cnt ? (double)(hi[0] - lo[0] + 3) * (double)(hi[1] - lo[1] + 3) * (double)(hi[2] - lo[2] + 3) : 0.0;
+        if (cnt < min_rows || vol > (double)max_table || vol > 64.0 * (double)cnt)
+          {
+            // too few rows, or a box that is mostly empty (a thin refined band): these rows stay with the general family
+            for (int32_t n = 0; n < NO; ++n)
+              if (regular[n] && node_level[n] == (int8_t)L)
+                regular[n] = 0;
+            continue;
+          }
+        Level3 lev;
+        for (int d = 0; d < 3; ++d)
+          {
+            lev.h[d] = lv[L].h[d];
+            lev.lo[d] = lo[d] - 1;
+            lev.dims[d] = (int)(hi[d] - lo[d] + 3);
+          }
+        const long long NX = lev.dims[0], NY = lev.dims[1], NZ = lev.dims[2];
+        lev.node_at.assign((size_t)(NX * NY * NZ), -1);
+        lev.row_at.assign((size_t)(NX * NY * NZ), -1);
+        const bool het = m->cell_lambda && m->cell_mu;
+        if (het)
+          {
+            lev.lam.assign((size_t)((NX - 1) * (NY - 1) * (NZ - 1)), 0.0);
+            lev.mu.assign((size_t)((NX - 1) * (NY - 1) * (NZ - 1)), 0.0);
+          }
+        bool clash = false;
+        for (int64_t k = 0; k < NC; ++k)
+          if (cell_level[k] == (int8_t)L)
+            {
+              const long long ci = cpos[3 * (size_t)k] - lev.lo[0], cj = cpos[3 * (size_t)k + 1] - lev.lo[1], ck = cpos[3 * (size_t)k + 2] - lev.lo[2];
+              if (ci < 0 || ci >= NX - 1 || cj < 0 || cj >= NY - 1 || ck < 0 || ck >= NZ - 1)
+                continue;
+              for (int a = 0; a < 8; ++a)
+                {
+                  int32_t &slot = lev.node_at[(size_t)((ci + (a & 1)) + NX * ((cj + ((a >> 1) & 1)) + NY * (ck + (a >> 2))))];
+                  const int32_t n = m->cell_nodes[8 * (size_t)k + a];
+                  if (slot == -1)
+                    slot = n;
+                  else if (slot != n)
+                    clash = true; // two nodes at one lattice position (a slit): not a mesh for this overlay
+                }
+              if (het)
+                {
+                  lev.lam[(size_t)(ci + (NX - 1) * (cj + (NY - 1) * ck))] = m->cell_lambda[k];
+                  lev.mu[(size_t)(ci + (NX - 1) * (cj + (NY - 1) * ck))] = m->cell_mu[k];
+                }
+            }
+        if (clash)
+          {
+            for (int32_t n = 0; n < NO; ++n)
+              if (regular[n] && node_level[n] == (int8_t)L)
+                regular[n] = 0;
+            continue;
+          }
+        for (int32_t n = 0; n < NO; ++n)
+          if (regular[n] && node_level[n] == (int8_t)L)
+            {
+              const long long i = npos[3 * (size_t)n] - lev.lo[0], j = npos[3 * (size_t)n + 1] - lev.lo[1], kk = npos[3 * (size_t)n + 2] - lev.lo[2];
+              lev.row_at[(size_t)(i + NX * (j + NY * kk))] = n;
+              ++lev.n_rows;
+            }
+        pl.levels.push_back(std::move(lev));
+      }
+    if (pl.levels.empty())
+      return pl;
+    for (int32_t n = 0; n < NO; ++n)
+      {
+        pl.n_regular += regular[n];
+        if (!regular[n])
+          pl.rows_general.push_back(n);
+      }
+    pl.hang.assign((size_t)N, 0);
+    for (int32_t n = 0; n < N; ++n)
+      pl.hang[n] = hanging(n) ? 1 : 0;
+    pl.regular.swap(regular);
+    return pl;
+  }
+
+  // context part: reduced colour lists of the general family, uploads of the level lattices
+  void finish_patches3d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan3 &pl, const std::vector<int32_t> &order)
+  {
+    DevView &v = c->v;
+    const int32_t NO = m->n_owned_nodes;
+    const int64_t NC = m->n_cells;
+    if (pl.levels.empty())
+      return;
+    std::vector<uint8_t> need((size_t)NC, 0);
+    for (int64_t k = 0; k < NC; ++k)
+      for (int a = 0; a < 8; ++a)
+        {
+          const int32_t n = m->cell_nodes[8 * k + a];
+          if (pl.hang[n] || (n < NO && !pl.regular[n]))
+            need[k] = 1;
+        }
+    std::vector<int32_t> order_red;
+    c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
+    for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
+      {
+        c->color_ptr_reduced[cl] = (long long)order_red.size();
+        for (long long i = c->color_ptr[cl]; i < c->color_ptr[cl + 1]; ++i)
+          if (need[order[(size_t)i]])
+            order_red.push_back(order[(size_t)i]);
+      }
+    c->color_ptr_reduced.back() = (long long)order_red.size();
+    c->n_general_cells = (int64_t)order_red.size();
+    if (order_red.empty())
+      order_red.push_back(0);
+    v.row_patch = dev_upload(c, pl.regular.data(), pl.regular.size());
+    c->d_color_cells_reduced = dev_upload(c, order_red.data(), order_red.size());
+    c->n_rows_general = (int32_t)pl.rows_general.size();
+    if (pl.rows_general.empty())
+      pl.rows_general.push_back(0);
+    c->d_rows_general = dev_upload(c, pl.rows_general.data(), pl.rows_general.size());
+    c->n_patch_rows = pl.n_regular;
+    for (Level3 &lev : pl.levels)
+      {
+        pfm_ctx::OverlayLevel ol;
+        CartView &cv = ol.cv;
+        cv.NX = lev.dims[0];
+        cv.NY = lev.dims[1];
+        cv.NZ = lev.dims[2];
+        for (int d = 0; d < 3; ++d)
+          {
+            cv.o0[d] = 1; // the rows of the launch lie inside the halo
+            cv.o1[d] = lev.dims[d] - 2;
+            cv.h[d] = lev.h[d];
+          }
+        cv.local_of_box = dev_upload(c, lev.node_at.data(), lev.node_at.size());
+        cv.row_of_box = dev_upload(c, lev.row_at.data(), lev.row_at.size());
+        cv.owned_lex = 0;
+        cv.cell_lam = cv.cell_mu = nullptr;
+        if (!lev.lam.empty())
+          {
+            cv.cell_lam = dev_upload(c, lev.lam.data(), lev.lam.size());
+            cv.cell_mu = dev_upload(c, lev.mu.data(), lev.mu.size());
+          }
+        ol.d_scal = dev_alloc<unsigned char>(c, PFM_SCAL_BYTES);
+        ol.n_rows = lev.n_rows;
+        c->levels3.push_back(ol);
+      }
+    c->overlay3_rows_valid = false;
+  }
+
   struct PhaseClock
   {
     const bool on = getenv("PFM_CTX_TIMING") != nullptr;
@@ -1132,11 +1435,15 @@ extern "C"
           colour_thread = std::thread(colour_classes);
         // cartesian overlay of a 2-D mesh: the host classification (8 ms at 2.7e5 cells) on its own thread as well
         PatchPlan patch_plan;
+        PatchPlan3 patch_plan3;
         std::exception_ptr patch_err;
         auto plan_patches = [&]() {
           try
             {
-              patch_plan = plan_patches2d(m, hn_index);
+              if (dim == 2)
+                patch_plan = plan_patches2d(m, hn_index);
+              else if (!lattice_ok) // (a uniform 3-D box takes the cartesian family as a whole; no stress split in 3-D)
+                patch_plan3 = plan_patches3d(m, hn_index);
             }
           catch (...)
             {
@@ -1144,7 +1451,7 @@ extern "C"
             }
         };
         std::thread patch_thread;
-        if (dim == 2 && NC > 65536)
+        if (NC > 65536)
           patch_thread = std::thread(plan_patches);
         struct Joiner
         {
@@ -1255,7 +1562,8 @@ extern "C"
         if (patch_err)
           std::rethrow_exception(patch_err);
         finish_patches2d(c, m, patch_plan, order);
-        clk.mark("cartesian overlay (2-D)");
+        finish_patches3d(c, m, patch_plan3, order);
+        clk.mark("cartesian overlay");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
           {
@@ -1330,7 +1638,7 @@ extern "C"
       {
         return hipfail(c, f.e, f.what);
       }
-    c->kernel_path = c->cart_ok ? 1 : (c->n_patch_blocks > 0 ? 3 : 0); // 3: general family + cartesian overlay (2-D)
+    c->kernel_path = c->cart_ok ? 1 : ((c->n_patch_blocks > 0 || !c->levels3.empty()) ? 3 : 0); // 3: general family + cartesian overlay
     return PFM_OK;
   }
 
@@ -1407,6 +1715,8 @@ extern "C"
     c->prm = *p;
     c->have_params = true;
     c->scal_dirty = true; // the per-launch scalar tables of the cartesian Jacobian kernels follow the parameters
+    for (auto &lv : c->levels3)
+      lv.scal_dirty = true;
     return PFM_OK;
   }
 
@@ -1585,6 +1895,7 @@ extern "C"
                     hipMemcpy(const_cast<int32_t *>(c->v.nadj), c->h_nadj.data(), c->h_nadj.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
                   throw HipFail{hipGetLastError(), "hipMemcpy nadj"};
                 c->patch_slots_valid = false; // the regular rows' slots follow the bound order
+                c->overlay3_rows_valid = false;
                 if (launch_build_cslot(c->v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
                   throw HipFail{hipGetLastError(), "cslot kernel"};
               }
@@ -2139,6 +2450,57 @@ extern "C"
     return PFM_OK;
   }
 
+  // 3-D overlay: neighbour masks and CSR slots of the regular rows from the current order of the node-graph rows
+  static int ensure_overlay3_ready(pfm_ctx *c)
+  {
+    if (c->levels3.empty() || c->overlay3_rows_valid)
+      return PFM_OK;
+    try
+      {
+        ensure_general_tables(c); // v.nadj
+        if (!c->d_nbr_mask3)
+          {
+            c->d_nbr_mask3 = dev_alloc<uint32_t>(c, (size_t)std::max<int32_t>(c->v.n_owned, 1));
+            c->d_row_perm3 = dev_alloc<uint8_t>(c, (size_t)std::max<long long>(c->h_nadj_ptr.empty() ? 1 : c->h_nadj_ptr.back(), 1));
+          }
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
+      }
+    catch (const std::bad_alloc &)
+      {
+        return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+      }
+    int *d_bad = nullptr;
+    if (hipMalloc((void **)&d_bad, sizeof(int)) != hipSuccess)
+      return fail(c, PFM_ERR_NOMEM, "overlay row tables");
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), c->stream);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(c->d_nbr_mask3, 0, sizeof(uint32_t) * (size_t)std::max<int32_t>(c->v.n_owned, 1), c->stream);
+    int rc = e == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+    for (auto &lv : c->levels3)
+      if (rc == PFM_OK)
+        rc = launch_overlay3_rows(lv.cv.local_of_box, lv.cv.row_of_box, lv.cv.NX, lv.cv.NY, lv.cv.NZ, c->v.nadj_ptr, c->v.nadj, c->d_nbr_mask3,
+                                  c->d_row_perm3, d_bad, c->stream);
+    int bad = 0;
+    if (rc == PFM_OK && (hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                         hipStreamSynchronize(c->stream) != hipSuccess))
+      rc = PFM_ERR_HIP;
+    (void)hipFree(d_bad);
+    if (rc)
+      return fail(c, rc, "overlay row tables");
+    if (bad != 0)
+      return fail(c, PFM_ERR_INTERNAL, "3-D overlay: a regular row is not a plain 27-neighbour row of its level");
+    for (auto &lv : c->levels3)
+      {
+        lv.cv.nbr_mask = c->d_nbr_mask3;
+        lv.cv.row_perm = c->d_row_perm3;
+      }
+    c->overlay3_rows_valid = true;
+    return PFM_OK;
+  }
+
   // phase 2 of pfm_assemble_overlapped launches only the tiles that read ghost nodes: their indices, once per context
   static int ensure_overlap_lists(pfm_ctx *c)
   {
@@ -2201,10 +2563,11 @@ extern "C"
     const bool overlay_uu = c->kernel_path == 2 && !residual_only && !split; // debug: general + cart (u,u)
     // cartesian overlay of a general 2-D mesh (AMR meshes; stress-split runs on a lattice): patch kernel for the regular rows,
     // the general family for the rest (PFM_NO_PATCH=1 at context creation: general family alone)
-    const bool patches = !cart && c->v.dim == 2 && c->n_patch_blocks > 0 && c->kernel_path != 0 && phase != 1;
+    const bool overlay3 = !cart && c->v.dim == 3 && !c->levels3.empty() && c->kernel_path != 0 && phase != 1 && !split;
+    const bool patches = (!cart && c->v.dim == 2 && c->n_patch_blocks > 0 && c->kernel_path != 0 && phase != 1) || overlay3;
     if (patches)
       {
-        const int rcp = ensure_patch_ready(c);
+        const int rcp = overlay3 ? ensure_overlay3_ready(c) : ensure_patch_ready(c);
         if (rcp)
           return rcp;
       }
@@ -2337,7 +2700,23 @@ extern "C"
         // the patch kernel: every regular row is written once, with plain stores; next to it (side stream) the general
         // family over the cells that touch a non-regular row (it skips the regular ones: DevView::row_patch), its classes one
         // after the other
-        rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks, c->stream);
+        rc = PFM_OK;
+        if (overlay3)
+          {
+            // the row-owner kernels of the cartesian family on every level lattice, one after the other on the stream
+            for (auto &lv : c->levels3)
+              {
+                if (rc == PFM_OK && !residual_only && lv.scal_dirty)
+                  {
+                    rc = upload_mat_scal(c->prm, lv.cv, lv.d_scal, c->stream);
+                    lv.scal_dirty = rc != PFM_OK;
+                  }
+                if (rc == PFM_OK)
+                  rc = launch_assemble_cart(c->v, lv.cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->stream, lv.d_scal, 0);
+              }
+          }
+        else
+          rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks, c->stream);
         pfm::DevView vg = c->v;
         vg.color_cells = c->d_color_cells_reduced;
         if (rc == PFM_OK && c->n_general_cells > 0)
@@ -2732,7 +3111,7 @@ extern "C"
 
   int pfm_ctx_force_path(pfm_ctx *c, int path)
   {
-    if (path == 3 && c && !c->cart_ok && c->n_patch_blocks > 0)
+    if (path == 3 && c && !c->cart_ok && (c->n_patch_blocks > 0 || !c->levels3.empty()))
       {
         c->kernel_path = 3;
         return PFM_OK;
@@ -2748,9 +3127,9 @@ extern "C"
     if (!c)
       return PFM_ERR_BAD_ARG;
     if (n_patch_rows)
-      *n_patch_rows = c->n_patch_blocks > 0 ? c->n_patch_rows : 0;
+      *n_patch_rows = (c->n_patch_blocks > 0 || !c->levels3.empty()) ? c->n_patch_rows : 0;
     if (n_general_cells)
-      *n_general_cells = c->n_patch_blocks > 0 ? c->n_general_cells : c->v.n_cells;
+      *n_general_cells = (c->n_patch_blocks > 0 || !c->levels3.empty()) ? c->n_general_cells : c->v.n_cells;
     return PFM_OK;
   }
 

@@ -78,6 +78,11 @@ namespace pfm
     double *patch_val;
     int *patch_count;
     int patch_cap;
+    // Cartesian overlay of a general 3-D mesh (round 5): the lattice is ONE refinement level's, local_of_box holds -1
+    // where the level has no node, and the rows this launch writes are those of row_of_box (-1: not a row of this level's
+    // launch -- hanging, parent, mixed-level or ghost nodes stay with the general family).  nullptr: every owned node of
+    // the box is a row (uniform boxes).
+    const int32_t *row_of_box;
     int tile_sel;                     // 0: every tile; 1: only tiles that read no ghost node ("interior"); 2: only the
                                       // others -- the two launches of pfm_assemble_overlapped, between which the ghost
                                       // import lands (cracks.cc:2147-2154 next to the cell loop instead of in front of it)
@@ -169,6 +174,9 @@ namespace pfm
   int graph_build_rows(const int32_t *d_cells, long long NC, int nv, int32_t NO, const int32_t *d_hn_index, const long long *d_hn_ptr,
                        const int32_t *d_hn_parents, const long long *d_nadj_ptr, int32_t *d_nadj, const GraphScratch &sc, hipStream_t s);
   void graph_build_free(GraphScratch &sc);
+  // row tables (CartView::nbr_mask, row_perm) of one level lattice of the 3-D cartesian overlay, from the current row order
+  int launch_overlay3_rows(const int32_t *d_node_at, const int32_t *d_row_at, int NX, int NY, int NZ, const long long *d_nadj_ptr,
+                           const int32_t *d_nadj, uint32_t *d_nbr_mask, uint8_t *d_row_perm, int *d_bad, hipStream_t s);
   // host: indices of the tiles of k_cart_uu3 / k_cart_residual3 that read a ghost node (pfm_assemble_overlapped, phase 2)
   void cart_uu3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out);
   void cart_res3_boundary_tiles(const CartView &cv, std::vector<int32_t> &out, int &zc);
@@ -247,6 +255,20 @@ struct pfm_ctx
   int64_t n_patch_rows = 0, n_general_cells = 0;
   unsigned long long *d_node_slots = nullptr;
   bool patch_slots_valid = false;
+  // cartesian overlay of a general 3-D mesh (round 5): one level lattice per refinement level with regular rows; the
+  // row-owner kernels of the cartesian family (k_cart_uu3, k_cart_phi4, k_cart_residual3) run on each of them and write the
+  // regular rows, the general family keeps the rest (same reduced lists as the 2-D overlay)
+  struct OverlayLevel
+  {
+    pfm::CartView cv{};
+    void *d_scal = nullptr; // the level's MatScal (its cell size)
+    bool scal_dirty = true;
+    int64_t n_rows = 0;
+  };
+  std::vector<OverlayLevel> levels3;
+  uint32_t *d_nbr_mask3 = nullptr;
+  uint8_t *d_row_perm3 = nullptr;
+  bool overlay3_rows_valid = false;
   int32_t *d_rows_general = nullptr;        // owned nodes whose rows the general family writes in an overlay assembly
   int32_t n_rows_general = 0;
   int32_t *d_color_cells_reduced = nullptr; // colour-sorted cells that touch a row the patches do not write

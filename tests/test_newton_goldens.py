@@ -172,12 +172,24 @@ def test_hetero_3d_with_oracle():
 
 @pytest.mark.gpu
 def test_hetero_3d_on_gpu_end_to_end():
-    """General family in 3-D: hanging nodes, per-cell Lame coefficients, time-dependent pressure; energies by pfm_functionals."""
+    """3-D AMR mesh: hanging nodes, per-cell Lame coefficients, time-dependent pressure; energies by pfm_functionals.  Since
+    round 5 the regular rows of both refinement levels come from the cartesian row-owner kernels on the level lattices
+    (kernel path 3: general family + cartesian overlay), the rest from the general family."""
     from cracks_amd.newton import GpuAssembler
 
     setup, cl, cm = NC.hetero_3d_setup()
     asm = GpuAssembler(setup.mesh, setup.layout, cl, cm)
-    assert asm.ctx.kernel_path == 0
+    assert asm.ctx.kernel_path == 3 and asm.ctx.overlay_info()[0] > 0
+    _check_hetero_3d(ActiveSetDriver(setup, asm).run(n_steps=2))
+
+
+@pytest.mark.gpu
+def test_hetero_3d_on_gpu_through_the_general_family_alone():
+    from cracks_amd.newton import GpuAssembler
+
+    setup, cl, cm = NC.hetero_3d_setup()
+    asm = GpuAssembler(setup.mesh, setup.layout, cl, cm)
+    asm.ctx.force_path(0)
     _check_hetero_3d(ActiveSetDriver(setup, asm).run(n_steps=2))
 
 
