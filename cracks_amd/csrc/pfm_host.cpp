@@ -2703,7 +2703,9 @@ extern "C"
         rc = PFM_OK;
         if (overlay3)
           {
-            // the row-owner kernels of the cartesian family on every level lattice, one after the other on the stream
+            // the row-owner kernels of the cartesian family on every level lattice, one after the other on the stream (next to
+            // each other on streams of their own they gained nothing -- 8.3 against 8.4 ms at 1.1e6 cells: the general
+            // family's atomic class on the side stream is the long pole of an overlay assembly)
             for (auto &lv : c->levels3)
               {
                 if (rc == PFM_OK && !residual_only && lv.scal_dirty)
