@@ -27,6 +27,26 @@ cp $O/stats/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube.csv 2>/dev/null
 run_prof stats_res --stats --output-format csv -d $O/stats_res -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --residual-only
 cp $O/stats_res/p_kernel_stats.csv $O/rocprofv3_kernel_stats_216cube_residual_only.csv 2>/dev/null
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU"
+# the 2-D kernels (BASELINE config 2 and the 2-D Jacobian): kernel durations and where their waves spend the cycles
+run_prof stats_2d --stats --output-format csv -d $O/stats_2d -o p -- python $R/bench.py --dim 2 --steps 20 --warmup 3 --no-cpu-baseline --no-extras
+cp $O/stats_2d/p_kernel_stats.csv $O/rocprofv3_kernel_stats_2d_1000sq_jacobian.csv 2>/dev/null
+run_prof stats_2d_res --stats --output-format csv -d $O/stats_2d_res -o p -- python $R/bench.py --dim 2 --residual-only --steps 50 --warmup 5 --no-cpu-baseline --no-extras
+cp $O/stats_2d_res/p_kernel_stats.csv $O/rocprofv3_kernel_stats_2d_1000sq_residual_only.csv 2>/dev/null
+run_prof pmc_sq_2d --pmc $SQ --output-format csv -d $O/pmc_sq_2d -o p -- python $R/bench.py --dim 2 --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+cp $O/pmc_sq_2d/p_counter_collection.csv $O/rocprofv3_pmc_SQ_2d_1000sq_jacobian.csv 2>/dev/null
+run_prof pmc_sq_2d_res --pmc $SQ --output-format csv -d $O/pmc_sq_2d_res -o p -- python $R/bench.py --dim 2 --residual-only --steps 3 --warmup 1 --no-cpu-baseline --no-extras
+cp $O/pmc_sq_2d_res/p_counter_collection.csv $O/rocprofv3_pmc_SQ_2d_1000sq_residual_only.csv 2>/dev/null
+rm -rf $O/stats_2d $O/stats_2d_res $O/pmc_sq_2d $O/pmc_sq_2d_res
+# the 3-D overlay (refined block, 1.1e6 cells): kernel durations
+cat > /tmp/ov3run.py <<PYX
+import sys, torch
+sys.path.insert(0, "$R")
+import bench
+bench.overlay_3d(torch.device("cuda:0"), 0, 6, 84)
+PYX
+run_prof stats_ov3 --stats --output-format csv -d $O/stats_ov3 -o p -- python /tmp/ov3run.py
+cp $O/stats_ov3/p_kernel_stats.csv $O/rocprofv3_kernel_stats_overlay3d.csv 2>/dev/null
+rm -rf $O/stats_ov3
 run_prof pmc_sq --pmc $SQ --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
 cp $O/pmc_sq/p_counter_collection.csv $O/rocprofv3_pmc_SQ_216cube.csv 2>/dev/null
 run_prof pmc_lds --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/pmc_lds -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras
