@@ -218,6 +218,108 @@ namespace pfm
     sc = GraphScratch{};
   }
 
+  // ---- uniform box numbered lexicographically (node n at lattice position n): row pointers and colour lists on the device ----
+  namespace
+  {
+    __global__ void k_lattice_degree(long long *__restrict__ deg, int NX, int NY, int NZ)
+    {
+      const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x, NN = (long long)NX * NY * NZ;
+      if (n > NN)
+        return;
+      long long d = 0;
+      if (n < NN)
+        {
+          const int i = (int)(n % NX), j = (int)((n / NX) % NY), k = (int)(n / ((long long)NX * NY));
+          d = (1 + (i > 0) + (i < NX - 1)) * (1 + (j > 0) + (j < NY - 1)) * (1 + (k > 0) + (k < NZ - 1));
+        }
+      deg[n] = d;
+    }
+    // colour of a cell = parity of the lattice position of its lower corner (vertex 0 of the cell)
+    __global__ void k_lattice_cell_colour(const int32_t *__restrict__ vertex0, const int32_t *__restrict__ box_of_local, long long NC, int NX, int NY,
+                                          uint8_t *__restrict__ key, int32_t *__restrict__ cell)
+    {
+      const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (c >= NC)
+        return;
+      const int32_t n = vertex0[c];
+      const long long b = box_of_local ? box_of_local[n] : n;
+      const int i = (int)(b % NX), j = (int)((b / NX) % NY), k = (int)(b / ((long long)NX * NY));
+      key[c] = (uint8_t)((i & 1) + 2 * (j & 1) + 4 * (k & 1));
+      cell[c] = (int32_t)c;
+    }
+  } // namespace
+
+  // d_ptr [NX NY NZ + 1]: exclusive scan of the row lengths of the lattice node graph (the 1e7 row pointers of a 216^3 box:
+  // 6 ms of host scan and an 80 MB upload otherwise)
+  int launch_lattice_row_ptr(long long *d_ptr, int NX, int NY, int NZ, hipStream_t s)
+  {
+    const long long NN = (long long)NX * NY * NZ;
+    long long *deg = nullptr;
+    void *tmp = nullptr;
+    size_t tb = 0;
+    auto done = [&](int rc) {
+      (void)hipFree(deg);
+      (void)hipFree(tmp);
+      return rc;
+    };
+    if (hipMalloc((void **)&deg, sizeof(long long) * (size_t)(NN + 1)) != hipSuccess)
+      return done(PFM_ERR_HIP);
+    hipLaunchKernelGGL(k_lattice_degree, dim3((unsigned)((NN + 256) / 256)), dim3(256), 0, s, deg, NX, NY, NZ);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, deg, d_ptr, (int)(NN + 1), s);
+    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+      return done(PFM_ERR_HIP);
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, tb, deg, d_ptr, (int)(NN + 1), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+        hipGetLastError() != hipSuccess)
+      return done(PFM_ERR_HIP);
+    return done(PFM_OK);
+  }
+
+  // d_order [NC]: the cells by colour class (parity of the lower corner), ascending cell number within a class: the list the
+  // host's counting sort makes.  d_vertex0: first column of the SoA cell table; d_box_of_local: null when node n sits at
+  // lattice position n.
+  int launch_lattice_colour_order(int32_t *d_order, const int32_t *d_vertex0, const int32_t *d_box_of_local, long long NC, int NX, int NY, hipStream_t s)
+  {
+    if (NC == 0)
+      return PFM_OK;
+    uint8_t *key = nullptr, *key2 = nullptr;
+    int32_t *cell = nullptr;
+    void *tmp = nullptr;
+    size_t tb = 0;
+    auto done = [&](int rc) {
+      for (void *q : {(void *)key, (void *)key2, (void *)cell, tmp})
+        (void)hipFree(q);
+      return rc;
+    };
+    if (hipMalloc((void **)&key, (size_t)NC) != hipSuccess || hipMalloc((void **)&key2, (size_t)NC) != hipSuccess ||
+        hipMalloc((void **)&cell, sizeof(int32_t) * (size_t)NC) != hipSuccess)
+      return done(PFM_ERR_HIP);
+    hipLaunchKernelGGL(k_lattice_cell_colour, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s, d_vertex0, d_box_of_local, NC, NX, NY, key, cell);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, cell, d_order, (int)NC, 0, 3, s);
+    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+      return done(PFM_ERR_HIP);
+    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, key, key2, cell, d_order, (int)NC, 0, 3, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+        hipGetLastError() != hipSuccess)
+      return done(PFM_ERR_HIP);
+    return done(PFM_OK);
+  }
+
+  // bad != 0 afterwards: a marked row does not have `want` entries (2-D overlay: a regular row has the nine nodes of its cells)
+  namespace
+  {
+    __global__ void k_check_row_lengths(const uint8_t *__restrict__ mark, const long long *__restrict__ ptr, int32_t NO, int want, int *__restrict__ bad)
+    {
+      const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (n < NO && mark[n] && ptr[n + 1] - ptr[n] != want)
+        atomicOr(bad, 1);
+    }
+  } // namespace
+  int launch_check_row_lengths(const uint8_t *d_mark, const long long *d_ptr, int32_t NO, int want, int *d_bad, hipStream_t s)
+  {
+    if (NO > 0)
+      hipLaunchKernelGGL(k_check_row_lengths, dim3((unsigned)((NO + 255) / 256)), dim3(256), 0, s, d_mark, d_ptr, NO, want, d_bad);
+    return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
+  }
+
   // ---- cartesian overlay of a general 3-D mesh (round 5): row tables of one refinement level's lattice --------------------
   // node_at / row_at: node id / row id per lattice point of the level's box (-1: none).  For every row r of the level:
   // nbr_mask[r] = all 27 offsets exist, the row is not in lattice order (bit 31); row_perm[nadj_ptr[r] + o] = CSR slot of

@@ -27,6 +27,10 @@
 #include <new>
 #include <mutex>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <pthread.h>
+#include <cstdlib>
 #include <chrono>
 
 using namespace pfm;
@@ -85,56 +89,189 @@ namespace
     return n;
   }
 
+  // Worker threads of the context build, kept between calls: a rebuild at 2.7e5 cells runs some twenty parallel loops of
+  // 20-200 us each, and starting 16 threads costs more than such a loop.  One parallel region at a time (a second caller --
+  // the colour and overlay threads of pfm_ctx_create run next to the main thread -- starts its own threads as before).
+  // A forked child has none of the parent's threads: it starts over with an empty pool (pthread_atfork).
+  struct HostPool
+  {
+    std::mutex mx, region;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(int)> *job = nullptr;
+    uint64_t gen = 0;
+    int want = 0, left = 0;
+    bool stop = false;
+
+    void worker(int id)
+    {
+      uint64_t seen = 0;
+      std::unique_lock<std::mutex> lk(mx);
+      for (;;)
+        {
+          cv.wait(lk, [&] { return stop || gen != seen; });
+          if (stop)
+            return;
+          seen = gen;
+          if (id < want)
+            {
+              const std::function<void(int)> *j = job;
+              lk.unlock();
+              (*j)(id);
+              lk.lock();
+              if (--left == 0)
+                cv_done.notify_one();
+            }
+        }
+    }
+    // f(t) for t = 0 .. nt-1, t = 0 on the calling thread; false when the pool is taken (caller falls back)
+    bool run(int nt, const std::function<void(int)> &f)
+    {
+      std::unique_lock<std::mutex> reg(region, std::try_to_lock);
+      if (!reg.owns_lock())
+        return false;
+      {
+        std::unique_lock<std::mutex> lk(mx);
+        while ((int)th.size() + 1 < nt)
+          {
+            const int id = (int)th.size() + 1;
+            th.emplace_back([this, id] { worker(id); });
+          }
+        job = &f;
+        want = nt;
+        left = nt - 1;
+        ++gen;
+      }
+      cv.notify_all();
+      f(0);
+      std::unique_lock<std::mutex> lk(mx);
+      cv_done.wait(lk, [&] { return left == 0; });
+      job = nullptr;
+      want = 0;
+      return true;
+    }
+    ~HostPool()
+    {
+      {
+        std::lock_guard<std::mutex> lk(mx);
+        stop = true;
+      }
+      cv.notify_all();
+      for (auto &t : th)
+        t.join();
+    }
+  };
+  // Three pools: pfm_ctx_create classifies the cells (overlay) and colours them on two threads next to the one that uploads;
+  // each takes the first pool that is free.
+  constexpr int N_POOLS = 3;
+  std::atomic<HostPool *> g_pools{nullptr};
+  HostPool *host_pools()
+  {
+    HostPool *p = g_pools.load(std::memory_order_acquire);
+    if (p)
+      return p;
+    static std::mutex mk;
+    std::lock_guard<std::mutex> lk(mk);
+    p = g_pools.load(std::memory_order_acquire);
+    if (!p)
+      {
+        static bool hooked = false;
+        if (!hooked)
+          {
+            hooked = true;
+            pthread_atfork(nullptr, nullptr, [] { g_pools.store(nullptr, std::memory_order_release); }); // the child's copy is leaked
+            atexit([] { delete[] g_pools.exchange(nullptr); });
+          }
+        p = new HostPool[N_POOLS];
+        g_pools.store(p, std::memory_order_release);
+      }
+    return p;
+  }
+
   // fn(begin, end) over [0, n) in contiguous chunks, one per thread (at least `grain` items per thread).  An exception
   // thrown by a worker (bad_alloc in a lambda that grows a vector) is carried to the caller instead of ending the
-  // process in std::terminate.
+  // process in std::terminate.  parallel_chunks: the same with the chunk index, for loops that keep per-chunk results.
   template <class F>
-  void parallel_for(int64_t n, F &&fn, int64_t grain = 65536)
+  void parallel_chunks(int nt, F &&fn)
   {
-    const int nt = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(grain, 1)));
+    if (nt <= 1)
+      {
+        fn(0);
+        return;
+      }
+    std::vector<std::exception_ptr> err((size_t)nt);
+    const std::function<void(int)> body = [&fn, &err](int t) {
+      try
+        {
+          fn(t);
+        }
+      catch (...)
+        {
+          err[(size_t)t] = std::current_exception();
+        }
+    };
+    HostPool *pools = host_pools();
+    bool done = false;
+    for (int q = 0; q < N_POOLS && !done; ++q)
+      done = pools[q].run(nt, body);
+    if (!done)
+      {
+        std::vector<std::thread> th;
+        th.reserve(nt);
+        for (int t = 1; t < nt; ++t)
+          th.emplace_back([&body, t] { body(t); });
+        body(0);
+        for (auto &x : th)
+          x.join();
+      }
+    for (auto &e : err)
+      if (e)
+        std::rethrow_exception(e);
+  }
+  inline int chunks_for(int64_t n, int64_t grain) { return (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(grain, 1))); }
+  template <class F>
+  void parallel_for(int64_t n, F &&fn, int64_t grain = 16384)
+  {
+    const int nt = chunks_for(n, grain);
     if (nt <= 1)
       {
         fn((int64_t)0, n);
         return;
       }
-    std::vector<std::thread> th;
-    std::vector<std::exception_ptr> err((size_t)nt);
-    th.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-      th.emplace_back([&fn, &err, n, nt, t] {
-        try
-          {
-            fn(n * t / nt, n * (t + 1) / nt);
-          }
-        catch (...)
-          {
-            err[(size_t)t] = std::current_exception();
-          }
-      });
-    for (auto &x : th)
-      x.join();
-    for (auto &e : err)
-      if (e)
-        std::rethrow_exception(e);
+    parallel_chunks(nt, [&fn, n, nt](int t) { fn(n * t / nt, n * (t + 1) / nt); });
   }
 
   // Host -> device copy of caller-owned (pageable) memory.  hipMemcpy from pageable memory ran at ~3.6 GB/s on the
-  // test box; large tables go through two pinned staging buffers filled by the host threads (parallel memcpy) while
-  // the previous chunk is on the bus.
+  // test box; tables from 256 KB go through two pinned staging buffers filled by the host threads (parallel memcpy) while
+  // the previous piece is on the bus.  On return the caller's buffer has been read.  The copy itself is complete as well,
+  // unless the calling thread is inside an H2dBatch scope (pfm_ctx_create: some twenty uploads, one synchronisation at the
+  // end, 0.1-0.3 ms each otherwise): then it is ordered on the null stream like a hipMemcpyAsync from pinned memory.
+  thread_local int g_h2d_batch = 0;
+  struct H2dBatch
+  {
+    H2dBatch() { ++g_h2d_batch; }
+    ~H2dBatch() { --g_h2d_batch; }
+  };
   hipError_t h2d(void *d, const void *h, size_t bytes)
   {
     constexpr size_t CHUNK = 32u << 20;
-    if (bytes < (4u << 20))
+    if (bytes < (256u << 10))
       return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
-    static thread_local struct Stage
+    static std::mutex stage_mx; // one upload at a time goes through the staging buffers (pfm_ctx_create uploads on a second thread)
+    std::lock_guard<std::mutex> stage_lock(stage_mx);
+    static struct Stage
     {
       void *buf[2] = {nullptr, nullptr};
       hipEvent_t ev[2] = {nullptr, nullptr};
+      bool pending[2] = {false, false};
+      int next = 0;
       bool ok = false, tried = false;
       ~Stage()
       {
         for (int i = 0; i < 2; ++i)
           {
+            if (pending[i])
+              (void)hipEventSynchronize(ev[i]);
             if (buf[i])
               (void)hipHostFree(buf[i]);
             if (ev[i])
@@ -155,28 +292,31 @@ namespace
       }
     if (!st.ok)
       return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
-    bool used[2] = {false, false};
-    int k = 0;
-    for (size_t off = 0; off < bytes; off += CHUNK, k ^= 1)
+    // pieces: a table of a few MB in two halves (the second is copied to the staging buffer while the first is on the bus)
+    const size_t piece = bytes <= (1u << 20) ? bytes : std::min(CHUNK, ((bytes + 1) / 2 + 4095) & ~(size_t)4095);
+    for (size_t off = 0; off < bytes; off += piece)
       {
-        const size_t nb = std::min(CHUNK, bytes - off);
-        if (used[k])
+        const int k = st.next;
+        st.next ^= 1;
+        const size_t nb = std::min(piece, bytes - off);
+        if (st.pending[k])
           {
+            st.pending[k] = false;
             const hipError_t e = hipEventSynchronize(st.ev[k]);
             if (e != hipSuccess)
               return e;
           }
         const char *src = static_cast<const char *>(h) + off;
         char *dst = static_cast<char *>(st.buf[k]);
-        parallel_for((int64_t)nb, [&](int64_t b, int64_t e) { memcpy(dst + b, src + b, (size_t)(e - b)); });
+        parallel_for((int64_t)nb, [&](int64_t b, int64_t e) { memcpy(dst + b, src + b, (size_t)(e - b)); }, 1 << 18);
         hipError_t e = hipMemcpyAsync(static_cast<char *>(d) + off, st.buf[k], nb, hipMemcpyHostToDevice, nullptr);
         if (e == hipSuccess)
           e = hipEventRecord(st.ev[k], nullptr);
         if (e != hipSuccess)
           return e;
-        used[k] = true;
+        st.pending[k] = true;
       }
-    return hipStreamSynchronize(nullptr);
+    return g_h2d_batch > 0 ? hipSuccess : hipStreamSynchronize(nullptr);
   }
 
   template <class T>
@@ -191,6 +331,45 @@ namespace
       }
     return d;
   }
+  // a[i] += a[i-1] ... in place (row pointers of 1e7 rows: 24 ms on one core)
+  template <class T>
+  void inclusive_scan_parallel(T *a, int64_t n)
+  {
+    const int nt = chunks_for(n, 65536);
+    if (nt <= 1)
+      {
+        for (int64_t i = 1; i < n; ++i)
+          a[i] += a[i - 1];
+        return;
+      }
+    std::vector<T> tot((size_t)nt);
+    parallel_chunks(nt, [&](int t) {
+      const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+      T s = 0;
+      for (int64_t i = b; i < e; ++i)
+        {
+          s += a[i];
+          a[i] = s;
+        }
+      tot[(size_t)t] = s;
+    });
+    T run = 0;
+    for (int t = 0; t < nt; ++t)
+      {
+        const T x = tot[(size_t)t];
+        tot[(size_t)t] = run;
+        run += x;
+      }
+    parallel_chunks(nt, [&](int t) {
+      const T off = tot[(size_t)t];
+      if (off == 0)
+        return;
+      const int64_t b = n * t / nt, e = n * (t + 1) / nt;
+      for (int64_t i = b; i < e; ++i)
+        a[i] += off;
+    });
+  }
+
   // Lattice of a uniform Cartesian box: node n <-> lattice index box_of_local[n] (x fastest), cells in deal.II
   // vertex order, every lattice cell present exactly once.  false whenever any check fails.
   using Lattice = pfm::LatticeHost;
@@ -209,20 +388,43 @@ namespace
       return false;
     const int32_t N = m->n_nodes;
     double x0[3] = {0, 0, 0}, x1[3] = {0, 0, 0}, h[3] = {1, 1, 1};
-    for (int d = 0; d < dim; ++d)
-      {
-        x0[d] = x1[d] = m->coords[d];
-        for (int32_t n = 1; n < N; ++n)
+    {
+      const int nt = chunks_for(N, 16384);
+      std::vector<double> lo((size_t)nt * 3), hi((size_t)nt * 3);
+      parallel_chunks(nt, [&](int t) {
+        const int64_t nb = (int64_t)N * t / nt, ne = (int64_t)N * (t + 1) / nt;
+        double a[3], b[3];
+        for (int d = 0; d < dim; ++d)
+          a[d] = b[d] = m->coords[(size_t)nb * dim + d];
+        for (int64_t n = nb; n < ne; ++n)
+          for (int d = 0; d < dim; ++d)
+            {
+              const double x = m->coords[(size_t)n * dim + d];
+              a[d] = std::min(a[d], x);
+              b[d] = std::max(b[d], x);
+            }
+        for (int d = 0; d < dim; ++d)
           {
-            x0[d] = std::min(x0[d], m->coords[(size_t)n * dim + d]);
-            x1[d] = std::max(x1[d], m->coords[(size_t)n * dim + d]);
+            lo[(size_t)t * 3 + d] = a[d];
+            hi[(size_t)t * 3 + d] = b[d];
           }
-        h[d] = (x1[d] - x0[d]) / nc[d];
-        if (!(h[d] > 0))
-          return false;
-      }
-    std::vector<int32_t> local_of_box((size_t)nn, -1);
-    std::vector<int32_t> box_of_local((size_t)N);
+      });
+      for (int d = 0; d < dim; ++d)
+        {
+          x0[d] = lo[d];
+          x1[d] = hi[d];
+          for (int t = 1; t < nt; ++t)
+            {
+              x0[d] = std::min(x0[d], lo[(size_t)t * 3 + d]);
+              x1[d] = std::max(x1[d], hi[(size_t)t * 3 + d]);
+            }
+          h[d] = (x1[d] - x0[d]) / nc[d];
+          if (!(h[d] > 0))
+            return false;
+        }
+    }
+    pfm::raw_vector<int32_t> local_of_box((size_t)nn); // every entry is written below or the mesh is rejected
+    pfm::raw_vector<int32_t> box_of_local((size_t)N);
     std::atomic<bool> ok{true};
     parallel_for(N, [&](int64_t nb, int64_t ne) {
       for (int64_t n = nb; n < ne; ++n)
@@ -243,15 +445,25 @@ namespace
     });
     if (!ok)
       return false;
-    for (int32_t n = 0; n < N; ++n)
-      {
-        const int32_t b = box_of_local[n];
-        if (local_of_box[b] != -1)
-          return false; // duplicated coordinates (e.g. a slit): not a lattice
-        local_of_box[b] = n;
-      }
+    // N = nn nodes on nn positions: a bijection unless two nodes share one (duplicated coordinates, e.g. a slit) -- then
+    // one of the two does not find itself at its position (racing writers of one entry: either value shows the clash)
+    parallel_for(N, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        __atomic_store_n(&local_of_box[(size_t)box_of_local[n]], (int32_t)n, __ATOMIC_RELAXED);
+    });
+    parallel_for(N, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        if (local_of_box[(size_t)box_of_local[n]] != (int32_t)n)
+          {
+            ok = false;
+            return;
+          }
+    });
+    if (!ok)
+      return false;
     // every lattice cell must be present exactly once, vertices in deal.II order
-    std::vector<uint8_t> seen((size_t)m->n_cells, 0);
+    pfm::raw_vector<uint8_t> seen((size_t)m->n_cells);
+    parallel_for(m->n_cells, [&](int64_t b, int64_t e) { std::fill(seen.begin() + b, seen.begin() + e, (uint8_t)0); }, 1 << 20);
     parallel_for(m->n_cells, [&](int64_t cb, int64_t ce) {
       for (int64_t cell = cb; cell < ce; ++cell)
         {
@@ -276,9 +488,16 @@ namespace
     });
     if (!ok)
       return false;
-    for (int64_t cell = 0; cell < m->n_cells; ++cell)
-      if (!seen[cell])
-        return false; // n_cells matches the box, so a missing cell means another one is present twice
+    parallel_for(m->n_cells, [&](int64_t cb, int64_t ce) {
+      for (int64_t cell = cb; cell < ce; ++cell)
+        if (!seen[cell])
+          {
+            ok = false; // n_cells matches the box, so a missing cell means another one is present twice
+            return;
+          }
+    });
+    if (!ok)
+      return false;
     L.NX = NX;
     L.NY = NY;
     L.NZ = NZ;
@@ -296,12 +515,12 @@ namespace
   // ABI, what a host CSR sorted by local column id has).  Arithmetic instead of the generic cell-incidence build: the
   // neighbours of lattice node (i,j,k) are the lattice offsets that stay inside the local box (every cell of the box
   // is local, detect_lattice).  Also fills the host copies of the cartesian row tables (row_order_tables).
-  void lattice_graph(pfm_ctx *c, int dim, int32_t NO, const Lattice &L)
+  void lattice_host_ptr(pfm_ctx *c, int32_t NO, const Lattice &L)
   {
     const int NX = L.NX, NY = L.NY, NZ = L.NZ;
-    (void)dim;
-    std::vector<long long> &ptr = c->h_nadj_ptr;
-    ptr.assign((size_t)NO + 1, 0);
+    auto &ptr = c->h_nadj_ptr;
+    ptr.resize((size_t)NO + 1);
+    ptr[0] = 0;
     parallel_for(NO, [&](int64_t nb, int64_t ne) {
       for (int64_t n = nb; n < ne; ++n)
         {
@@ -311,8 +530,32 @@ namespace
           ptr[n + 1] = cx * cy * cz;
         }
     });
-    for (int32_t n = 0; n < NO; ++n)
-      ptr[n + 1] += ptr[n];
+    inclusive_scan_parallel(ptr.data() + 1, NO);
+  }
+  void lattice_graph(pfm_ctx *c, int dim, int32_t NO, const Lattice &L)
+  {
+    (void)dim;
+    // a box without ghost nodes, node n at lattice position n: the row lengths are a function of n alone -- the row pointers
+    // are made on the device (launch_lattice_row_ptr) and on the host only when a pattern query asks for them
+    std::atomic<bool> positional{(int64_t)NO == (int64_t)L.box_of_local.size()};
+    if (positional)
+      parallel_for(NO, [&](int64_t nb, int64_t ne) {
+        for (int64_t n = nb; n < ne; ++n)
+          if (L.box_of_local[n] != (int32_t)n)
+            {
+              positional = false;
+              return;
+            }
+      });
+    c->graph_positional = positional;
+    c->h_nadj_ptr.clear();
+    if (positional)
+      {
+        auto span = [](int n) { return n <= 1 ? 1LL : 3LL * n - 2; }; // sum over a line of (1 + left + right)
+        c->nadj_total = span(L.NX) * span(L.NY) * span(L.NZ);
+      }
+    else
+      lattice_host_ptr(c, NO, L);
     c->h_nadj.clear();
     c->graph_lazy = true; // rows are materialised by ensure_host_graph
   }
@@ -339,20 +582,37 @@ namespace
   // the canonical rows (ascending local node id) of a lattice context whose host graph has not been materialised
   void ensure_host_graph(pfm_ctx *c)
   {
-    if (c->graph_dev_only && c->h_nadj.empty() && !c->h_nadj_ptr.empty() && c->h_nadj_ptr.back() > 0)
+    if (c->graph_dev_only)
       {
-        // general mesh: the rows were built on the device (pfm_graph.hip); the host copy is a cache for pattern queries
-        c->h_nadj.resize((size_t)c->h_nadj_ptr.back());
+        // general mesh: rows and row pointers were built on the device (pfm_graph.hip); the host copy is a cache for pattern queries
         (void)hipSetDevice(c->device);
-        if (hipMemcpy(c->h_nadj.data(), c->v.nadj, sizeof(int32_t) * c->h_nadj.size(), hipMemcpyDeviceToHost) != hipSuccess)
-          throw HipFail{hipGetLastError(), "node graph D2H"};
+        if (c->h_nadj_ptr.empty())
+          {
+            c->h_nadj_ptr.resize((size_t)c->v.n_owned + 1);
+            if (hipMemcpy(c->h_nadj_ptr.data(), c->v.nadj_ptr, sizeof(long long) * c->h_nadj_ptr.size(), hipMemcpyDeviceToHost) != hipSuccess)
+              {
+                c->h_nadj_ptr.clear();
+                throw HipFail{hipGetLastError(), "node graph D2H"};
+              }
+          }
+        if (c->h_nadj.empty() && c->h_nadj_ptr.back() > 0)
+          {
+            c->h_nadj.resize((size_t)c->h_nadj_ptr.back());
+            if (hipMemcpy(c->h_nadj.data(), c->v.nadj, sizeof(int32_t) * c->h_nadj.size(), hipMemcpyDeviceToHost) != hipSuccess)
+              {
+                c->h_nadj.clear();
+                throw HipFail{hipGetLastError(), "node graph D2H"};
+              }
+          }
         return;
       }
     if (!c->graph_lazy)
       return;
     const int32_t NO = c->v.n_owned;
     const int dim = c->v.dim;
-    const std::vector<long long> &ptr = c->h_nadj_ptr;
+    if (c->h_nadj_ptr.empty())
+      lattice_host_ptr(c, NO, c->lat);
+    const auto &ptr = c->h_nadj_ptr;
     c->h_nadj.resize((size_t)ptr[NO]);
     parallel_for(NO, [&](int64_t nb, int64_t ne) {
       int32_t q[27];
@@ -376,6 +636,15 @@ namespace
       return;
     ensure_host_graph(c);
     DevView &v = c->v;
+    if (c->colours_lazy)
+      {
+        int32_t *d_order = dev_alloc<int32_t>(c, (size_t)std::max<int64_t>(v.n_cells, 1));
+        const int32_t *d_box = c->graph_positional ? nullptr : dev_upload(c, c->lat.box_of_local.data(), c->lat.box_of_local.size());
+        if (launch_lattice_colour_order(d_order, v.conn, d_box, v.n_cells, c->lat.NX, c->lat.NY, nullptr) != PFM_OK)
+          throw HipFail{hipGetLastError(), "colour lists"};
+        v.color_cells = d_order;
+        c->colours_lazy = false;
+      }
     v.nadj = dev_upload(c, c->h_nadj.data(), c->h_nadj.size());
     v.cslot = dev_alloc<uint8_t>(c, (size_t)v.n_cells * (size_t)(1 << v.dim) * (size_t)(1 << v.dim));
     if (launch_build_cslot(v, nullptr) != PFM_OK || hipDeviceSynchronize() != hipSuccess)
@@ -500,7 +769,7 @@ namespace
   {
     const int NX = L.NX, NY = L.NY;
     const int32_t NO = m->n_owned_nodes;
-    const std::vector<int32_t> &box_of_local = L.box_of_local;
+    const auto &box_of_local = L.box_of_local;
     // owned nodes must form a sub-box
     int o0[3] = {1 << 30, 1 << 30, 1 << 30}, o1[3] = {-1, -1, -1};
     {
@@ -612,7 +881,7 @@ int64_t pfm_ctx::block_rows(int b) const
 int64_t pfm_ctx::block_nnz(int b) const
 {
   const int dim = v.dim;
-  const int64_t g = h_nadj_ptr.empty() ? 0 : (int64_t)h_nadj_ptr.back();
+  const int64_t g = nadj_total >= 0 ? (int64_t)nadj_total : (h_nadj_ptr.empty() ? 0 : (int64_t)h_nadj_ptr.back());
   if (v.layout == PFM_LAYOUT_INTERLEAVED)
     return g * (dim + 1) * (dim + 1);
   switch (b)
@@ -645,6 +914,34 @@ namespace
     int64_t n_regular = 0;
     int n_blocks = 0;
   };
+  // indices i of [b, e) with pred(i), ascending (chunked over the host threads)
+  template <class P>
+  std::vector<int32_t> parallel_select(int64_t b, int64_t e, P &&pred)
+  {
+    const int64_t n = e - b;
+    const int nt = chunks_for(n, 16384);
+    std::vector<std::vector<int32_t>> part((size_t)nt);
+    parallel_chunks(nt, [&](int t) {
+      std::vector<int32_t> &out = part[(size_t)t];
+      for (int64_t i = b + n * t / nt; i < b + n * (t + 1) / nt; ++i)
+        if (pred(i))
+          out.push_back((int32_t)i);
+    });
+    if (nt == 1)
+      return std::move(part[0]);
+    size_t total = 0;
+    for (auto &q : part)
+      total += q.size();
+    std::vector<int32_t> out;
+    out.reserve(total);
+    for (auto &q : part)
+      out.insert(out.end(), q.begin(), q.end());
+    return out;
+  }
+
+  // Every loop below runs over cells, nodes or blocks in chunks on the host threads (HostPool): the classification is part of
+  // the context rebuild after every refine_mesh.  Tables that several cells write (the cell of which a node is vertex a, the
+  // node at a lattice position) are filled with compare-and-swap: a second claimant marks the entry instead of racing.
   PatchPlan plan_patches2d(const pfm_mesh_desc *m, const std::vector<int32_t> &hn_index)
   {
     PatchPlan pl;
@@ -653,14 +950,32 @@ namespace
     if (m->dim != 2 || NC == 0 || getenv("PFM_NO_PATCH"))
       return pl;
     const double *X = m->coords;
-    double xmin = X[0], ymin = X[1], xmax = X[0], ymax = X[1];
-    for (int32_t n = 0; n < N; ++n)
-      {
-        xmin = std::min(xmin, X[2 * n]);
-        xmax = std::max(xmax, X[2 * n]);
-        ymin = std::min(ymin, X[2 * n + 1]);
-        ymax = std::max(ymax, X[2 * n + 1]);
-      }
+    double xmin, ymin, xmax, ymax;
+    {
+      const int nt = chunks_for(N, 16384);
+      std::vector<double> bb((size_t)nt * 4);
+      parallel_chunks(nt, [&](int t) {
+        const int64_t nb = (int64_t)N * t / nt, ne = (int64_t)N * (t + 1) / nt;
+        double a0 = X[2 * nb], a1 = a0, b0 = X[2 * nb + 1], b1 = b0;
+        for (int64_t n = nb; n < ne; ++n)
+          {
+            a0 = std::min(a0, X[2 * n]);
+            a1 = std::max(a1, X[2 * n]);
+            b0 = std::min(b0, X[2 * n + 1]);
+            b1 = std::max(b1, X[2 * n + 1]);
+          }
+        double *q = bb.data() + (size_t)t * 4;
+        q[0] = a0, q[1] = a1, q[2] = b0, q[3] = b1;
+      });
+      xmin = bb[0], xmax = bb[1], ymin = bb[2], ymax = bb[3];
+      for (int t = 1; t < nt; ++t)
+        {
+          xmin = std::min(xmin, bb[(size_t)t * 4]);
+          xmax = std::max(xmax, bb[(size_t)t * 4 + 1]);
+          ymin = std::min(ymin, bb[(size_t)t * 4 + 2]);
+          ymax = std::max(ymax, bb[(size_t)t * 4 + 3]);
+        }
+    }
     const double tol = 1e-9 * std::max(xmax - xmin, ymax - ymin);
     // level of a cell (by its size), lattice position of its lower-left vertex
     struct Level
@@ -668,122 +983,206 @@ namespace
       double hx, hy;
       long long ix0, iy0, ix1, iy1; // cell index range
     };
+    struct Size
+    {
+      double hx, hy;
+    };
+    // the size of an EXACT axis-parallel rectangle in deal.II's vertex order (the patch kernel takes J = diag(hx, hy));
+    // any other cell stays with the general family
+    auto cell_size = [&](int64_t k, double &hx, double &hy, double &x0, double &y0) {
+      const int32_t *cn = m->cell_nodes + 4 * k;
+      x0 = X[2 * cn[0]], y0 = X[2 * cn[0] + 1];
+      const double x1 = X[2 * cn[1]], y1 = X[2 * cn[1] + 1];
+      const double x2 = X[2 * cn[2]], y2 = X[2 * cn[2] + 1], x3 = X[2 * cn[3]], y3 = X[2 * cn[3] + 1];
+      hx = x1 - x0, hy = y2 - y0;
+      return hx > tol && hy > tol && y1 == y0 && x2 == x0 && x3 == x1 && y3 == y2;
+    };
+    auto same_size = [](const Size &a, double hx, double hy) { return std::fabs(a.hx - hx) <= 1e-9 * hx && std::fabs(a.hy - hy) <= 1e-9 * hy; };
+    const int ntc = chunks_for(NC, 8192);
     std::vector<Level> levels;
-    std::vector<int8_t> cell_level((size_t)NC, -1);
-    std::vector<long long> cix((size_t)NC), ciy((size_t)NC);
-    for (int64_t k = 0; k < NC; ++k)
-      {
-        const int32_t *cn = m->cell_nodes + 4 * k;
-        const double x0 = X[2 * cn[0]], y0 = X[2 * cn[0] + 1], x1 = X[2 * cn[1]], y1 = X[2 * cn[1] + 1];
-        const double x2 = X[2 * cn[2]], y2 = X[2 * cn[2] + 1], x3 = X[2 * cn[3]], y3 = X[2 * cn[3] + 1];
-        const double hx = x1 - x0, hy = y2 - y0;
-        if (!(hx > tol && hy > tol) || y1 != y0 || x2 != x0 || x3 != x1 || y3 != y2)
-          continue; // not an EXACT axis-parallel rectangle in deal.II's vertex order (the patch kernel takes J = diag(hx, hy)): stays with the general family
-        int L = -1;
-        for (size_t l = 0; l < levels.size(); ++l)
-          if (std::fabs(levels[l].hx - hx) <= 1e-9 * hx && std::fabs(levels[l].hy - hy) <= 1e-9 * hy)
-            L = (int)l;
-        if (L < 0)
+    {
+      // the sizes that occur, in the order of their first cell: per chunk, then merged in chunk order
+      std::vector<std::vector<Size>> found((size_t)ntc);
+      parallel_chunks(ntc, [&](int t) {
+        std::vector<Size> &mine = found[(size_t)t];
+        for (int64_t k = NC * t / ntc; k < NC * (t + 1) / ntc; ++k)
           {
-            if (levels.size() >= 100)
+            double hx, hy, x0, y0;
+            if (!cell_size(k, hx, hy, x0, y0))
               continue;
-            levels.push_back(Level{hx, hy, LLONG_MAX, LLONG_MAX, LLONG_MIN, LLONG_MIN});
-            L = (int)levels.size() - 1;
+            bool known = false;
+            for (const Size &q : mine)
+              known = known || same_size(q, hx, hy);
+            if (!known && mine.size() < 100)
+              mine.push_back(Size{hx, hy});
           }
-        const double fx = (x0 - xmin) / levels[L].hx, fy = (y0 - ymin) / levels[L].hy;
-        const long long ix = std::llround(fx), iy = std::llround(fy);
-        if (std::fabs(fx - (double)ix) > 1e-6 || std::fabs(fy - (double)iy) > 1e-6)
-          continue; // off the level's lattice
-        cell_level[k] = (int8_t)L;
-        cix[k] = ix;
-        ciy[k] = iy;
-        Level &lv = levels[L];
-        lv.ix0 = std::min(lv.ix0, ix);
-        lv.iy0 = std::min(lv.iy0, iy);
-        lv.ix1 = std::max(lv.ix1, ix);
-        lv.iy1 = std::max(lv.iy1, iy);
-      }
+      });
+      for (const auto &mine : found)
+        for (const Size &q : mine)
+          {
+            bool known = false;
+            for (const Level &l : levels)
+              known = known || same_size(Size{l.hx, l.hy}, q.hx, q.hy);
+            if (!known && levels.size() < 100)
+              levels.push_back(Level{q.hx, q.hy, LLONG_MAX, LLONG_MAX, LLONG_MIN, LLONG_MIN});
+          }
+    }
     if (levels.empty())
       return pl;
-    // cells by level (the per-level tables below walk their own cells only)
-    std::vector<std::vector<int32_t>> level_cells(levels.size());
-    for (int64_t k = 0; k < NC; ++k)
-      if (cell_level[k] >= 0)
-        level_cells[(size_t)cell_level[k]].push_back((int32_t)k);
-    // incident cells per node: count, common level, the 4 cells by the vertex the node is of them
-    std::vector<uint8_t> n_inc((size_t)N, 0), is_parent((size_t)N, 0);
-    std::vector<int8_t> node_level((size_t)N, -2); // -2 none yet, -1 mixed / off-lattice
-    std::vector<int32_t> inc((size_t)N * 4, -1);   // inc[4 n + a]: the cell of which n is vertex a
-    for (int64_t k = 0; k < NC; ++k)
-      for (int a = 0; a < 4; ++a)
-        {
-          const int32_t n = m->cell_nodes[4 * k + a];
-          if (n_inc[n] < 255)
-            ++n_inc[n];
-          const int8_t L = cell_level[k];
-          node_level[n] = (node_level[n] == -2) ? L : (node_level[n] == L ? L : (int8_t)-1);
-          inc[(size_t)n * 4 + a] = (inc[(size_t)n * 4 + a] == -1) ? (int32_t)k : -2; // -2: two cells claim the same corner
-        }
+    const int NL = (int)levels.size();
+    std::vector<int8_t> cell_level((size_t)NC);
+    std::vector<int32_t> cix((size_t)NC), ciy((size_t)NC);
+    {
+      std::vector<Level> part((size_t)ntc * NL);
+      std::atomic<bool> too_far{false};
+      parallel_chunks(ntc, [&](int t) {
+        Level *mine = part.data() + (size_t)t * NL;
+        for (int l = 0; l < NL; ++l)
+          mine[l] = Level{0, 0, LLONG_MAX, LLONG_MAX, LLONG_MIN, LLONG_MIN};
+        for (int64_t k = NC * t / ntc; k < NC * (t + 1) / ntc; ++k)
+          {
+            cell_level[k] = -1;
+            double hx, hy, x0, y0;
+            if (!cell_size(k, hx, hy, x0, y0))
+              continue;
+            int L = -1;
+            for (int l = 0; l < NL; ++l)
+              if (same_size(Size{levels[l].hx, levels[l].hy}, hx, hy))
+                L = l;
+            if (L < 0)
+              continue;
+            const double fx = (x0 - xmin) / levels[L].hx, fy = (y0 - ymin) / levels[L].hy;
+            const long long ix = std::llround(fx), iy = std::llround(fy);
+            if (std::fabs(fx - (double)ix) > 1e-6 || std::fabs(fy - (double)iy) > 1e-6)
+              continue; // off the level's lattice
+            if (ix > (1 << 30) || iy > (1 << 30))
+              {
+                too_far = true;
+                continue;
+              }
+            cell_level[k] = (int8_t)L;
+            cix[k] = (int32_t)ix;
+            ciy[k] = (int32_t)iy;
+            Level &lv = mine[L];
+            lv.ix0 = std::min(lv.ix0, ix);
+            lv.iy0 = std::min(lv.iy0, iy);
+            lv.ix1 = std::max(lv.ix1, ix);
+            lv.iy1 = std::max(lv.iy1, iy);
+          }
+      });
+      (void)too_far; // such cells keep level -1: general family
+      for (int t = 0; t < ntc; ++t)
+        for (int l = 0; l < NL; ++l)
+          {
+            const Level &q = part[(size_t)t * NL + l];
+            Level &lv = levels[l];
+            lv.ix0 = std::min(lv.ix0, q.ix0);
+            lv.iy0 = std::min(lv.iy0, q.iy0);
+            lv.ix1 = std::max(lv.ix1, q.ix1);
+            lv.iy1 = std::max(lv.iy1, q.iy1);
+          }
+    }
+    // incident cells per node: inc[4 n + a] = the cell of which n is vertex a (-1 none, -2 two cells claim the corner)
+    std::vector<int32_t> inc((size_t)N * 4);
+    parallel_for((int64_t)N * 4, [&](int64_t b, int64_t e) { std::fill(inc.begin() + b, inc.begin() + e, -1); });
+    parallel_for(NC, [&](int64_t cb, int64_t ce) {
+      for (int64_t k = cb; k < ce; ++k)
+        for (int a = 0; a < 4; ++a)
+          {
+            int32_t *slot = &inc[(size_t)m->cell_nodes[4 * k + a] * 4 + a];
+            int32_t expect = -1;
+            if (!__atomic_compare_exchange_n(slot, &expect, (int32_t)k, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+              __atomic_store_n(slot, -2, __ATOMIC_RELAXED);
+          }
+    }, 8192);
+    std::vector<uint8_t> is_parent((size_t)N, 0);
     if (m->n_hanging > 0)
       for (int64_t j = 0; j < m->hn_ptr[m->n_hanging]; ++j)
         is_parent[m->hn_parents[j]] = 1;
-    // two nodes at one lattice position (the lips of a slit, meshes/unit_slit.inp): neither they nor their neighbours are regular
+    // two nodes at one lattice position (the lips of a slit, meshes/unit_slit.inp): neither they nor their neighbours are
+    // regular.  One table per level (node at a lattice position), all in one array.
     std::vector<uint8_t> dup((size_t)N, 0);
-    for (size_t L = 0; L < levels.size(); ++L)
-      {
-        const Level &lv = levels[L];
-        if (lv.ix0 > lv.ix1)
-          continue;
-        const long long W = lv.ix1 - lv.ix0 + 2, Hh = lv.iy1 - lv.iy0 + 2;
-        if ((double)W * (double)Hh > 4.0e8)
-          continue;
-        std::vector<int32_t> node_at((size_t)(W * Hh), -1);
-        for (const int32_t k : level_cells[L])
+    {
+      std::vector<long long> off((size_t)NL + 1, 0), Wn((size_t)NL, 0);
+      for (int L = 0; L < NL; ++L)
+        {
+          const Level &lv = levels[L];
+          long long sz = 0;
+          if (lv.ix0 <= lv.ix1)
+            {
+              const long long W = lv.ix1 - lv.ix0 + 2, Hh = lv.iy1 - lv.iy0 + 2;
+              if ((double)W * (double)Hh <= 4.0e8)
+                {
+                  sz = W * Hh;
+                  Wn[L] = W;
+                }
+            }
+          off[(size_t)L + 1] = off[L] + sz;
+        }
+      std::vector<int32_t> node_at((size_t)off[NL]);
+      parallel_for(off[NL], [&](int64_t b, int64_t e) { std::fill(node_at.begin() + b, node_at.begin() + e, -1); });
+      parallel_for(NC, [&](int64_t cb, int64_t ce) {
+        for (int64_t k = cb; k < ce; ++k)
+          {
+            const int L = cell_level[k];
+            if (L < 0 || Wn[L] == 0)
+              continue;
+            const Level &lv = levels[L];
             for (int a = 0; a < 4; ++a)
               {
                 const int32_t n = m->cell_nodes[4 * k + a];
-                int32_t &slot = node_at[(size_t)((ciy[k] - lv.iy0 + (a >> 1)) * W + (cix[k] - lv.ix0 + (a & 1)))];
-                if (slot == -1)
-                  slot = n;
-                else if (slot != n)
-                  dup[n] = dup[slot] = 1;
+                int32_t *slot = &node_at[(size_t)(off[L] + (ciy[k] - lv.iy0 + (a >> 1)) * Wn[L] + (cix[k] - lv.ix0 + (a & 1)))];
+                int32_t seen = -1;
+                if (!__atomic_compare_exchange_n(slot, &seen, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED) && seen != n)
+                  dup[n] = dup[seen] = 1; // (bytes, racing writers store the same value)
               }
-      }
+          }
+      }, 8192);
+    }
     auto hanging = [&](int32_t n) { return (!hn_index.empty() && hn_index[n] >= 0) || dup[n] != 0; };
     std::vector<uint8_t> regular((size_t)N, 0);
+    std::vector<int8_t> node_level((size_t)N, -1); // of regular nodes: the common level of their four cells
     int64_t n_regular = 0;
-    for (int32_t n = 0; n < NO; ++n)
-      {
-        if (n_inc[n] != 4 || node_level[n] < 0 || hanging(n) || is_parent[n])
-          continue;
-        bool ok = true;
-        for (int a = 0; a < 4 && ok; ++a)
+    {
+      const int nt = chunks_for(NO, 8192);
+      std::vector<int64_t> cnt((size_t)nt, 0);
+      parallel_chunks(nt, [&](int t) {
+        int64_t mine = 0;
+        for (int64_t n = (int64_t)NO * t / nt; n < (int64_t)NO * (t + 1) / nt; ++n)
           {
-            const int32_t k = inc[(size_t)n * 4 + a];
-            ok = k >= 0;
-            if (ok)
+            if (hanging((int32_t)n) || is_parent[n])
+              continue;
+            const int32_t k0 = inc[(size_t)n * 4 + 0], k1 = inc[(size_t)n * 4 + 1], k2 = inc[(size_t)n * 4 + 2], k3 = inc[(size_t)n * 4 + 3];
+            if (k0 < 0 || k1 < 0 || k2 < 0 || k3 < 0)
+              continue; // not exactly four cells, one at each corner
+            const int8_t L = cell_level[k0];
+            if (L < 0 || cell_level[k1] != L || cell_level[k2] != L || cell_level[k3] != L)
+              continue;
+            bool ok = true;
+            for (const int32_t k : {k0, k1, k2, k3})
               for (int b = 0; b < 4; ++b)
                 ok = ok && !hanging(m->cell_nodes[4 * k + b]);
-          }
-        // the four cells really are the 2 x 2 cells around n on the level's lattice
-        if (ok)
-          {
-            const int32_t k3 = inc[(size_t)n * 4 + 3], k2 = inc[(size_t)n * 4 + 2], k1 = inc[(size_t)n * 4 + 1], k0 = inc[(size_t)n * 4 + 0];
-            ok = cix[k2] == cix[k3] + 1 && ciy[k2] == ciy[k3] && cix[k1] == cix[k3] && ciy[k1] == ciy[k3] + 1 && cix[k0] == cix[k3] + 1 &&
+            // the four cells really are the 2 x 2 cells around n on the level's lattice
+            ok = ok && cix[k2] == cix[k3] + 1 && ciy[k2] == ciy[k3] && cix[k1] == cix[k3] && ciy[k1] == ciy[k3] + 1 && cix[k0] == cix[k3] + 1 &&
                  ciy[k0] == ciy[k3] + 1;
+            if (ok)
+              {
+                regular[n] = 1;
+                node_level[n] = L;
+                ++mine;
+              }
           }
-        if (ok)
-          {
-            regular[n] = 1;
-            ++n_regular;
-          }
-      }
+        cnt[(size_t)t] = mine;
+      });
+      for (const int64_t q : cnt)
+        n_regular += q;
+    }
     if (n_regular == 0)
       return pl;
     // blocks: block (bx, by) of a level owns the lattice nodes [7 bx, 7 bx + 6] x [7 by, 7 by + 6] and holds the cells
     // [7 bx - 1, 7 bx + 6] x [7 by - 1, 7 by + 6]; node (i, j) of the lattice = upper-right vertex of cell (i - 1, j - 1)
     std::vector<int32_t> blk_cells, blk_nodes;
-    for (size_t L = 0; L < levels.size(); ++L)
+    for (int L = 0; L < NL; ++L)
       {
         const Level &lv = levels[L];
         if (lv.ix0 > lv.ix1)
@@ -791,21 +1190,29 @@ namespace
         const long long W = lv.ix1 - lv.ix0 + 1, Hh = lv.iy1 - lv.iy0 + 1;
         if ((double)W * (double)Hh > 4.0e8)
           continue; // a level whose bounding box is mostly empty: not worth a dense table
-        std::vector<int32_t> at((size_t)(W * Hh), -1);
-        for (const int32_t k : level_cells[L])
-          at[(size_t)((ciy[k] - lv.iy0) * W + (cix[k] - lv.ix0))] = k;
+        std::vector<int32_t> at((size_t)(W * Hh));
+        parallel_for(W * Hh, [&](int64_t b, int64_t e) { std::fill(at.begin() + b, at.begin() + e, -1); });
+        parallel_for(NC, [&](int64_t cb, int64_t ce) {
+          for (int64_t k = cb; k < ce; ++k)
+            if (cell_level[k] == (int8_t)L)
+              at[(size_t)((ciy[k] - lv.iy0) * W + (cix[k] - lv.ix0))] = (int32_t)k;
+        });
         auto cell_at = [&](long long i, long long j) -> int32_t {
           return (i < lv.ix0 || i > lv.ix1 || j < lv.iy0 || j > lv.iy1) ? -1 : at[(size_t)((j - lv.iy0) * W + (i - lv.ix0))];
         };
         auto floordiv = [](long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
         const long long bx0 = floordiv(lv.ix0, 7), bx1 = floordiv(lv.ix1 + 1, 7), by0 = floordiv(lv.iy0, 7), by1 = floordiv(lv.iy1 + 1, 7);
-        for (long long by = by0; by <= by1; ++by)
-          for (long long bx = bx0; bx <= bx1; ++bx)
+        const long long nbx = bx1 - bx0 + 1, nblk = nbx * (by1 - by0 + 1);
+        const int nt = chunks_for(nblk, 64);
+        std::vector<std::vector<int32_t>> pc((size_t)nt), pn((size_t)nt);
+        parallel_chunks(nt, [&](int t) {
+          for (long long q = nblk * t / nt; q < nblk * (t + 1) / nt; ++q)
             {
+              const long long by = by0 + q / nbx, bx = bx0 + q % nbx;
               int32_t cells[64], nodes[81];
               bool any = false;
-              for (int q = 0; q < 81; ++q)
-                nodes[q] = -1;
+              for (int i = 0; i < 81; ++i)
+                nodes[i] = -1;
               for (int cy = 0; cy < 8; ++cy)
                 for (int cx = 0; cx < 8; ++cx)
                   {
@@ -831,9 +1238,15 @@ namespace
                     if (n >= 0 && n < NO && regular[n] && node_level[n] != (int8_t)L)
                       nodes[hx + 9 * hy] = -1;
                   }
-              blk_cells.insert(blk_cells.end(), cells, cells + 64);
-              blk_nodes.insert(blk_nodes.end(), nodes, nodes + 81);
+              pc[(size_t)t].insert(pc[(size_t)t].end(), cells, cells + 64);
+              pn[(size_t)t].insert(pn[(size_t)t].end(), nodes, nodes + 81);
             }
+        });
+        for (int t = 0; t < nt; ++t)
+          {
+            blk_cells.insert(blk_cells.end(), pc[(size_t)t].begin(), pc[(size_t)t].end());
+            blk_nodes.insert(blk_nodes.end(), pn[(size_t)t].begin(), pn[(size_t)t].end());
+          }
       }
     const int n_blocks = (int)(blk_cells.size() / 64);
     if (n_blocks == 0)
@@ -841,28 +1254,32 @@ namespace
     // only the rows some block really writes are the patch kernel's (a level without a table above keeps its rows general)
     {
       std::vector<uint8_t> covered((size_t)N, 0);
+      const int nt = chunks_for(n_blocks, 64);
+      std::vector<int64_t> cnt((size_t)nt, 0);
+      parallel_chunks(nt, [&](int t) {
+        int64_t mine = 0;
+        for (int64_t b = (int64_t)n_blocks * t / nt; b < (int64_t)n_blocks * (t + 1) / nt; ++b)
+          for (int hy = 1; hy <= 7; ++hy)
+            for (int hx = 1; hx <= 7; ++hx)
+              {
+                const int32_t n = blk_nodes[(size_t)b * 81 + hx + 9 * hy];
+                if (n >= 0 && n < NO && regular[n] && !__atomic_exchange_n(&covered[n], (uint8_t)1, __ATOMIC_RELAXED))
+                  ++mine;
+              }
+        cnt[(size_t)t] = mine;
+      });
       n_regular = 0;
-      for (int b = 0; b < n_blocks; ++b)
-        for (int hy = 1; hy <= 7; ++hy)
-          for (int hx = 1; hx <= 7; ++hx)
-            {
-              const int32_t n = blk_nodes[(size_t)b * 81 + hx + 9 * hy];
-              if (n >= 0 && n < NO && regular[n] && !covered[n])
-                {
-                  covered[n] = 1;
-                  ++n_regular;
-                }
-            }
+      for (const int64_t q : cnt)
+        n_regular += q;
       regular.swap(covered);
     }
     // the rows of the general family (zeroed before every Jacobian; the patch kernel stores its rows whole)
-    std::vector<int32_t> rows_general;
-    for (int32_t n = 0; n < NO; ++n)
-      if (!regular[n])
-        rows_general.push_back(n);
-    pl.hang.assign((size_t)N, 0);
-    for (int32_t n = 0; n < N; ++n)
-      pl.hang[n] = hanging(n) ? 1 : 0;
+    std::vector<int32_t> rows_general = parallel_select(0, NO, [&](int64_t n) { return !regular[n]; });
+    pl.hang.resize((size_t)N);
+    parallel_for(N, [&](int64_t nb, int64_t ne) {
+      for (int64_t n = nb; n < ne; ++n)
+        pl.hang[n] = hanging((int32_t)n) ? 1 : 0;
+    });
     pl.regular.swap(regular);
     pl.blk_cells.swap(blk_cells);
     pl.blk_nodes.swap(blk_nodes);
@@ -873,7 +1290,7 @@ namespace
   }
 
   // context part: reduced colour lists, uploads (after the colour classes and the node graph exist)
-  void finish_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan &pl, const std::vector<int32_t> &order)
+  void finish_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan &pl, const pfm::raw_vector<int32_t> &order)
   {
     DevView &v = c->v;
     const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
@@ -884,37 +1301,64 @@ namespace
     std::vector<int32_t> &blk_cells = pl.blk_cells, &blk_nodes = pl.blk_nodes, &rows_general = pl.rows_general;
     const int n_blocks = pl.n_blocks;
     const int64_t n_regular = pl.n_regular;
-    // a regular node has the nine nodes of its 2 x 2 cells in its row and nothing else, by construction; checked where the
-    // node graph is on the host (a violation would mean a coupling this classification does not know: no overlay then)
+    // a regular node has the nine nodes of its 2 x 2 cells in its row and nothing else, by construction; checked against the
+    // node graph, on the host or (general mesh: the graph was built there) on the device below (a violation would mean a
+    // coupling this classification does not know: no overlay then)
     if (c->h_nadj_ptr.size() == (size_t)NO + 1)
-      for (int32_t n = 0; n < NO; ++n)
-        if (regular[n] && c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n] != 9)
+      {
+        std::atomic<bool> nine{true};
+        parallel_for(NO, [&](int64_t nb, int64_t ne) {
+          for (int64_t n = nb; n < ne; ++n)
+            if (regular[n] && c->h_nadj_ptr[n + 1] - c->h_nadj_ptr[n] != 9)
+              nine = false;
+        });
+        if (!nine)
           return;
-    auto hanging = [&](int32_t n) { return pl.hang[n] != 0; };
+      }
     (void)N;
     // reduced lists of the general family: the cells that touch a row the patches do not write
-    std::vector<uint8_t> need((size_t)NC, 0);
-    for (int64_t k = 0; k < NC; ++k)
-      for (int a = 0; a < 4; ++a)
+    std::vector<uint8_t> need((size_t)NC);
+    parallel_for(NC, [&](int64_t cb, int64_t ce) {
+      for (int64_t k = cb; k < ce; ++k)
         {
-          const int32_t n = m->cell_nodes[4 * k + a];
-          if (hanging(n) || (n < NO && !regular[n]))
-            need[k] = 1;
+          uint8_t q = 0;
+          for (int a = 0; a < 4; ++a)
+            {
+              const int32_t n = m->cell_nodes[4 * k + a];
+              if (pl.hang[n] != 0 || (n < NO && !regular[n]))
+                q = 1;
+            }
+          need[k] = q;
         }
+    });
     std::vector<int32_t> order_red;
     c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
     for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
       {
         c->color_ptr_reduced[cl] = (long long)order_red.size();
-        for (long long i = c->color_ptr[cl]; i < c->color_ptr[cl + 1]; ++i)
-          if (need[order[(size_t)i]])
-            order_red.push_back(order[(size_t)i]);
+        const std::vector<int32_t> pos = parallel_select(c->color_ptr[cl], c->color_ptr[cl + 1], [&](int64_t i) { return need[order[(size_t)i]] != 0; });
+        for (const int32_t i : pos)
+          order_red.push_back(order[(size_t)i]);
       }
     c->color_ptr_reduced.back() = (long long)order_red.size();
     c->n_general_cells = (int64_t)order_red.size();
     if (order_red.empty())
       order_red.push_back(0);
     v.row_patch = dev_upload(c, regular.data(), regular.size());
+    if (c->graph_dev_only && c->h_nadj_ptr.empty())
+      {
+        int bad = 1;
+        if (launch_check_row_lengths(v.row_patch, v.nadj_ptr, NO, 9, v.status, nullptr) != PFM_OK ||
+            hipMemcpy(&bad, v.status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+          throw HipFail{hipGetLastError(), "row length check"};
+        if (bad)
+          {
+            if (hipMemset(v.status, 0, sizeof(int)) != hipSuccess)
+              throw HipFail{hipGetLastError(), "hipMemset"};
+            v.row_patch = nullptr;
+            return;
+          }
+      }
     v.patch_cells = dev_upload(c, blk_cells.data(), blk_cells.size());
     v.patch_nodes = dev_upload(c, blk_nodes.data(), blk_nodes.size());
     c->d_node_slots = dev_alloc<unsigned long long>(c, (size_t)std::max<int32_t>(NO, 1));
@@ -1168,7 +1612,7 @@ namespace
   }
 
   // context part: reduced colour lists of the general family, uploads of the level lattices
-  void finish_patches3d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan3 &pl, const std::vector<int32_t> &order)
+  void finish_patches3d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan3 &pl, const pfm::raw_vector<int32_t> &order)
   {
     DevView &v = c->v;
     const int32_t NO = m->n_owned_nodes;
@@ -1252,6 +1696,7 @@ extern "C"
   int pfm_ctx_create(pfm_ctx **out, const pfm_mesh_desc *m, int device)
   {
     PhaseClock clk;
+    H2dBatch batch; // uploads are ordered on the null stream; the build ends with a device synchronisation
     if (!out || !m || (m->dim != 2 && m->dim != 3) ||
         (m->layout != PFM_LAYOUT_INTERLEAVED && m->layout != PFM_LAYOUT_BLOCKED) ||
         m->n_nodes <= 0 || m->n_owned_nodes < 0 || m->n_owned_nodes > m->n_nodes || m->n_cells < 0 ||
@@ -1294,8 +1739,81 @@ extern "C"
     clk.mark("argument checks");
     Lattice &lattice = c->lat;
     bool lattice_ok = false;
+    // The cell table and the coordinates go to the device as the host handed them over (cell-major / node-major) and are
+    // transposed to SoA by a kernel (a host transposition of 8e7 + 3e7 entries cost 0.25 s at 1e7 cells).  Large meshes: on
+    // a second thread, next to the host passes below that read the same tables (lattice detection: 20 ms at 1e7 cells).
+    struct MeshUpload
+    {
+      int32_t *raw = nullptr, *conn = nullptr;
+      double *rawx = nullptr, *xs = nullptr;
+      int rct = PFM_OK, rcx = PFM_OK;
+      hipError_t err = hipSuccess;
+      const char *what = "";
+    } up;
+    auto upload_mesh = [&]() {
+      H2dBatch in_batch;
+      auto bad = [&](hipError_t e, const char *what) {
+        up.err = e;
+        up.what = what;
+      };
+      if (hipSetDevice(device) != hipSuccess)
+        return bad(hipGetLastError(), "hipSetDevice");
+      const size_t cb = sizeof(int32_t) * std::max<size_t>((size_t)NC * nv, 1), xb = sizeof(double) * (size_t)N * dim;
+      if (hipMalloc((void **)&up.raw, cb) != hipSuccess || hipMalloc((void **)&up.conn, cb) != hipSuccess ||
+          hipMalloc((void **)&up.rawx, xb) != hipSuccess || hipMalloc((void **)&up.xs, xb) != hipSuccess)
+        return bad(hipGetLastError(), "hipMalloc");
+      hipError_t e2 = NC > 0 ? h2d(up.raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
+      if (e2 != hipSuccess)
+        return bad(e2, "hipMemcpy H2D");
+      up.rct = launch_aos_to_soa_i32(up.raw, up.conn, NC, nv, nullptr);
+      e2 = h2d(up.rawx, m->coords, xb);
+      if (e2 != hipSuccess)
+        return bad(e2, "hipMemcpy H2D");
+      up.rcx = launch_aos_to_soa_f64(up.rawx, up.xs, N, dim, nullptr);
+    };
+    std::thread upload_thread;
+    struct UploadJoiner // an early return or an exception must not leave the thread running, nor its buffers behind
+    {
+      std::thread &t;
+      MeshUpload &u;
+      bool taken = false;
+      ~UploadJoiner()
+      {
+        if (t.joinable())
+          t.join();
+        if (!taken)
+          for (void *q : {(void *)u.raw, (void *)u.conn, (void *)u.rawx, (void *)u.xs})
+            if (q)
+              (void)hipFree(q);
+      }
+    } upload_joiner{upload_thread, up};
     try
       {
+        // constraint bytes, the nodal state and the status word: one allocation, one clear (a hipMalloc costs 0.1-3 ms)
+        {
+          const size_t sb = ((size_t)N * sizeof(double) + 255) & ~(size_t)255, fb = ((size_t)N + 255) & ~(size_t)255;
+          const size_t total = fb + (size_t)(dim + 3) * sb + 256;
+          char *slab = dev_alloc<char>(c, total);
+          e = hipMemsetAsync(slab, 0, total, nullptr);
+          if (e != hipSuccess)
+            throw HipFail{e, "hipMemset"};
+          v.node_flags = reinterpret_cast<uint8_t *>(slab);
+          char *at = slab + fb;
+          auto take = [&]() {
+            double *q = reinterpret_cast<double *>(at);
+            at += sb;
+            return q;
+          };
+          for (int d = 0; d < 3; ++d)
+            v.u[d] = (d < dim) ? take() : nullptr;
+          v.phi = take();
+          v.phi_old = take();
+          v.phi_oldold = take();
+          v.status = reinterpret_cast<int *>(at);
+        }
+        clk.mark("state buffers");
+        if (NC > (1 << 20))
+          upload_thread = std::thread(upload_mesh);
         // ---- hanging table: node -> k
         std::vector<int32_t> hn_index;
         if (m->n_hanging > 0)
@@ -1326,7 +1844,7 @@ extern "C"
 
         // Colour classes (below) only read host tables: on a general mesh they are computed by a host thread NEXT TO the
         // uploads and the device build of the node graph (1.7 of the remaining 5.8 ms of a rebuild at 2.7e5 cells).
-        std::vector<int32_t> order((size_t)NC);
+        pfm::raw_vector<int32_t> order((size_t)NC);
         std::vector<uint8_t> ring;
         bool any_ring = false;
         std::exception_ptr colour_err;
@@ -1337,7 +1855,7 @@ extern "C"
           // launch with plain read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter
           // of a 2-D Jacobian took 1.1 of 1.2 ms).  Lattice: parity of the cell's lattice position; otherwise greedy
           // in cell order.  Cells with a hanging vertex go to the last class, which keeps the atomics.
-          std::vector<uint8_t> col((size_t)NC);
+          pfm::raw_vector<uint8_t> col((size_t)NC);
           int n_col = 0;
           if (lattice_ok)
             {
@@ -1414,15 +1932,32 @@ extern "C"
                       any_ring = any_ring || r;
                     }
             }
+          // cells in class order, ascending cell number within a class (a counting sort, chunked over the host threads)
           c->color_ptr.assign((size_t)n_col + 2, 0);
-          for (int64_t cell = 0; cell < NC; ++cell)
-            ++c->color_ptr[col[cell] + 1];
-          for (int k = 0; k <= n_col; ++k)
-            c->color_ptr[k + 1] += c->color_ptr[k];
           {
-            std::vector<long long> fill(c->color_ptr.begin(), c->color_ptr.end() - 1);
-            for (int64_t cell = 0; cell < NC; ++cell)
-              order[fill[col[cell]]++] = (int32_t)cell;
+            const int nt = chunks_for(NC, 65536), nk = n_col + 1;
+            std::vector<long long> hist((size_t)nt * nk, 0);
+            parallel_chunks(nt, [&](int t) {
+              long long *hh = hist.data() + (size_t)t * nk;
+              for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+                ++hh[col[cell]];
+            });
+            for (int k = 0; k < nk; ++k)
+              {
+                long long at = c->color_ptr[k];
+                for (int t = 0; t < nt; ++t)
+                  {
+                    const long long cnt = hist[(size_t)t * nk + k];
+                    hist[(size_t)t * nk + k] = at;
+                    at += cnt;
+                  }
+                c->color_ptr[k + 1] = at;
+              }
+            parallel_chunks(nt, [&](int t) {
+              long long *fill = hist.data() + (size_t)t * nk;
+              for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+                order[fill[col[cell]]++] = (int32_t)cell;
+            });
           }
             }
           catch (...)
@@ -1465,27 +2000,25 @@ extern "C"
 
         // ---- device mirrors (SoA)
         {
-          // host order (cell-major / node-major) -> SoA on the device: the raw tables are uploaded as they are and
-          // transposed by a kernel (a host transposition of 8e7 + 3e7 entries cost 0.25 s at 1e7 cells)
-          int32_t *raw = nullptr;
-          if (NC > 0 && hipMalloc((void **)&raw, sizeof(int32_t) * (size_t)NC * nv) != hipSuccess)
-            throw HipFail{hipGetLastError(), "hipMalloc"};
-          int32_t *conn = dev_alloc<int32_t>(c, (size_t)NC * nv);
-          clk.mark("  conn buffers");
-          hipError_t e2 = NC > 0 ? h2d(raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
-          clk.mark("  conn h2d");
-          const int rct = e2 == hipSuccess ? launch_aos_to_soa_i32(raw, conn, NC, nv, nullptr) : PFM_ERR_HIP;
-          double *rawx = nullptr;
-          if (hipMalloc((void **)&rawx, sizeof(double) * (size_t)N * dim) != hipSuccess)
+          if (upload_thread.joinable())
+            upload_thread.join();
+          else
+            upload_mesh();
+          upload_joiner.taken = true;
+          clk.mark("  conn + coords h2d");
+          int32_t *raw = up.raw, *conn = up.conn;
+          double *rawx = up.rawx, *xs = up.xs;
+          for (void *q : {(void *)conn, (void *)xs})
+            if (q)
+              c->allocs.push_back(q);
+          c->device_bytes += (int64_t)(sizeof(int32_t) * (size_t)NC * nv + sizeof(double) * (size_t)N * dim);
+          if (up.err != hipSuccess)
             {
               (void)hipFree(raw);
-              throw HipFail{hipGetLastError(), "hipMalloc"};
+              (void)hipFree(rawx);
+              throw HipFail{up.err, up.what};
             }
-          double *xs = dev_alloc<double>(c, (size_t)N * dim);
-          clk.mark("  coords buffers");
-          e2 = h2d(rawx, m->coords, sizeof(double) * (size_t)N * dim);
-          clk.mark("  coords h2d");
-          const int rcx = e2 == hipSuccess ? launch_aos_to_soa_f64(rawx, xs, N, dim, nullptr) : PFM_ERR_HIP;
+          const int rct = up.rct, rcx = up.rcx;
           int rcg = PFM_OK;
           v.hn_index = nullptr;
           v.hn_ptr = nullptr;
@@ -1501,6 +2034,7 @@ extern "C"
                   v.hn_parents = dev_upload(c, m->hn_parents, (size_t)hp.back());
                   v.hn_weights = dev_upload(c, m->hn_weights, (size_t)hp.back());
                 }
+              clk.mark("  hanging tables");
               if (device_graph && rct == PFM_OK)
                 {
                   // node graph of a general mesh on the device, from the cell table as the host handed it over
@@ -1512,18 +2046,18 @@ extern "C"
                   } g;
                   long long total = 0;
                   rcg = graph_build_begin(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, g.sc, total, nullptr);
+                  clk.mark("  graph rows counted");
                   if (rcg == PFM_OK)
                     {
                       int32_t *d_adj = dev_alloc<int32_t>(c, (size_t)std::max<long long>(total, 1));
                       rcg = graph_build_rows(raw, NC, nv, NO, v.hn_index, v.hn_ptr, v.hn_parents, d_ptr, d_adj, g.sc, nullptr);
-                      c->h_nadj_ptr.assign((size_t)NO + 1, 0);
-                      if (rcg == PFM_OK && hipMemcpy(c->h_nadj_ptr.data(), d_ptr, sizeof(long long) * ((size_t)NO + 1), hipMemcpyDeviceToHost) != hipSuccess)
-                        rcg = PFM_ERR_HIP;
+                      clk.mark("  graph rows filled");
                       if (rcg == PFM_OK)
                         {
                           v.nadj_ptr = d_ptr;
                           v.nadj = d_adj;
-                          c->graph_dev_only = true; // the host copy of the columns is fetched when a pattern query asks for it
+                          c->nadj_total = total;
+                          c->graph_dev_only = true; // the host copy of rows and row pointers is fetched when a pattern query asks for it
                         }
                     }
                 }
@@ -1534,8 +2068,9 @@ extern "C"
               (void)hipFree(rawx);
               throw;
             }
+          clk.mark("  row pointers to the host");
           const hipError_t es = hipDeviceSynchronize();
-          clk.mark("  transposes, node graph");
+          clk.mark("  device synchronize");
           (void)hipFree(raw);
           (void)hipFree(rawx);
           if (rcg == PFM_ERR_UNSUPPORTED)
@@ -1546,14 +2081,32 @@ extern "C"
           v.coords = xs;
         }
         clk.mark("conn + coords upload");
-        if (colour_thread.joinable())
-          colour_thread.join();
+        if (lattice_ok && dim == 3)
+          {
+            // uniform 3-D box: the cartesian family runs it; the lists of the general family (eight parity classes, their sizes
+            // known from the box) are sorted on the device when that family is first asked for (ensure_general_tables)
+            c->color_ptr.assign(10, 0);
+            for (int k = 0; k < 8; ++k)
+              {
+                auto half = [](int n, int odd) { return (long long)(odd ? n / 2 : (n + 1) / 2); };
+                c->color_ptr[(size_t)k + 1] = c->color_ptr[k] + half(lattice.nc[0], k & 1) * half(lattice.nc[1], (k >> 1) & 1) * half(lattice.nc[2], (k >> 2) & 1);
+              }
+            c->color_ptr[9] = c->color_ptr[8];
+            c->colours_lazy = true;
+            v.color_cells = nullptr;
+            v.cell_ring = nullptr;
+          }
         else
-          colour_classes();
-        if (colour_err)
-          std::rethrow_exception(colour_err);
-        v.color_cells = dev_upload(c, order.data(), order.size());
-        v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
+          {
+            if (colour_thread.joinable())
+              colour_thread.join();
+            else
+              colour_classes();
+            if (colour_err)
+              std::rethrow_exception(colour_err);
+            v.color_cells = dev_upload(c, order.data(), order.size());
+            v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
+          }
         clk.mark("colour classes");
         if (patch_thread.joinable())
           patch_thread.join();
@@ -1570,7 +2123,14 @@ extern "C"
             v.cell_lambda = dev_upload(c, m->cell_lambda, (size_t)NC);
             v.cell_mu = dev_upload(c, m->cell_mu, (size_t)NC);
           }
-        if (!c->graph_dev_only)
+        if (c->graph_positional)
+          {
+            long long *d_ptr = dev_alloc<long long>(c, (size_t)NO + 1);
+            if (launch_lattice_row_ptr(d_ptr, lattice.NX, lattice.NY, lattice.NZ, nullptr) != PFM_OK)
+              throw HipFail{hipGetLastError(), "lattice row pointers"};
+            v.nadj_ptr = d_ptr;
+          }
+        else if (!c->graph_dev_only)
           v.nadj_ptr = dev_upload(c, c->h_nadj_ptr.data(), c->h_nadj_ptr.size());
         // node graph columns + slot table of the general kernel family (position of vertex b's node in the row of
         // vertex a's node, searched on the device: 64 row searches per hex, 8 s on one host core at 1e7 cells); a
@@ -1588,28 +2148,6 @@ extern "C"
             if (launch_build_cslot(v, nullptr) != PFM_OK)
               throw HipFail{hipGetLastError(), "cslot kernel"};
           }
-        uint8_t *flags = dev_alloc<uint8_t>(c, (size_t)N);
-        e = hipMemset(flags, 0, (size_t)N);
-        if (e != hipSuccess)
-          throw HipFail{e, "hipMemset"};
-        v.node_flags = flags;
-        for (int d = 0; d < 3; ++d)
-          v.u[d] = (d < dim) ? dev_alloc<double>(c, (size_t)N) : nullptr;
-        v.phi = dev_alloc<double>(c, (size_t)N);
-        v.phi_old = dev_alloc<double>(c, (size_t)N);
-        v.phi_oldold = dev_alloc<double>(c, (size_t)N);
-        auto zero = [](void *q, size_t bytes) {
-          const hipError_t e = hipMemset(q, 0, bytes);
-          if (e != hipSuccess)
-            throw HipFail{e, "hipMemset"};
-        };
-        for (int d = 0; d < dim; ++d)
-          zero(v.u[d], sizeof(double) * (size_t)N);
-        zero(v.phi, sizeof(double) * (size_t)N);
-        zero(v.phi_old, sizeof(double) * (size_t)N);
-        zero(v.phi_oldold, sizeof(double) * (size_t)N);
-        v.status = dev_alloc<int>(c, 1);
-        zero(v.status, sizeof(int));
       }
     catch (const HipFail &f)
       {
@@ -1780,6 +2318,10 @@ extern "C"
       {
         return PFM_ERR_NOMEM;
       }
+    catch (const HipFail &)
+      {
+        return PFM_ERR_HIP;
+      }
     int64_t pos = 0, row = 0;
     rowptr[0] = 0;
     for (int32_t n = 0; n < c->v.n_owned; ++n)
@@ -1825,6 +2367,10 @@ extern "C"
     catch (const std::bad_alloc &)
       {
         return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+      }
+    catch (const HipFail &f)
+      {
+        return hipfail(c, f.e, f.what);
       }
     std::vector<int32_t> order(c->h_nadj.size());
     std::atomic<int> bad{0}; // 1: structure, 2: column set
@@ -2461,7 +3007,7 @@ extern "C"
         if (!c->d_nbr_mask3)
           {
             c->d_nbr_mask3 = dev_alloc<uint32_t>(c, (size_t)std::max<int32_t>(c->v.n_owned, 1));
-            c->d_row_perm3 = dev_alloc<uint8_t>(c, (size_t)std::max<long long>(c->h_nadj_ptr.empty() ? 1 : c->h_nadj_ptr.back(), 1));
+            c->d_row_perm3 = dev_alloc<uint8_t>(c, (size_t)std::max<long long>(c->nadj_total >= 0 ? c->nadj_total : (c->h_nadj_ptr.empty() ? 1 : c->h_nadj_ptr.back()), 1));
           }
       }
     catch (const HipFail &f)

@@ -6,6 +6,9 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <memory>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/pfm_assemble.h"
 
@@ -102,11 +105,36 @@ namespace pfm
   }
 
   // host copy of the lattice tables of a uniform box (kept for pfm_pattern_bind)
+  // std::vector whose resize(n) / vector(n) leaves trivially constructible elements uninitialised: tables of 1e7 entries that
+  // are written once by the host threads are not cleared (and their pages not touched) by one thread first
+  template <class T>
+  struct default_init_allocator : std::allocator<T>
+  {
+    template <class U>
+    struct rebind
+    {
+      using other = default_init_allocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+      ::new (static_cast<void *>(p)) U;
+    }
+    template <class U, class... A>
+    void construct(U *p, A &&...a)
+    {
+      ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+    }
+  };
+  template <class T>
+  using raw_vector = std::vector<T, default_init_allocator<T>>;
+
   struct LatticeHost
   {
     int NX = 0, NY = 0, NZ = 0, nc[3] = {0, 0, 0};
     double h[3] = {1, 1, 1};
-    std::vector<int32_t> local_of_box, box_of_local;
+    raw_vector<int32_t> local_of_box, box_of_local;
   };
 
   struct HaloPeer
@@ -175,6 +203,9 @@ namespace pfm
                        const int32_t *d_hn_parents, const long long *d_nadj_ptr, int32_t *d_nadj, const GraphScratch &sc, hipStream_t s);
   void graph_build_free(GraphScratch &sc);
   // row tables (CartView::nbr_mask, row_perm) of one level lattice of the 3-D cartesian overlay, from the current row order
+  int launch_lattice_row_ptr(long long *d_ptr, int NX, int NY, int NZ, hipStream_t s);
+  int launch_lattice_colour_order(int32_t *d_order, const int32_t *d_vertex0, const int32_t *d_box_of_local, long long NC, int NX, int NY, hipStream_t s);
+  int launch_check_row_lengths(const uint8_t *d_mark, const long long *d_ptr, int32_t NO, int want, int *d_bad, hipStream_t s);
   int launch_overlay3_rows(const int32_t *d_node_at, const int32_t *d_row_at, int NX, int NY, int NZ, const long long *d_nadj_ptr,
                            const int32_t *d_nadj, uint32_t *d_nbr_mask, uint8_t *d_row_perm, int *d_bad, hipStream_t s);
   // host: indices of the tiles of k_cart_uu3 / k_cart_residual3 that read a ghost node (pfm_assemble_overlapped, phase 2)
@@ -210,11 +241,14 @@ struct pfm_ctx
   bool cart_ok = false;
   pfm::CartView cv{};
   // host copies needed for pattern queries
-  std::vector<long long> h_nadj_ptr;
+  pfm::raw_vector<long long> h_nadj_ptr;
+  long long nadj_total = -1; // entries of the node graph when its row pointers only exist on the device so far (graph_dev_only)
   std::vector<int32_t> h_nadj;
   // Lattice meshes: the 27-wide host node graph (h_nadj), its device copy (v.nadj) and the slot table of the general
   // cell kernel (v.cslot) are 1.1 + 1.1 + 0.65 GB at 1e7 cells and are only needed by pfm_pattern_get / _bind and by the
   // general family: built on first use (ensure_host_graph, ensure_general_tables in pfm_host.cpp)
+  bool graph_positional = false; // uniform box, node n at lattice position n, no ghosts: row pointers and colour lists are made on the device
+  bool colours_lazy = false;     // DevView::color_cells is filled when the general family is first used (ensure_general_tables)
   bool graph_lazy = false;    // h_nadj not materialised yet (h_nadj_ptr is)
   bool graph_dev_only = false; // general mesh: v.nadj was built on the device (pfm_graph.hip), h_nadj is fetched on demand
   bool general_ready = true;  // v.nadj and v.cslot exist on the device
