@@ -99,28 +99,46 @@ namespace
     std::condition_variable cv, cv_done;
     std::vector<std::thread> th;
     const std::function<void(int)> *job = nullptr;
-    uint64_t gen = 0;
-    int want = 0, left = 0;
-    bool stop = false;
+    std::atomic<uint64_t> gen{0};
+    std::atomic<int> left{0};
+    int want = 0;
+    std::atomic<bool> stop{false};
 
+    // the loops of a rebuild follow one another within microseconds: a worker (and the caller, for the end of a region) polls
+    // for ~50 us before it sleeps on the condition variable (a sleep and a wake-up cost 30-50 us each with 16 threads)
+    static bool spin_until(const std::function<bool()> &ready)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0;; ++i)
+        {
+          if (ready())
+            return true;
+          __builtin_ia32_pause();
+          if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50))
+            return false;
+        }
+    }
     void worker(int id)
     {
       uint64_t seen = 0;
-      std::unique_lock<std::mutex> lk(mx);
       for (;;)
         {
-          cv.wait(lk, [&] { return stop || gen != seen; });
-          if (stop)
-            return;
-          seen = gen;
-          if (id < want)
+          if (!spin_until([&] { return stop.load(std::memory_order_acquire) || gen.load(std::memory_order_acquire) != seen; }))
             {
-              const std::function<void(int)> *j = job;
-              lk.unlock();
-              (*j)(id);
-              lk.lock();
-              if (--left == 0)
-                cv_done.notify_one();
+              std::unique_lock<std::mutex> lk(mx);
+              cv.wait(lk, [&] { return stop.load() || gen.load() != seen; });
+            }
+          if (stop.load())
+            return;
+          seen = gen.load(std::memory_order_acquire);
+          // EVERY worker answers every region (those beyond `want` without running anything): want and job are then never
+          // rewritten while a worker may still read them
+          if (id < want)
+            (*job)(id);
+          if (left.fetch_sub(1, std::memory_order_acq_rel) == 1)
+            {
+              std::lock_guard<std::mutex> lk(mx);
+              cv_done.notify_one();
             }
         }
     }
@@ -130,31 +148,33 @@ namespace
       std::unique_lock<std::mutex> reg(region, std::try_to_lock);
       if (!reg.owns_lock())
         return false;
+      while ((int)th.size() + 1 < nt)
+        {
+          const int id = (int)th.size() + 1;
+          th.emplace_back([this, id] { worker(id); });
+        }
+      job = &f;
+      want = nt;
+      left.store((int)th.size(), std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
       {
-        std::unique_lock<std::mutex> lk(mx);
-        while ((int)th.size() + 1 < nt)
-          {
-            const int id = (int)th.size() + 1;
-            th.emplace_back([this, id] { worker(id); });
-          }
-        job = &f;
-        want = nt;
-        left = nt - 1;
-        ++gen;
+        std::lock_guard<std::mutex> lk(mx); // a worker is either before its look at gen or asleep and notified below
       }
       cv.notify_all();
       f(0);
-      std::unique_lock<std::mutex> lk(mx);
-      cv_done.wait(lk, [&] { return left == 0; });
+      if (!spin_until([&] { return left.load(std::memory_order_acquire) == 0; }))
+        {
+          std::unique_lock<std::mutex> lk(mx);
+          cv_done.wait(lk, [&] { return left.load() == 0; });
+        }
       job = nullptr;
-      want = 0;
       return true;
     }
     ~HostPool()
     {
+      stop.store(true);
       {
         std::lock_guard<std::mutex> lk(mx);
-        stop = true;
       }
       cv.notify_all();
       for (auto &t : th)
@@ -914,6 +934,185 @@ namespace
     int64_t n_regular = 0;
     int n_blocks = 0;
   };
+  // Colour classes of the general cell kernel: cells of one class share no node and are assembled by one launch with plain
+  // read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter of a 2-D Jacobian took 1.1 of
+  // 1.2 ms).  Greedy in cell order over the cells with subset[cell] != 0 (null: all cells); cells with a hanging vertex go to
+  // the last class, which keeps the atomics.  order: the cells by class, ascending within a class; ptr [n_col + 2].
+  struct Colours
+  {
+    std::vector<long long> ptr;
+    pfm::raw_vector<int32_t> order;
+    bool overflow = false;  // more than 62 classes were needed: such cells sit in the atomic class although no vertex hangs
+    bool cancelled = false; // the caller lost interest (cancel): ptr and order are not filled
+  };
+  template <class NodeOf>
+  void greedy_colours(int64_t NC, int nv, int32_t N, NodeOf node_of, const int32_t *hn_index, const uint8_t *subset, const std::atomic<bool> *cancel,
+                      Colours &out)
+  {
+    constexpr uint8_t NONE = 255, ATOMIC = 254;
+    pfm::raw_vector<uint8_t> col((size_t)NC);
+    std::vector<uint64_t> used((size_t)N, 0);
+    int n_col = 0;
+    for (int64_t cell = 0; cell < NC; ++cell)
+      {
+        if (subset && !subset[cell])
+          {
+            col[cell] = NONE;
+            continue;
+          }
+        if ((cell & 4095) == 0 && cancel && cancel->load(std::memory_order_relaxed))
+          {
+            out.cancelled = true;
+            return;
+          }
+        uint64_t mask = 0;
+        bool hanging = false;
+        int32_t nd[8];
+        for (int a = 0; a < nv; ++a)
+          {
+            nd[a] = node_of(cell, a);
+            mask |= used[nd[a]];
+            hanging = hanging || (hn_index && hn_index[nd[a]] >= 0);
+          }
+        int k = 63;
+        if (!hanging && ~mask != 0)
+          k = __builtin_ctzll(~mask);
+        if (k < 62)
+          {
+            for (int a = 0; a < nv; ++a)
+              used[nd[a]] |= 1ull << k;
+            n_col = std::max(n_col, k + 1);
+            col[cell] = (uint8_t)k;
+          }
+        else
+          {
+            col[cell] = ATOMIC;
+            out.overflow = out.overflow || !hanging;
+          }
+      }
+    // counting sort, chunked over the host threads
+    const int nk = n_col + 1;
+    out.ptr.assign((size_t)n_col + 2, 0);
+    const int nt = chunks_for(NC, 65536);
+    std::vector<long long> hist((size_t)nt * nk, 0);
+    parallel_chunks(nt, [&](int t) {
+      long long *hh = hist.data() + (size_t)t * nk;
+      for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+        if (col[cell] != NONE)
+          ++hh[col[cell] == ATOMIC ? n_col : col[cell]];
+    });
+    for (int k = 0; k < nk; ++k)
+      {
+        long long at = out.ptr[k];
+        for (int t = 0; t < nt; ++t)
+          {
+            const long long cnt = hist[(size_t)t * nk + k];
+            hist[(size_t)t * nk + k] = at;
+            at += cnt;
+          }
+        out.ptr[(size_t)k + 1] = at;
+      }
+    out.order.resize((size_t)std::max<long long>(out.ptr.back(), 1));
+    out.order[0] = 0;
+    parallel_chunks(nt, [&](int t) {
+      long long *fill = hist.data() + (size_t)t * nk;
+      for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+        if (col[cell] != NONE)
+          out.order[(size_t)fill[col[cell] == ATOMIC ? n_col : col[cell]]++] = (int32_t)cell;
+    });
+  }
+
+  // Cells of the plain classes that share a constraint-resolved node with a cell at a hanging vertex add atomically as well
+  // (DevView::cell_ring): every row the atomic class touches then only ever receives atomic adds, and the class -- 68
+  // latency-bound waves, 15 % of a Jacobian at 2.7e5 cells -- runs next to the others.  false: no such cell (ring empty).
+  template <class NodeOf>
+  bool ring_cells(int64_t NC, int nv, int32_t N, NodeOf node_of, const int32_t *hn_index, const int64_t *hn_ptr, const int32_t *hn_parents,
+                  std::vector<uint8_t> &ring)
+  {
+    ring.clear();
+    if (!hn_index)
+      return false;
+    std::vector<uint8_t> touched((size_t)N, 0), at_hanging((size_t)NC);
+    std::atomic<bool> any_atomic{false}, any_ring{false};
+    parallel_for(NC, [&](int64_t cb, int64_t ce) {
+      bool mine = false;
+      for (int64_t cell = cb; cell < ce; ++cell)
+        {
+          bool hanging = false;
+          for (int a = 0; a < nv; ++a)
+            hanging = hanging || hn_index[node_of(cell, a)] >= 0;
+          at_hanging[cell] = hanging ? 1 : 0;
+          if (!hanging)
+            continue;
+          mine = true;
+          for (int a = 0; a < nv; ++a)
+            {
+              const int32_t n = node_of(cell, a);
+              touched[n] = 1; // (bytes; racing writers store the same value)
+              const int32_t k = hn_index[n];
+              if (k >= 0)
+                for (long long j = hn_ptr[k]; j < hn_ptr[k + 1]; ++j)
+                  touched[hn_parents[j]] = 1;
+            }
+        }
+      if (mine)
+        any_atomic = true;
+    });
+    if (!any_atomic)
+      return false;
+    ring.resize((size_t)NC);
+    parallel_for(NC, [&](int64_t cb, int64_t ce) {
+      bool mine = false;
+      for (int64_t cell = cb; cell < ce; ++cell)
+        {
+          bool r = false;
+          if (!at_hanging[cell])
+            for (int a = 0; a < nv; ++a)
+              r = r || touched[node_of(cell, a)] != 0;
+          ring[cell] = r ? 1 : 0;
+          mine = mine || r;
+        }
+      if (mine)
+        any_ring = true;
+    });
+    if (!any_ring)
+      ring.clear();
+    return any_ring;
+  }
+
+  // The colour lists of the general family over ALL cells, for a context whose overlay made them unnecessary at pfm_ctx_create
+  // (full_colours_lazy): from the device copies of the cell table and the hanging-node index, when that family is first run
+  // without the overlay (pfm_ctx_force_path, a stress-split assembly of a 3-D overlay context)
+  void ensure_full_colours(pfm_ctx *c)
+  {
+    if (!c->full_colours_lazy)
+      return;
+    DevView &v = c->v;
+    const int64_t NC = v.n_cells;
+    const int nv = 1 << v.dim;
+    (void)hipSetDevice(c->device);
+    pfm::raw_vector<int32_t> conn((size_t)NC * nv), hn;
+    if (NC > 0 && hipMemcpy(conn.data(), v.conn, sizeof(int32_t) * conn.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      throw HipFail{hipGetLastError(), "cell table D2H"};
+    if (v.hn_index)
+      {
+        hn.resize((size_t)v.n_nodes);
+        if (hipMemcpy(hn.data(), v.hn_index, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost) != hipSuccess)
+          throw HipFail{hipGetLastError(), "hanging index D2H"};
+      }
+    Colours col;
+    greedy_colours(NC, nv, v.n_nodes, [&](int64_t cell, int a) { return conn[(size_t)a * NC + cell]; }, v.hn_index ? hn.data() : nullptr, nullptr, nullptr, col);
+    v.color_cells = dev_upload(c, col.order.data(), col.order.size());
+    c->color_ptr.swap(col.ptr);
+    if (col.overflow)
+      {
+        // (never seen: a node of more than 62 cells) every cell adds atomically
+        std::vector<uint8_t> all((size_t)NC, 1);
+        v.cell_ring = dev_upload(c, all.data(), all.size());
+      }
+    c->full_colours_lazy = false;
+  }
+
   // indices i of [b, e) with pred(i), ascending (chunked over the host threads)
   template <class P>
   std::vector<int32_t> parallel_select(int64_t b, int64_t e, P &&pred)
@@ -1290,7 +1489,7 @@ namespace
   }
 
   // context part: reduced colour lists, uploads (after the colour classes and the node graph exist)
-  void finish_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan &pl, const pfm::raw_vector<int32_t> &order)
+  void finish_patches2d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan &pl, const int32_t *hn_index)
   {
     DevView &v = c->v;
     const int32_t N = m->n_nodes, NO = m->n_owned_nodes;
@@ -1315,7 +1514,6 @@ namespace
         if (!nine)
           return;
       }
-    (void)N;
     // reduced lists of the general family: the cells that touch a row the patches do not write
     std::vector<uint8_t> need((size_t)NC);
     parallel_for(NC, [&](int64_t cb, int64_t ce) {
@@ -1331,19 +1529,15 @@ namespace
           need[k] = q;
         }
     });
-    std::vector<int32_t> order_red;
-    c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
-    for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
-      {
-        c->color_ptr_reduced[cl] = (long long)order_red.size();
-        const std::vector<int32_t> pos = parallel_select(c->color_ptr[cl], c->color_ptr[cl + 1], [&](int64_t i) { return need[order[(size_t)i]] != 0; });
-        for (const int32_t i : pos)
-          order_red.push_back(order[(size_t)i]);
-      }
-    c->color_ptr_reduced.back() = (long long)order_red.size();
-    c->n_general_cells = (int64_t)order_red.size();
-    if (order_red.empty())
-      order_red.push_back(0);
+    // its colour classes: greedy over these cells alone (the lists over all cells are made when the general family is first
+    // run without the overlay, ensure_full_colours)
+    Colours red;
+    greedy_colours(NC, 4, N, [&](int64_t cell, int a) { return m->cell_nodes[4 * cell + a]; }, hn_index, need.data(), nullptr, red);
+    if (red.overflow)
+      return; // (a node of more than 62 such cells: no overlay, the caller colours all cells)
+    c->color_ptr_reduced.swap(red.ptr);
+    pfm::raw_vector<int32_t> &order_red = red.order;
+    c->n_general_cells = (int64_t)c->color_ptr_reduced.back();
     v.row_patch = dev_upload(c, regular.data(), regular.size());
     if (c->graph_dev_only && c->h_nadj_ptr.empty())
       {
@@ -1612,34 +1806,34 @@ namespace
   }
 
   // context part: reduced colour lists of the general family, uploads of the level lattices
-  void finish_patches3d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan3 &pl, const pfm::raw_vector<int32_t> &order)
+  void finish_patches3d(pfm_ctx *c, const pfm_mesh_desc *m, PatchPlan3 &pl, const int32_t *hn_index)
   {
     DevView &v = c->v;
     const int32_t NO = m->n_owned_nodes;
     const int64_t NC = m->n_cells;
     if (pl.levels.empty())
       return;
-    std::vector<uint8_t> need((size_t)NC, 0);
-    for (int64_t k = 0; k < NC; ++k)
-      for (int a = 0; a < 8; ++a)
+    std::vector<uint8_t> need((size_t)NC);
+    parallel_for(NC, [&](int64_t cb, int64_t ce) {
+      for (int64_t k = cb; k < ce; ++k)
         {
-          const int32_t n = m->cell_nodes[8 * k + a];
-          if (pl.hang[n] || (n < NO && !pl.regular[n]))
-            need[k] = 1;
+          uint8_t q = 0;
+          for (int a = 0; a < 8; ++a)
+            {
+              const int32_t n = m->cell_nodes[8 * k + a];
+              if (pl.hang[n] || (n < NO && !pl.regular[n]))
+                q = 1;
+            }
+          need[k] = q;
         }
-    std::vector<int32_t> order_red;
-    c->color_ptr_reduced.assign(c->color_ptr.size(), 0);
-    for (size_t cl = 0; cl + 1 < c->color_ptr.size(); ++cl)
-      {
-        c->color_ptr_reduced[cl] = (long long)order_red.size();
-        for (long long i = c->color_ptr[cl]; i < c->color_ptr[cl + 1]; ++i)
-          if (need[order[(size_t)i]])
-            order_red.push_back(order[(size_t)i]);
-      }
-    c->color_ptr_reduced.back() = (long long)order_red.size();
-    c->n_general_cells = (int64_t)order_red.size();
-    if (order_red.empty())
-      order_red.push_back(0);
+    });
+    Colours red; // (see finish_patches2d)
+    greedy_colours(NC, 8, m->n_nodes, [&](int64_t cell, int a) { return m->cell_nodes[8 * cell + a]; }, hn_index, need.data(), nullptr, red);
+    if (red.overflow)
+      return;
+    c->color_ptr_reduced.swap(red.ptr);
+    pfm::raw_vector<int32_t> &order_red = red.order;
+    c->n_general_cells = (int64_t)c->color_ptr_reduced.back();
     v.row_patch = dev_upload(c, pl.regular.data(), pl.regular.size());
     c->d_color_cells_reduced = dev_upload(c, order_red.data(), order_red.size());
     c->n_rows_general = (int32_t)pl.rows_general.size();
@@ -1842,123 +2036,60 @@ extern "C"
         std::vector<int32_t> &nadj = c->h_nadj;
         clk.mark("node graph");
 
-        // Colour classes (below) only read host tables: on a general mesh they are computed by a host thread NEXT TO the
-        // uploads and the device build of the node graph (1.7 of the remaining 5.8 ms of a rebuild at 2.7e5 cells).
-        pfm::raw_vector<int32_t> order((size_t)NC);
-        std::vector<uint8_t> ring;
-        bool any_ring = false;
+        // Colour classes of the general family (greedy_colours) only read host tables: on a general mesh they are computed by a
+        // host thread NEXT TO the uploads and the device build of the node graph -- and given up as soon as the overlay plan
+        // (below, on a thread of its own) turns out non-empty: the overlay needs the classes of the few cells it leaves to
+        // the general family only (finish_patches2d / 3d), the lists over all cells are then made on first use.
+        const int32_t *hn_idx = hn_index.empty() ? nullptr : hn_index.data();
+        auto node_of = [m, nv](int64_t cell, int a) { return m->cell_nodes[cell * nv + a]; };
+        Colours full;
+        std::atomic<bool> colour_cancel{false};
         std::exception_ptr colour_err;
         auto colour_classes = [&]() {
           try
             {
-          // Colour classes of the general cell kernel: cells of one class share no node and are assembled by one
-          // launch with plain read-modify-write (device-scope FP64 atomics run at ~3e10 /s on this chip: the scatter
-          // of a 2-D Jacobian took 1.1 of 1.2 ms).  Lattice: parity of the cell's lattice position; otherwise greedy
-          // in cell order.  Cells with a hanging vertex go to the last class, which keeps the atomics.
-          pfm::raw_vector<uint8_t> col((size_t)NC);
-          int n_col = 0;
-          if (lattice_ok)
-            {
-              const int64_t NX = lattice.NX, NY = lattice.NY;
-              parallel_for(NC, [&](int64_t cb, int64_t ce) {
-                for (int64_t cell = cb; cell < ce; ++cell)
-                  {
-                    const int64_t b0 = lattice.box_of_local[m->cell_nodes[cell * nv]];
-                    const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / (NX * NY);
-                    col[cell] = (uint8_t)((i & 1) + 2 * (j & 1) + 4 * (k & 1));
-                  }
-              });
-              n_col = dim == 3 ? 8 : 4;
-            }
-          else
-            {
-              std::vector<uint64_t> used((size_t)N, 0);
-              for (int64_t cell = 0; cell < NC; ++cell)
+              if (lattice_ok)
                 {
-                  uint64_t mask = 0;
-                  bool hanging = false;
-                  for (int a = 0; a < nv; ++a)
-                    {
-                      const int32_t n = m->cell_nodes[cell * nv + a];
-                      mask |= used[n];
-                      hanging = hanging || (!hn_index.empty() && hn_index[n] >= 0);
-                    }
-                  int k = 63;
-                  if (!hanging && ~mask != 0)
-                    k = __builtin_ctzll(~mask);
-                  if (k < 62)
-                    {
-                      for (int a = 0; a < nv; ++a)
-                        used[m->cell_nodes[cell * nv + a]] |= 1ull << k;
-                      n_col = std::max(n_col, k + 1);
-                    }
-                  col[cell] = (uint8_t)std::min(k, 63);
-                }
-              for (int64_t cell = 0; cell < NC; ++cell)
-                if (col[cell] >= 62)
-                  col[cell] = (uint8_t)n_col; // hanging vertices (or more than 62 classes): the atomic class
-            }
-          // Cells of the plain classes that share a constraint-resolved node with a cell of the atomic class add
-          // atomically as well (DevView::cell_ring): every row the atomic class touches then only ever receives atomic
-          // adds, and the class -- 68 latency-bound waves, 15 % of a Jacobian at 2.7e5 cells -- runs next to the others
-          ring.assign((size_t)NC, 0);
-          any_ring = false;
-          if (!lattice_ok && !hn_index.empty())
-            {
-              std::vector<uint8_t> touched((size_t)N, 0);
-              bool any_atomic = false;
-              for (int64_t cell = 0; cell < NC; ++cell)
-                if (col[cell] == n_col)
-                  {
-                    any_atomic = true;
-                    for (int a = 0; a < nv; ++a)
+                  // (2-D boxes; a 3-D box sorts its lists on the device when asked, below)  parity of the cell's lattice position
+                  const int64_t NX = lattice.NX, NY = lattice.NY;
+                  pfm::raw_vector<uint8_t> col((size_t)NC);
+                  parallel_for(NC, [&](int64_t cb, int64_t ce) {
+                    for (int64_t cell = cb; cell < ce; ++cell)
                       {
-                        const int32_t n = m->cell_nodes[cell * nv + a];
-                        touched[n] = 1;
-                        const int32_t k = hn_index[n];
-                        if (k >= 0)
-                          for (int64_t j = m->hn_ptr[k]; j < m->hn_ptr[k + 1]; ++j)
-                            touched[m->hn_parents[j]] = 1;
+                        const int64_t b0 = lattice.box_of_local[m->cell_nodes[cell * nv]];
+                        const int64_t i = b0 % NX, j = (b0 / NX) % NY, k = b0 / (NX * NY);
+                        col[cell] = (uint8_t)((i & 1) + 2 * (j & 1) + 4 * (k & 1));
                       }
-                  }
-              if (any_atomic)
-                for (int64_t cell = 0; cell < NC; ++cell)
-                  if (col[cell] != n_col)
+                  });
+                  const int n_col = dim == 3 ? 8 : 4, nk = n_col + 1;
+                  full.ptr.assign((size_t)n_col + 2, 0);
+                  full.order.resize((size_t)std::max<int64_t>(NC, 1));
+                  const int nt = chunks_for(NC, 65536);
+                  std::vector<long long> hist((size_t)nt * nk, 0);
+                  parallel_chunks(nt, [&](int t) {
+                    long long *hh = hist.data() + (size_t)t * nk;
+                    for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+                      ++hh[col[cell]];
+                  });
+                  for (int k = 0; k < nk; ++k)
                     {
-                      bool r = false;
-                      for (int a = 0; a < nv; ++a)
-                        r = r || touched[m->cell_nodes[cell * nv + a]] != 0;
-                      ring[cell] = r ? 1 : 0;
-                      any_ring = any_ring || r;
+                      long long at = full.ptr[k];
+                      for (int t = 0; t < nt; ++t)
+                        {
+                          const long long cnt = hist[(size_t)t * nk + k];
+                          hist[(size_t)t * nk + k] = at;
+                          at += cnt;
+                        }
+                      full.ptr[(size_t)k + 1] = at;
                     }
-            }
-          // cells in class order, ascending cell number within a class (a counting sort, chunked over the host threads)
-          c->color_ptr.assign((size_t)n_col + 2, 0);
-          {
-            const int nt = chunks_for(NC, 65536), nk = n_col + 1;
-            std::vector<long long> hist((size_t)nt * nk, 0);
-            parallel_chunks(nt, [&](int t) {
-              long long *hh = hist.data() + (size_t)t * nk;
-              for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
-                ++hh[col[cell]];
-            });
-            for (int k = 0; k < nk; ++k)
-              {
-                long long at = c->color_ptr[k];
-                for (int t = 0; t < nt; ++t)
-                  {
-                    const long long cnt = hist[(size_t)t * nk + k];
-                    hist[(size_t)t * nk + k] = at;
-                    at += cnt;
-                  }
-                c->color_ptr[k + 1] = at;
-              }
-            parallel_chunks(nt, [&](int t) {
-              long long *fill = hist.data() + (size_t)t * nk;
-              for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
-                order[fill[col[cell]]++] = (int32_t)cell;
-            });
-          }
+                  parallel_chunks(nt, [&](int t) {
+                    long long *fill = hist.data() + (size_t)t * nk;
+                    for (int64_t cell = NC * t / nt; cell < NC * (t + 1) / nt; ++cell)
+                      full.order[(size_t)fill[col[cell]]++] = (int32_t)cell;
+                  });
+                }
+              else
+                greedy_colours(NC, nv, N, node_of, hn_idx, nullptr, &colour_cancel, full);
             }
           catch (...)
             {
@@ -2081,6 +2212,22 @@ extern "C"
           v.coords = xs;
         }
         clk.mark("conn + coords upload");
+        if (patch_thread.joinable())
+          patch_thread.join();
+        else
+          plan_patches();
+        if (patch_err)
+          std::rethrow_exception(patch_err);
+        clk.mark("overlay plan (wait)");
+        std::vector<uint8_t> ring;
+        const bool any_ring = !lattice_ok && ring_cells(NC, nv, N, node_of, hn_idx, m->hn_ptr, m->hn_parents, ring);
+        v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
+        v.color_cells = nullptr;
+        clk.mark("ring cells");
+        finish_patches2d(c, m, patch_plan, hn_idx);
+        finish_patches3d(c, m, patch_plan3, hn_idx);
+        const bool overlay = c->n_patch_blocks > 0 || !c->levels3.empty();
+        clk.mark("cartesian overlay");
         if (lattice_ok && dim == 3)
           {
             // uniform 3-D box: the cartesian family runs it; the lists of the general family (eight parity classes, their sizes
@@ -2093,8 +2240,13 @@ extern "C"
               }
             c->color_ptr[9] = c->color_ptr[8];
             c->colours_lazy = true;
-            v.color_cells = nullptr;
-            v.cell_ring = nullptr;
+          }
+        else if (overlay)
+          {
+            colour_cancel = true; // (the thread, if it runs, stops at its next look)
+            if (colour_thread.joinable())
+              colour_thread.join();
+            c->full_colours_lazy = true;
           }
         else
           {
@@ -2104,19 +2256,15 @@ extern "C"
               colour_classes();
             if (colour_err)
               std::rethrow_exception(colour_err);
-            v.color_cells = dev_upload(c, order.data(), order.size());
-            v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
+            v.color_cells = dev_upload(c, full.order.data(), full.order.size());
+            c->color_ptr.swap(full.ptr);
+            if (full.overflow)
+              {
+                ring.assign((size_t)NC, 1); // (never seen: a node of more than 62 cells) every cell adds atomically
+                v.cell_ring = dev_upload(c, ring.data(), ring.size());
+              }
           }
         clk.mark("colour classes");
-        if (patch_thread.joinable())
-          patch_thread.join();
-        else
-          plan_patches();
-        if (patch_err)
-          std::rethrow_exception(patch_err);
-        finish_patches2d(c, m, patch_plan, order);
-        finish_patches3d(c, m, patch_plan3, order);
-        clk.mark("cartesian overlay");
         v.cell_lambda = v.cell_mu = nullptr;
         if (m->cell_lambda && m->cell_mu)
           {
@@ -3116,6 +3264,21 @@ extern "C"
         const int rcp = overlay3 ? ensure_overlay3_ready(c) : ensure_patch_ready(c);
         if (rcp)
           return rcp;
+      }
+    else if (!cart && c->full_colours_lazy)
+      {
+        try
+          {
+            ensure_full_colours(c); // the general family over all cells of a context that has only run with its overlay so far
+          }
+        catch (const HipFail &f)
+          {
+            return hipfail(c, f.e, f.what);
+          }
+        catch (const std::bad_alloc &)
+          {
+            return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+          }
       }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing && phase == 2)
