@@ -2223,6 +2223,39 @@ extern "C"
         const bool any_ring = !lattice_ok && ring_cells(NC, nv, N, node_of, hn_idx, m->hn_ptr, m->hn_parents, ring);
         v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
         v.color_cells = nullptr;
+        v.hcell = nullptr;
+        v.cslot_h = nullptr;
+        v.cres = nullptr;
+        if (hn_idx && !lattice_ok)
+          {
+            // slot table of the cells at hanging vertices (DevView::cslot_h), filled next to cslot by launch_build_cslot
+            const int MPH = dim == 3 ? 4 : 2;
+            bool fits = true;
+            for (int32_t k = 0; k < m->n_hanging; ++k)
+              fits = fits && m->hn_ptr[k + 1] - m->hn_ptr[k] <= MPH;
+            if (fits)
+              {
+                const std::vector<int32_t> hcells = parallel_select(0, NC, [&](int64_t cell) {
+                  bool h = false;
+                  for (int a = 0; a < nv; ++a)
+                    h = h || hn_idx[m->cell_nodes[cell * nv + a]] >= 0;
+                  return h;
+                });
+                if (!hcells.empty())
+                  {
+                    pfm::raw_vector<int32_t> hcell((size_t)NC);
+                    parallel_for(NC, [&](int64_t b, int64_t e) { std::fill(hcell.begin() + b, hcell.begin() + e, -1); });
+                    parallel_for((int64_t)hcells.size(), [&](int64_t b, int64_t e) {
+                      for (int64_t i = b; i < e; ++i)
+                        hcell[(size_t)hcells[(size_t)i]] = (int32_t)i;
+                    });
+                    v.hcell = dev_upload(c, hcell.data(), hcell.size());
+                    v.cslot_h = dev_alloc<uint8_t>(c, hcells.size() * (size_t)(nv * MPH * nv * MPH));
+                    if (dim == 3)
+                      v.cres = dev_alloc<uint8_t>(c, hcells.size() * (size_t)pfm::PFM_CRES_BYTES);
+                  }
+              }
+          }
         clk.mark("ring cells");
         finish_patches2d(c, m, patch_plan, hn_idx);
         finish_patches3d(c, m, patch_plan3, hn_idx);
@@ -2348,6 +2381,16 @@ extern "C"
                     (void *)c->cv.patch_count})
       if (q)
         (void)hipFree(q);
+    if (c->atomic_stream)
+      (void)hipStreamDestroy(c->atomic_stream);
+    if (c->ev_atomic)
+      (void)hipEventDestroy(c->ev_atomic);
+    for (hipStream_t st : c->ov_streams)
+      (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : c->ov_events)
+      (void)hipEventDestroy(ev);
+    if (c->ov_fork)
+      (void)hipEventDestroy(c->ov_fork);
     if (c->side_stream)
       {
         (void)hipStreamDestroy(c->side_stream);
@@ -3412,27 +3455,84 @@ extern "C"
         rc = PFM_OK;
         if (overlay3)
           {
-            // the row-owner kernels of the cartesian family on every level lattice, one after the other on the stream (next to
-            // each other on streams of their own they gained nothing -- 8.3 against 8.4 ms at 1.1e6 cells: the general
-            // family's atomic class on the side stream is the long pole of an overlay assembly)
+            // the row-owner kernels of the cartesian family on every level lattice: each level on a stream of its own, forked
+            // off the context's stream (a level lattice of 6e5 nodes fills a third of the chip's dispatch slots; the levels
+            // write disjoint rows).  PFM_OVERLAY3_SEQUENTIAL=1: one after the other on the stream (A/B runs).
+            static const bool levels_sequential = getenv("PFM_OVERLAY3_CONCURRENT") == nullptr;
+            const size_t nl = c->levels3.size();
             for (auto &lv : c->levels3)
+              if (rc == PFM_OK && !residual_only && lv.scal_dirty)
+                {
+                  rc = upload_mat_scal(c->prm, lv.cv, lv.d_scal, c->stream);
+                  lv.scal_dirty = rc != PFM_OK;
+                }
+            const bool par = nl > 1 && !levels_sequential && rc == PFM_OK;
+            if (par)
               {
-                if (rc == PFM_OK && !residual_only && lv.scal_dirty)
+                while (c->ov_streams.size() < nl)
                   {
-                    rc = upload_mat_scal(c->prm, lv.cv, lv.d_scal, c->stream);
-                    lv.scal_dirty = rc != PFM_OK;
+                    hipStream_t st = nullptr;
+                    hipEvent_t ev = nullptr;
+                    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                      return fail(c, PFM_ERR_HIP, "overlay level stream");
+                    c->ov_streams.push_back(st);
+                    c->ov_events.push_back(ev);
                   }
-                if (rc == PFM_OK)
-                  rc = launch_assemble_cart(c->v, lv.cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->stream, lv.d_scal, 0);
+                if (!c->ov_fork && hipEventCreateWithFlags(&c->ov_fork, hipEventDisableTiming) != hipSuccess)
+                  return fail(c, PFM_ERR_HIP, "overlay level event");
+                e = hipEventRecord(c->ov_fork, c->stream);
+                for (size_t i = 0; i < nl && e == hipSuccess; ++i)
+                  e = hipStreamWaitEvent(c->ov_streams[i], c->ov_fork, 0);
+                if (e != hipSuccess)
+                  return hipfail(c, e, "fork (overlay levels)");
+              }
+            for (size_t i = 0; i < nl && rc == PFM_OK; ++i)
+              {
+                hipStream_t st = par ? c->ov_streams[i] : c->stream;
+                rc = launch_assemble_cart(c->v, c->levels3[i].cv, c->prm, residual_only, d_values, d_res_pde, d_res_tot, st, st, c->levels3[i].d_scal, 0);
+              }
+            if (par)
+              {
+                for (size_t i = 0; i < nl && e == hipSuccess; ++i)
+                  {
+                    e = hipEventRecord(c->ov_events[i], c->ov_streams[i]);
+                    if (e == hipSuccess)
+                      e = hipStreamWaitEvent(c->stream, c->ov_events[i], 0);
+                  }
+                if (e != hipSuccess)
+                  return hipfail(c, e, "join (overlay levels)");
               }
           }
         else
           rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks, c->stream);
         pfm::DevView vg = c->v;
         vg.color_cells = c->d_color_cells_reduced;
+        // 3-D overlay Jacobian: the class of the cells at hanging vertices (FP64 atomics, 4.7 of the general family's 6 ms at
+        // 1.1e6 cells) on a third stream next to the plain classes (DevView::cell_ring makes that safe)
+        hipStream_t s_atomic = nullptr;
+        if (overlay3 && fork_general && !residual_only && c->v.cell_ring && c->n_general_cells > 0)
+          {
+            int prio_lo = 0, prio_hi = 0; // (numerically lower = higher priority) the long pole gets its workgroups dispatched first
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (!c->atomic_stream && (hipStreamCreateWithPriority(&c->atomic_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+                                      hipEventCreateWithFlags(&c->ev_atomic, hipEventDisableTiming) != hipSuccess))
+              return fail(c, PFM_ERR_HIP, "atomic-class stream");
+            e = hipStreamWaitEvent(c->atomic_stream, c->ev_fork, 0);
+            if (e != hipSuccess)
+              return hipfail(c, e, "fork (atomic class)");
+            s_atomic = c->atomic_stream;
+          }
         if (rc == PFM_OK && c->n_general_cells > 0)
           rc = launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, fork_general ? c->side_stream : c->stream,
-                                       c->color_ptr_reduced, nullptr);
+                                       c->color_ptr_reduced, s_atomic);
+        if (s_atomic)
+          {
+            e = hipEventRecord(c->ev_atomic, s_atomic);
+            if (e == hipSuccess)
+              e = hipStreamWaitEvent(c->stream, c->ev_atomic, 0);
+            if (e != hipSuccess)
+              return hipfail(c, e, "join (atomic class)");
+          }
       }
     else
       {

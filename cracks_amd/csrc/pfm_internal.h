@@ -15,6 +15,7 @@
 namespace pfm
 {
   // Device-side view of the static mesh tables and the node state (SoA, HBM resident).
+  constexpr int PFM_CRES_SLOT = 64, PFM_CRES_R = 320, PFM_CRES_BYTES = 336;
   struct DevView
   {
     int dim, layout, n_nodes, n_owned;
@@ -31,6 +32,16 @@ namespace pfm
     const long long *hn_ptr;
     const int32_t *hn_parents;
     const double *hn_weights;
+    // cells with a hanging vertex: hcell[cell] = their running number (-1: none hangs), cslot_h[number][a][r][b][s] = slot of
+    // parent s of vertex b in the row of parent r of vertex a (r, s < 4 in 3-D, < 2 in 2-D; a vertex that does not hang is
+    // its own parent 0; 0xff: no such parent, row not owned, or not in the row).  nullptr: no hanging nodes, or one with more
+    // parents than that (the cell kernel then searches the row, find_slot)
+    const int32_t *hcell;
+    const uint8_t *cslot_h;
+    // 3-D: per such cell a record of PFM_CRES_BYTES: int32 node[16] (its distinct constraint-resolved nodes, -1 unused),
+    // uint8 slot[16][16] at PFM_CRES_SLOT (slot of node j in the row of node i), uint8 R at PFM_CRES_R (0xff: more than 16).
+    // The cell kernel forms C^T K C over these nodes before it adds (k_assemble_general, KRED).  nullptr: no such cells.
+    const uint8_t *cres;
     const uint8_t *node_flags; // [n_nodes] bit c: dof (node,c) has a homogeneous constraint line
     const uint8_t *cell_ring;  // [n_cells] or nullptr: 1 = a cell of a plain colour class that shares a (constraint-resolved) node
                                // with a cell of the atomic class: it adds atomically too, so that the atomic class may run NEXT
@@ -230,6 +241,11 @@ struct pfm_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  std::vector<hipStream_t> ov_streams; // 3-D overlay: one stream per level lattice (forked off `stream` in an assembly)
+  std::vector<hipEvent_t> ov_events;
+  hipEvent_t ov_fork = nullptr;
+  hipStream_t atomic_stream = nullptr; // 3-D overlay: the general family's atomic class next to its plain classes
+  hipEvent_t ev_atomic = nullptr;
   hipStream_t side_stream = nullptr;            // residual + clearing of the (u,phi) block, concurrent with the Jacobian
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   pfm::DevView v{};

@@ -220,7 +220,13 @@ namespace pfm
       __shared__ double s_u[dim][nv][CPB];
       __shared__ double s_p[3][nv][CPB]; // phi, phi_old, phi_oldold
       constexpr int QST = 50; // doubles per (q-point slot, cell) of the 3-D exchange buffer: 49 used, stride free of bank conflicts for 16-byte reads
-      __shared__ __attribute__((aligned(16))) double s_q[(dim == 3 && !SPLIT) ? NSLOT * CPB * QST : 2];
+      // KRED (the class of the 3-D cells at hanging vertices): the scatter first forms C^T K C over the cell's constraint-resolved
+      // nodes in LDS (below); the cell's part of the exchange buffer is the head of a region that holds its 8 x 8 x 13 matrix
+      constexpr bool KRED = Q3 && ATOMIC;
+      constexpr int KCMP = 13;                      // Kuu 3 x 3, Kpu 3, Kpp
+      constexpr int KCELL = KRED ? nv * nv * KCMP : NSLOT * QST; // doubles per cell of s_q
+      __shared__ __attribute__((aligned(16))) double s_q[(dim == 3 && !SPLIT) ? (KRED ? CPB * KCELL : NSLOT * CPB * QST) : 2];
+      auto sq_at = [&](int slot, int cell_in_wg) { return KRED ? cell_in_wg * KCELL + slot * QST : (slot * CPB + cell_in_wg) * QST; };
 
       const int tid = threadIdx.x;
       const int a = tid % nv, part = Q3 ? (tid / nv) % NPART : 0, cl0 = tid / LPC;
@@ -663,7 +669,7 @@ namespace pfm
                   inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id;
                   inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
                   const double JxW = det * wq;
-                  double *const o = s_q + (slot * CPB + cl) * QST;
+                  double *const o = s_q + sq_at(slot, cl);
                   const bool writer = Q3 ? part == 0 : a < 4;
                   double gu[3][3], gpf[3] = {0.0, 0.0, 0.0}, pf = 0.0, pfo = 0.0, pfoo = 0.0;
 #pragma unroll
@@ -754,7 +760,7 @@ namespace pfm
                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
               // ---------------- phase B: q-point q, rows of this lane's vertex (cracks.cc:2308-2432)
-              const double *const i = s_q + ((q & (NSLOT - 1)) * CPB + cl) * QST;
+              const double *const i = s_q + sq_at(q & (NSLOT - 1), cl);
               const double2 ga01 = *reinterpret_cast<const double2 *>(i + 4 * a), ga2n = *reinterpret_cast<const double2 *>(i + 4 * a + 2);
               const double gNa[3] = {ga01.x, ga01.y, ga2n.x}, Na = ga2n.y;
               const double2 s01 = *reinterpret_cast<const double2 *>(i + O_SP), s23 = *reinterpret_cast<const double2 *>(i + O_SP + 2),
@@ -1426,6 +1432,9 @@ namespace pfm
           return;
         }
       const uint8_t *cs = v.cslot + (long long)cell * nv * nv;
+      constexpr int MPH = dim == 3 ? 4 : 2;
+      const int hc = v.cslot_h ? v.hcell[cell] : -1;
+      const uint8_t *csh = hc >= 0 ? v.cslot_h + (long long)hc * (nv * MPH * nv * MPH) : nullptr;
       const int kA = v.hn_index ? v.hn_index[A] : -1;
       const long long rb = kA < 0 ? 0 : v.hn_ptr[kA];
       const long long re = kA < 0 ? 1 : v.hn_ptr[kA + 1];
@@ -1458,6 +1467,113 @@ namespace pfm
 #pragma unroll
           for (int c = 0; c < nc; ++c)
             diag[c] = 0.0;
+          // The class of the 3-D cells at hanging vertices was bound by the rate of the FP64 atomics (a hex at a refined face
+          // sends (5 + 2 + 2 + 4)^2 = 169 node pairs x 13 values through its parents, 4.7 ms for 4.2e4 hexes): the pairs fall on
+          // only 8 x 8 DISTINCT constraint-resolved nodes.  So the lanes of the hex first form K' = C^T K C in LDS -- the 8 x 8
+          // blocks into the cell's region of s_q, lane i < R collects the vertices that feed resolved node i, lane p takes the
+          // node pairs p, p + 32, ... -- and add each value of K' once (DevView::cres: resolved nodes and their slots).
+          bool reduced = false;
+          if constexpr (KRED)
+            {
+              const uint8_t *rec = (v.cres && hc >= 0) ? v.cres + (long long)hc * PFM_CRES_BYTES : nullptr;
+              const int R = rec ? (int)rec[PFM_CRES_R] : 0xff;
+              if (R <= 16)
+                {
+                  reduced = true;
+                  __shared__ uint8_t s_icnt[CPB][16], s_ia[CPB][16][8];
+                  __shared__ double s_iw[CPB][16][8];
+                  const int32_t *rnode = reinterpret_cast<const int32_t *>(rec);
+                  double *const Kc = s_q + cl * KCELL; // (the q-loop of this hex is over: its lanes sit in one wave)
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                  for (int bb = 0; bb < NBL; ++bb)
+                    {
+                      double *o = Kc + (a * nv + B0 + bb) * KCMP;
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+                          o[3 * c + d] = Kuu[bb][c][d];
+#pragma unroll
+                      for (int d = 0; d < 3; ++d)
+                        o[9 + d] = Kpu[bb][d];
+                      o[12] = Kpp[bb];
+                    }
+                  const int l32 = a + nv * part; // lane of the hex
+                  if (l32 < R)
+                    {
+                      const int mine = rnode[l32];
+                      int cnt = 0;
+                      for (int a2 = 0; a2 < nv; ++a2)
+                        {
+                          const int A2 = v.conn[(long long)a2 * v.n_cells + cell];
+                          const int k2 = v.hn_index[A2];
+                          if (k2 < 0)
+                            {
+                              if (A2 == mine)
+                                {
+                                  s_ia[cl][l32][cnt] = (uint8_t)a2;
+                                  s_iw[cl][l32][cnt++] = 1.0;
+                                }
+                            }
+                          else
+                            for (long long r = v.hn_ptr[k2]; r < v.hn_ptr[k2 + 1]; ++r)
+                              if (v.hn_parents[r] == mine && cnt < 8)
+                                {
+                                  s_ia[cl][l32][cnt] = (uint8_t)a2;
+                                  s_iw[cl][l32][cnt++] = v.hn_weights[r];
+                                }
+                        }
+                      s_icnt[cl][l32] = (uint8_t)cnt;
+                    }
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                  for (int pq = l32; pq < R * R; pq += 32)
+                    {
+                      const int i = pq / R, j = pq - i * R;
+                      const int P = rnode[i], Q = rnode[j];
+                      const int slot = (int)rec[PFM_CRES_SLOT + 16 * i + j];
+                      if (P >= v.n_owned || (v.row_patch && v.row_patch[P]) || slot == 0xff)
+                        continue;
+                      double acc[KCMP];
+#pragma unroll
+                      for (int k = 0; k < KCMP; ++k)
+                        acc[k] = 0.0;
+                      const int ni = s_icnt[cl][i], nj = s_icnt[cl][j];
+                      for (int x = 0; x < ni; ++x)
+                        for (int y = 0; y < nj; ++y)
+                          {
+                            const double w = s_iw[cl][i][x] * s_iw[cl][j][y];
+                            const double *k = Kc + ((int)s_ia[cl][i][x] * nv + (int)s_ia[cl][j][y]) * KCMP;
+#pragma unroll
+                            for (int t = 0; t < KCMP; ++t)
+                              acc[t] = fma(w, k[t], acc[t]);
+                          }
+                      const unsigned fP = v.node_flags[P], fQ = v.node_flags[Q];
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        {
+                          if ((fP >> c) & 1u)
+                            continue;
+#pragma unroll
+                          for (int d = 0; d < 3; ++d)
+                            if (!((fQ >> d) & 1u))
+                              add_to<true>(val_ptr<dim>(v, vals, P, c, slot, d), acc[3 * c + d]);
+                        }
+                      if (!((fP >> 3) & 1u))
+                        {
+#pragma unroll
+                          for (int d = 0; d < 3; ++d)
+                            if (!((fQ >> d) & 1u))
+                              add_to<true>(val_ptr<dim>(v, vals, P, 3, slot, d), acc[9 + d]);
+                          if (!((fQ >> 3) & 1u))
+                            add_to<true>(val_ptr<dim>(v, vals, P, 3, slot, 3), acc[12]);
+                        }
+                    }
+                }
+            }
           // matrix rows of vertex a
 #pragma unroll
           for (int bb = 0; bb < NBL; ++bb)
@@ -1471,6 +1587,8 @@ namespace pfm
                     diag[c] = fabs(Kuu[bb][c][c]);
                   diag[dim] = fabs(Kpp[bb]);
                 }
+              if (reduced)
+                continue;
               const int kB = v.hn_index ? v.hn_index[B] : -1;
               const long long cb = kB < 0 ? 0 : v.hn_ptr[kB];
               const long long ce = kB < 0 ? 1 : v.hn_ptr[kB + 1];
@@ -1486,7 +1604,11 @@ namespace pfm
                       const int Q = kB < 0 ? B : v.hn_parents[s];
                       const double w = wP * (kB < 0 ? 1.0 : v.hn_weights[s]);
                       const unsigned fQ = v.node_flags[Q];
-                      const int slot = (kA < 0 && kB < 0) ? (int)cs[a * nv + b] : find_slot(v, P, Q);
+                      // a row search per parent pair (find_slot: a chain of dependent loads) made the class of the cells at
+                      // hanging vertices take 5.5 ms for 4.2e4 hexes; their slots come from a table now (DevView::cslot_h)
+                      const int slot = (kA < 0 && kB < 0) ? (int)cs[a * nv + b]
+                                       : csh                ? (int)csh[((a * MPH + (int)(r - rb)) * nv + b) * MPH + (int)(s - cb)]
+                                                            : find_slot(v, P, Q);
 #pragma unroll
                       for (int c = 0; c < dim; ++c)
                         {
@@ -1654,6 +1776,108 @@ namespace pfm
         }
     }
 
+    // the same for the cells at hanging vertices, per pair of parents (DevView::cslot_h).  thread <-> (cell, a, r)
+    template <int dim>
+    __global__ void k_build_cslot_h(DevView v, uint8_t *__restrict__ cslot_h)
+    {
+      constexpr int nv = 1 << dim, MPH = dim == 3 ? 4 : 2;
+      const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      if (idx >= v.n_cells * nv * MPH)
+        return;
+      const long long cell = idx / (nv * MPH);
+      const int hc = v.hcell[cell];
+      if (hc < 0)
+        return;
+      const int a = (int)((idx / MPH) % nv), r = (int)(idx % MPH);
+      const int A = v.conn[(long long)a * v.n_cells + cell];
+      const int kA = v.hn_index[A];
+      int P = -1;
+      if (kA < 0)
+        P = r == 0 ? A : -1;
+      else if (v.hn_ptr[kA] + r < v.hn_ptr[kA + 1])
+        P = v.hn_parents[v.hn_ptr[kA] + r];
+      uint8_t *out = cslot_h + ((long long)hc * nv * MPH + a * MPH + r) * (nv * MPH);
+      for (int b = 0; b < nv; ++b)
+        {
+          const int B = v.conn[(long long)b * v.n_cells + cell];
+          const int kB = v.hn_index[B];
+          for (int s = 0; s < MPH; ++s)
+            {
+              int Q = -1;
+              if (kB < 0)
+                Q = s == 0 ? B : -1;
+              else if (v.hn_ptr[kB] + s < v.hn_ptr[kB + 1])
+                Q = v.hn_parents[v.hn_ptr[kB] + s];
+              uint8_t slot = 0xff;
+              if (P >= 0 && P < v.n_owned && Q >= 0)
+                {
+                  const long long lo = v.nadj_ptr[P], hi = v.nadj_ptr[P + 1];
+                  long long k = lo;
+                  while (k < hi && v.nadj[k] != Q)
+                    ++k;
+                  if (k < hi)
+                    slot = (uint8_t)(k - lo);
+                }
+              out[b * MPH + s] = slot;
+            }
+        }
+    }
+
+    // DevView::cres, one record per 3-D cell at a hanging vertex: the distinct constraint-resolved nodes of the cell (a vertex
+    // that does not hang is its own, a hanging one brings its parents), their number R (0xff: more than 16), and slot[i][j] =
+    // position of node j in the row of node i (0xff: row not owned / not in the row).  16 threads per cell: thread i fills row i.
+    __global__ void k_build_cres(DevView v, uint8_t *__restrict__ cres)
+    {
+      const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+      const long long cell = idx >> 4;
+      if (cell >= v.n_cells)
+        return;
+      const int hc = v.hcell[cell], i = (int)(idx & 15);
+      if (hc < 0)
+        return;
+      int node[16], R = 0;
+      bool over = false;
+      for (int a = 0; a < 8; ++a)
+        {
+          const int A = v.conn[(long long)a * v.n_cells + cell];
+          const int kA = v.hn_index[A];
+          const long long rb = kA < 0 ? 0 : v.hn_ptr[kA], re = kA < 0 ? 1 : v.hn_ptr[kA + 1];
+          for (long long r = rb; r < re; ++r)
+            {
+              const int P = kA < 0 ? A : v.hn_parents[r];
+              bool known = false;
+              for (int t = 0; t < R; ++t)
+                known = known || node[t] == P;
+              if (known)
+                continue;
+              if (R == 16)
+                over = true;
+              else
+                node[R++] = P;
+            }
+        }
+      uint8_t *rec = cres + (long long)hc * PFM_CRES_BYTES;
+      if (i == 0)
+        {
+          for (int t = 0; t < 16; ++t)
+            reinterpret_cast<int32_t *>(rec)[t] = t < R ? node[t] : -1;
+          rec[PFM_CRES_R] = over ? (uint8_t)0xff : (uint8_t)R;
+        }
+      uint8_t *out = rec + PFM_CRES_SLOT + 16 * i;
+      for (int j = 0; j < 16; ++j)
+        out[j] = 0xff;
+      if (i >= R || over || node[i] >= v.n_owned)
+        return;
+      const long long lo = v.nadj_ptr[node[i]], hi = v.nadj_ptr[node[i] + 1];
+      for (long long k = lo; k < hi; ++k)
+        {
+          const int q = v.nadj[k];
+          for (int j = 0; j < R; ++j)
+            if (node[j] == q)
+              out[j] = (uint8_t)(k - lo);
+        }
+    }
+
     // raises PFM_ERR_NONFINITE in the context's status word if any of the n values is NaN or +-Inf
     __global__ void k_check_finite(const double *__restrict__ x, long long n, int *__restrict__ status)
     {
@@ -1775,6 +1999,17 @@ namespace pfm
       hipLaunchKernelGGL(k_build_cslot<2>, dim3(nb), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot));
     else
       hipLaunchKernelGGL(k_build_cslot<3>, dim3(nb), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot));
+    if (v.cslot_h)
+      {
+        const long long nh = n * (v.dim == 3 ? 4 : 2);
+        const unsigned nbh = (unsigned)((nh + bs - 1) / bs);
+        if (v.dim == 2)
+          hipLaunchKernelGGL(k_build_cslot_h<2>, dim3(nbh), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot_h));
+        else
+          hipLaunchKernelGGL(k_build_cslot_h<3>, dim3(nbh), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cslot_h));
+      }
+    if (v.cres && v.dim == 3)
+      hipLaunchKernelGGL(k_build_cres, dim3((unsigned)((v.n_cells * 16 + bs - 1) / bs)), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cres));
     return check_launch();
   }
 
