@@ -340,19 +340,31 @@ namespace pfm
       const int i = (int)(p % NX), j = (int)((p / NX) % NY), k = (int)(p / ((long long)NX * NY));
       const long long base = nadj_ptr[r];
       const int deg = (int)(nadj_ptr[r + 1] - base);
-      bool ok = deg == 27 && i > 0 && i < NX - 1 && j > 0 && j < NY - 1 && k > 0 && k < NZ - 1;
+      // the offsets that stay inside the level lattice (a node on one of its faces has fewer than 27: the face of a level that
+      // reaches the boundary of the domain); every one of them must be a node of the level and sit in the row
+      unsigned mask = 0;
+      int rank = 0;
+      bool ok = true;
       for (int o = 0; o < 27 && ok; ++o)
         {
-          const int q = node_at[(i + o % 3 - 1) + (long long)NX * ((j + (o / 3) % 3 - 1) + (long long)NY * (k + o / 9 - 1))];
+          const int ii = i + o % 3 - 1, jj = j + (o / 3) % 3 - 1, kk = k + o / 9 - 1;
+          if (ii < 0 || ii >= NX || jj < 0 || jj >= NY || kk < 0 || kk >= NZ)
+            continue;
+          const int q = node_at[ii + (long long)NX * (jj + (long long)NY * kk)];
           int slot = -1;
-          for (int t = 0; t < 27; ++t)
+          for (int t = 0; t < deg; ++t)
             if (nadj[base + t] == q)
               slot = t;
-          ok = q >= 0 && slot >= 0;
+          ok = q >= 0 && slot >= 0 && rank < deg;
           if (ok)
-            row_perm[base + o] = (uint8_t)slot;
+            {
+              row_perm[base + rank] = (uint8_t)slot;
+              mask |= 1u << o;
+              ++rank;
+            }
         }
-      nbr_mask[r] = ok ? 0x87ffffffu : 0u;
+      ok = ok && rank == deg;
+      nbr_mask[r] = ok ? (mask | 0x80000000u) : 0u;
       if (!ok)
         atomicAdd(bad, 1);
     }

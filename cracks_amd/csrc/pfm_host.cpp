@@ -30,6 +30,10 @@
 #include <condition_variable>
 #include <functional>
 #include <pthread.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <csignal>
+#include <unistd.h>
 #include <cstdlib>
 #include <chrono>
 
@@ -118,9 +122,8 @@ namespace
             return false;
         }
     }
-    void worker(int id)
+    void worker(int id, uint64_t seen) // seen: the generation at the worker's creation (it answers the ones after it)
     {
-      uint64_t seen = 0;
       for (;;)
         {
           if (!spin_until([&] { return stop.load(std::memory_order_acquire) || gen.load(std::memory_order_acquire) != seen; }))
@@ -151,7 +154,8 @@ namespace
       while ((int)th.size() + 1 < nt)
         {
           const int id = (int)th.size() + 1;
-          th.emplace_back([this, id] { worker(id); });
+          const uint64_t born = gen.load(std::memory_order_acquire);
+          th.emplace_back([this, id, born] { worker(id, born); });
         }
       job = &f;
       want = nt;
@@ -272,48 +276,55 @@ namespace
     H2dBatch() { ++g_h2d_batch; }
     ~H2dBatch() { --g_h2d_batch; }
   };
-  hipError_t h2d(void *d, const void *h, size_t bytes)
+  struct Stage // two pinned buffers per device: the events belong to the device that was current when they were made
   {
-    constexpr size_t CHUNK = 32u << 20;
-    if (bytes < (256u << 10))
-      return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
-    static std::mutex stage_mx; // one upload at a time goes through the staging buffers (pfm_ctx_create uploads on a second thread)
-    std::lock_guard<std::mutex> stage_lock(stage_mx);
-    static struct Stage
+    static constexpr size_t CHUNK = 32u << 20;
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
+    int next = 0;
+    bool ok = false, tried = false;
+    ~Stage()
     {
-      void *buf[2] = {nullptr, nullptr};
-      hipEvent_t ev[2] = {nullptr, nullptr};
-      bool pending[2] = {false, false};
-      int next = 0;
-      bool ok = false, tried = false;
-      ~Stage()
-      {
-        for (int i = 0; i < 2; ++i)
-          {
-            if (pending[i])
-              (void)hipEventSynchronize(ev[i]);
-            if (buf[i])
-              (void)hipHostFree(buf[i]);
-            if (ev[i])
-              (void)hipEventDestroy(ev[i]);
-          }
-      }
-    } stages[16]; // one per device: the events belong to the device that was current when they were made
+      for (int i = 0; i < 2; ++i)
+        {
+          if (pending[i])
+            (void)hipEventSynchronize(ev[i]);
+          if (buf[i])
+            (void)hipHostFree(buf[i]);
+          if (ev[i])
+            (void)hipEventDestroy(ev[i]);
+        }
+    }
+  };
+  std::mutex g_stage_mx; // one transfer at a time goes through the staging buffers (pfm_ctx_create uploads on a second thread)
+  Stage g_stages[16];
+  Stage *stage_of_current_device() // call with g_stage_mx held; nullptr: no pinned memory to be had
+  {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    Stage &st = stages[dev & 15];
+    Stage &st = g_stages[dev & 15];
     if (!st.tried)
       {
         st.tried = true;
-        st.ok = hipHostMalloc(&st.buf[0], CHUNK, hipHostMallocPortable) == hipSuccess &&
-                hipHostMalloc(&st.buf[1], CHUNK, hipHostMallocPortable) == hipSuccess &&
+        st.ok = hipHostMalloc(&st.buf[0], Stage::CHUNK, hipHostMallocPortable) == hipSuccess &&
+                hipHostMalloc(&st.buf[1], Stage::CHUNK, hipHostMallocPortable) == hipSuccess &&
                 hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming) == hipSuccess;
       }
-    if (!st.ok)
+    return st.ok ? &st : nullptr;
+  }
+  hipError_t h2d(void *d, const void *h, size_t bytes)
+  {
+    if (bytes < (256u << 10))
       return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+    std::lock_guard<std::mutex> stage_lock(g_stage_mx);
+    Stage *stp = stage_of_current_device();
+    if (!stp)
+      return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+    Stage &st = *stp;
     // pieces: a table of a few MB in two halves (the second is copied to the staging buffer while the first is on the bus)
-    const size_t piece = bytes <= (1u << 20) ? bytes : std::min(CHUNK, ((bytes + 1) / 2 + 4095) & ~(size_t)4095);
+    const size_t piece = bytes <= (1u << 20) ? bytes : std::min(Stage::CHUNK, ((bytes + 1) / 2 + 4095) & ~(size_t)4095);
     for (size_t off = 0; off < bytes; off += piece)
       {
         const int k = st.next;
@@ -337,6 +348,58 @@ namespace
         st.pending[k] = true;
       }
     return g_h2d_batch > 0 ? hipSuccess : hipStreamSynchronize(nullptr);
+  }
+
+  // Device -> host copy into pageable memory of the caller through the same buffers, ordered behind the work on `s`,
+  // complete on return (results the host reads right after a call: residual vectors, small matrices).
+  hipError_t d2h_staged(void *h, const void *d, size_t bytes, hipStream_t s)
+  {
+    std::lock_guard<std::mutex> stage_lock(g_stage_mx);
+    Stage *stp = stage_of_current_device();
+    if (!stp)
+      {
+        const hipError_t e = hipStreamSynchronize(s);
+        return e != hipSuccess ? e : hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+      }
+    Stage &st = *stp;
+    for (int k = 0; k < 2; ++k)
+      if (st.pending[k])
+        {
+          st.pending[k] = false;
+          const hipError_t e = hipEventSynchronize(st.ev[k]);
+          if (e != hipSuccess)
+            return e;
+        }
+    const size_t piece = Stage::CHUNK;
+    size_t prev_off = 0, prev_nb = 0;
+    int prev_k = -1;
+    auto land = [&]() -> hipError_t { // the previous piece: wait for it, hand it to the caller's buffer
+      if (prev_k < 0)
+        return hipSuccess;
+      const hipError_t e = hipEventSynchronize(st.ev[prev_k]);
+      if (e != hipSuccess)
+        return e;
+      const char *src = static_cast<const char *>(st.buf[prev_k]);
+      char *dst = static_cast<char *>(h) + prev_off;
+      parallel_for((int64_t)prev_nb, [&](int64_t b, int64_t e2) { memcpy(dst + b, src + b, (size_t)(e2 - b)); }, 1 << 18);
+      prev_k = -1;
+      return hipSuccess;
+    };
+    for (size_t off = 0; off < bytes; off += piece)
+      {
+        const int k = st.next;
+        st.next ^= 1;
+        const size_t nb = std::min(piece, bytes - off);
+        hipError_t e = hipMemcpyAsync(st.buf[k], static_cast<const char *>(d) + off, nb, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+          e = hipEventRecord(st.ev[k], s);
+        if (e == hipSuccess)
+          e = land();
+        if (e != hipSuccess)
+          return e;
+        prev_k = k, prev_off = off, prev_nb = nb;
+      }
+    return land();
   }
 
   template <class T>
@@ -1616,6 +1679,7 @@ namespace
     struct Lv
     {
       double h[3];
+      long long clo[3] = {LLONG_MAX, LLONG_MAX, LLONG_MAX}, chi[3] = {LLONG_MIN, LLONG_MIN, LLONG_MIN}; // box of its cells' positions
     };
     std::vector<Lv> lv;
     std::vector<int8_t> cell_level((size_t)NC, -1);
@@ -1645,7 +1709,9 @@ namespace
           {
             if (lv.size() >= 100)
               continue;
-            lv.push_back(Lv{{h[0], h[1], h[2]}});
+            lv.push_back(Lv{});
+            for (int d = 0; d < 3; ++d)
+              lv.back().h[d] = h[d];
             L = (int)lv.size() - 1;
           }
         bool on = true;
@@ -1657,7 +1723,14 @@ namespace
             cpos[3 * (size_t)k + d] = i;
           }
         if (on)
-          cell_level[k] = (int8_t)L;
+          {
+            cell_level[k] = (int8_t)L;
+            for (int d = 0; d < 3; ++d)
+              {
+                lv[L].clo[d] = std::min(lv[L].clo[d], cpos[3 * (size_t)k + d]);
+                lv[L].chi[d] = std::max(lv[L].chi[d], cpos[3 * (size_t)k + d]);
+              }
+          }
       }
     if (lv.empty())
       return pl;
@@ -1681,25 +1754,41 @@ namespace
     auto hanging = [&](int32_t n) { return !hn_index.empty() && hn_index[n] >= 0; };
     std::vector<uint8_t> regular((size_t)N, 0);
     std::vector<long long> npos((size_t)N * 3, 0);
+    // Regular: every cell around the node that the level's box has room for exists, is of the node's level and has no
+    // hanging vertex.  A cell position OUTSIDE the box of the level's cells may be missing: the node then lies on a face of the
+    // level lattice -- for a level that reaches the boundary of the domain, on that boundary -- and the row-owner kernels
+    // treat it like a face node of a uniform box (fewer than 27 neighbours, cells from index ranges).
     for (int32_t n = 0; n < NO; ++n)
       {
-        if (n_inc[n] != 8 || node_level[n] < 0 || hanging(n) || is_parent[n])
+        if (n_inc[n] == 0 || node_level[n] < 0 || hanging(n) || is_parent[n])
           continue;
+        const Lv &l = lv[(size_t)node_level[n]];
         bool ok = true;
-        const int32_t k7 = inc[(size_t)n * 8 + 0]; // the cell of which n is vertex 0 sits AT the node's lattice position
-        ok = k7 >= 0;
         long long pn[3] = {0, 0, 0};
-        if (ok)
-          for (int d = 0; d < 3; ++d)
-            pn[d] = cpos[3 * (size_t)k7 + d];
+        bool have = false;
+        for (int a = 0; a < 8 && !have; ++a)
+          {
+            const int32_t k = inc[(size_t)n * 8 + a];
+            if (k >= 0)
+              {
+                have = true; // the cell of which n is vertex a lies at pn - (a_x, a_y, a_z)
+                pn[0] = cpos[3 * (size_t)k] + (a & 1), pn[1] = cpos[3 * (size_t)k + 1] + ((a >> 1) & 1), pn[2] = cpos[3 * (size_t)k + 2] + (a >> 2);
+              }
+          }
+        ok = have;
         for (int a = 0; a < 8 && ok; ++a)
           {
             const int32_t k = inc[(size_t)n * 8 + a];
-            ok = k >= 0;
-            if (!ok)
-              break;
-            // the cell of which n is vertex a lies at pn - (a_x, a_y, a_z)
-            ok = cpos[3 * (size_t)k] == pn[0] - (a & 1) && cpos[3 * (size_t)k + 1] == pn[1] - ((a >> 1) & 1) && cpos[3 * (size_t)k + 2] == pn[2] - (a >> 2);
+            const long long cp[3] = {pn[0] - (a & 1), pn[1] - ((a >> 1) & 1), pn[2] - (a >> 2)};
+            if (k == -1)
+              {
+                bool outside = false;
+                for (int d = 0; d < 3; ++d)
+                  outside = outside || cp[d] < l.clo[d] || cp[d] > l.chi[d];
+                ok = outside;
+                continue;
+              }
+            ok = k >= 0 && cpos[3 * (size_t)k] == cp[0] && cpos[3 * (size_t)k + 1] == cp[1] && cpos[3 * (size_t)k + 2] == cp[2];
             for (int b = 0; b < 8 && ok; ++b)
               ok = !hanging(m->cell_nodes[8 * (size_t)k + b]);
           }
@@ -1710,7 +1799,7 @@ namespace
               npos[3 * (size_t)n + d] = pn[d];
           }
       }
-    // per level: the box of its regular nodes + halo, the tables
+    // per level: the lattice of the box of its cells, the tables
     static const long long max_table = getenv("PFM_OVERLAY3_MAX_TABLE") ? atoll(getenv("PFM_OVERLAY3_MAX_TABLE")) : 400000000LL;
     static const long long min_rows = getenv("PFM_OVERLAY3_MIN_ROWS") ? atoll(getenv("PFM_OVERLAY3_MIN_ROWS")) : 64;
     for (size_t L = 0; L < lv.size(); ++L)
@@ -1727,7 +1816,12 @@ namespace
                   hi[d] = std::max(hi[d], npos[3 * (size_t)n + d]);
                 }
             }
-        const double vol = cnt ? (double)(hi[0] - lo[0] + 3) * (double)(hi[1] - lo[1] + 3) * (double)(hi[2] - lo[2] + 3) : 0.0;
+        for (int d = 0; d < 3 && cnt; ++d) // the lattice of the level: the nodes of the box of its cells
+          {
+            lo[d] = lv[L].clo[d];
+            hi[d] = lv[L].chi[d] + 1;
+          }
+        const double vol = cnt ? (double)(hi[0] - lo[0] + 1) * (double)(hi[1] - lo[1] + 1) * (double)(hi[2] - lo[2] + 1) : 0.0;
         if (cnt < min_rows || vol > (double)max_table || vol > 64.0 * (double)cnt)
           {
             // too few rows, or a box that is mostly empty (a thin refined band): these rows stay with the general family
@@ -1740,8 +1834,8 @@ namespace
         for (int d = 0; d < 3; ++d)
           {
             lev.h[d] = lv[L].h[d];
-            lev.lo[d] = lo[d] - 1;
-            lev.dims[d] = (int)(hi[d] - lo[d] + 3);
+            lev.lo[d] = lo[d];
+            lev.dims[d] = (int)(hi[d] - lo[d] + 1);
           }
         const long long NX = lev.dims[0], NY = lev.dims[1], NZ = lev.dims[2];
         lev.node_at.assign((size_t)(NX * NY * NZ), -1);
@@ -1850,8 +1944,8 @@ namespace
         cv.NZ = lev.dims[2];
         for (int d = 0; d < 3; ++d)
           {
-            cv.o0[d] = 1; // the rows of the launch lie inside the halo
-            cv.o1[d] = lev.dims[d] - 2;
+            cv.o0[d] = 0; // every node of the level lattice may own a row (CartView::row_of_box says which do)
+            cv.o1[d] = lev.dims[d] - 1;
             cv.h[d] = lev.h[d];
           }
         cv.local_of_box = dev_upload(c, lev.node_at.data(), lev.node_at.size());
@@ -1885,10 +1979,38 @@ namespace
   };
 } // namespace
 
+namespace
+{
+  // PFM_ABORT_TRACE=<file>: a backtrace of the aborting thread into that file (debugging aid: a test runner that captures
+  // stderr hides what libstdc++ or the HIP runtime say before they abort)
+  void abort_trace_handler(int)
+  {
+    const char *path = getenv("PFM_ABORT_TRACE");
+    const int fd = path ? open(path, O_WRONLY | O_CREAT | O_APPEND, 0644) : 2;
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, fd >= 0 ? fd : 2);
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+  }
+  void install_abort_trace()
+  {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      if (getenv("PFM_ABORT_TRACE"))
+        {
+          signal(SIGABRT, abort_trace_handler);
+          signal(SIGSEGV, abort_trace_handler);
+        }
+    });
+  }
+} // namespace
+
 extern "C"
 {
   int pfm_ctx_create(pfm_ctx **out, const pfm_mesh_desc *m, int device)
   {
+    install_abort_trace();
     PhaseClock clk;
     H2dBatch batch; // uploads are ordered on the null stream; the build ends with a device synchronisation
     if (!out || !m || (m->dim != 2 && m->dim != 3) ||
@@ -2449,13 +2571,40 @@ extern "C"
     return PFM_OK;
   }
 
+  static pfm_ctx::HostPin *find_pin(pfm_ctx *c, const void *p, size_t bytes);
+
+  // Host -> device copy of a buffer the CALLER owns.  Page-locked through pfm_host_register: an asynchronous DMA on `s`.
+  // Anything else goes through the library's own staging buffers (h2d) and is complete on return: the runtime's path for
+  // pageable memory pins the caller's pages on the fly, and on this stack that faulted intermittently ("Memory access fault by
+  // GPU ... on address <host heap>") when such pages had been registered and unregistered before (tests/test_gpu_cart.py's
+  // host-pointer cases followed by the 216^3 test).
+  static hipError_t h2d_user(pfm_ctx *c, void *d, const void *h, size_t bytes, hipStream_t s)
+  {
+    if (bytes == 0)
+      return hipSuccess;
+    if (find_pin(c, h, bytes))
+      return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    return h2d(d, h, bytes);
+  }
+
+  // The other direction.  Page-locked: asynchronous on `s`.  Pageable and up to 64 MB (glibc serves such blocks from the
+  // heap, where registered pages may have lived): through the staging buffers, complete on return.  Larger pageable arrays
+  // (always mappings of their own) take the runtime's path.
+  static hipError_t d2h_user(pfm_ctx *c, void *h, const void *d, size_t bytes, hipStream_t s)
+  {
+    if (bytes == 0)
+      return hipSuccess;
+    if (find_pin(c, h, bytes) || bytes > ((size_t)64 << 20))
+      return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    return d2h_staged(h, d, bytes, s);
+  }
+
   int pfm_set_constraints(pfm_ctx *c, const uint8_t *node_flags)
   {
     if (!c || !node_flags)
       return PFM_ERR_BAD_ARG;
     (void)hipSetDevice(c->device);
-    hipError_t e = hipMemcpyAsync(const_cast<uint8_t *>(c->v.node_flags), node_flags,
-                                  (size_t)c->v.n_nodes, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = h2d_user(c, const_cast<uint8_t *>(c->v.node_flags), node_flags, (size_t)c->v.n_nodes, c->stream);
     // capacity of the deferred patch list of the cartesian 3-D Jacobian (counted while the copy is in flight)
     if (c->cart_ok && c->v.dim == 3)
       {
@@ -2691,7 +2840,7 @@ extern "C"
                   return hipfail(c, e, "hipMalloc stage");
                 c->device_bytes += (int64_t)bytes;
               }
-            hipError_t e = hipMemcpyAsync(c->d_stage_vec[k], src[k], bytes, hipMemcpyHostToDevice, c->stream);
+            hipError_t e = h2d_user(c, c->d_stage_vec[k], src[k], bytes, c->stream);
             if (e != hipSuccess)
               return hipfail(c, e, "state H2D");
             d[k] = c->d_stage_vec[k];
@@ -3795,7 +3944,7 @@ extern "C"
                 continue;
               }
           }
-        e = hipMemcpyAsync(h_values[b], d_values[b], bytes, hipMemcpyDeviceToHost, b == 0 ? c->stream : c->copy_stream);
+        e = d2h_user(c, h_values[b], d_values[b], bytes, b == 0 ? c->stream : c->copy_stream);
       }
     if (e == hipSuccess)
       e = hipEventRecord(c->ev_copy, c->copy_stream);
@@ -3849,9 +3998,9 @@ extern "C"
     if (rc)
       return rc;
     // the residual first (the caller's Newton loop reads it at once, cracks.cc:2791-2794), then the matrix blocks
-    hipError_t e = hipMemcpyAsync(residual_pde, c->d_stage_res[0], vb, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = d2h_user(c, residual_pde, c->d_stage_res[0], vb, c->stream);
     if (e == hipSuccess && residual_only)
-      e = hipMemcpyAsync(residual_total, c->d_stage_res[1], vb, hipMemcpyDeviceToHost, c->stream);
+      e = d2h_user(c, residual_total, c->d_stage_res[1], vb, c->stream);
     if (e != hipSuccess)
       return hipfail(c, e, "copy back");
     if (!residual_only)
