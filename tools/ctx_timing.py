@@ -1,3 +1,6 @@
+"""Wall time of the phases of pfm_ctx_create (PFM_CTX_TIMING=1 prints them): `python tools/ctx_timing.py c5` -- the meshes
+of the config-5 stand-in, two contexts each (the first of a process pays one-time costs); `python tools/ctx_timing.py 216` --
+three contexts on the 216^3 box.  profiles/r05/ctx_timing_*.txt."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

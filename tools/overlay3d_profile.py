@@ -1,3 +1,6 @@
+"""Six Jacobian assemblies of bench.py's 3-D overlay mesh (84^3, inner half refined) for rocprofv3 --kernel-trace:
+`PFM_GENERAL_SEQUENTIAL=1 rocprofv3 --kernel-trace --stats ... -- python tools/overlay3d_profile.py` gives the sequential
+durations of the level kernels and of the general family's classes (profiles/r05/ov3_kst*.txt, ov3_timeline.txt)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
