@@ -12,9 +12,77 @@
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <mutex>
+#include <vector>
 
 namespace pfm
 {
+  namespace
+  {
+    struct ScratchEntry
+    {
+      void *p = nullptr;
+      size_t bytes = 0;
+      int device = 0;
+      bool in_use = false;
+    };
+    std::mutex g_scratch_mx;
+    std::vector<ScratchEntry> g_scratch;
+    constexpr size_t SCRATCH_KEEP_ONE = (size_t)32 << 20, SCRATCH_KEEP_ALL = (size_t)64 << 20;
+  } // namespace
+
+  hipError_t scratch_acquire(void **p, size_t bytes)
+  {
+    *p = nullptr;
+    bytes = std::max<size_t>(bytes, 16);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> lk(g_scratch_mx);
+      ScratchEntry *best = nullptr;
+      size_t kept = 0;
+      for (auto &e : g_scratch)
+        {
+          kept += e.bytes;
+          if (!e.in_use && e.device == dev && e.bytes >= bytes && e.bytes <= std::max<size_t>(4 * bytes, (size_t)1 << 20) && (!best || e.bytes < best->bytes))
+            best = &e;
+        }
+      if (best)
+        {
+          best->in_use = true;
+          *p = best->p;
+          return hipSuccess;
+        }
+      if (bytes <= SCRATCH_KEEP_ONE && kept + bytes <= SCRATCH_KEEP_ALL && g_scratch.size() < 64)
+        {
+          void *q = nullptr;
+          const hipError_t e = hipMalloc(&q, bytes);
+          if (e != hipSuccess)
+            return e;
+          g_scratch.push_back(ScratchEntry{q, bytes, dev, true});
+          *p = q;
+          return hipSuccess;
+        }
+    }
+    return hipMalloc(p, bytes);
+  }
+
+  void scratch_release(void *p)
+  {
+    if (!p)
+      return;
+    {
+      std::lock_guard<std::mutex> lk(g_scratch_mx);
+      for (auto &e : g_scratch)
+        if (e.p == p)
+          {
+            e.in_use = false;
+            return;
+          }
+    }
+    (void)hipFree(p);
+  }
+
   namespace
   {
     constexpr int MAX_ROW = 254; // the slot tables of the general family hold uint8 positions
@@ -143,11 +211,11 @@ namespace pfm
     auto fail = [&]() {
       for (void *q : {(void *)cnt, (void *)inc_ptr, (void *)inc, (void *)status, (void *)deg, tmp})
         if (q)
-          (void)hipFree(q);
+          scratch_release(q);
       return PFM_ERR_HIP;
     };
-    if (hipMalloc((void **)&cnt, sizeof(int) * ((size_t)NO + 1)) != hipSuccess || hipMalloc((void **)&inc_ptr, sizeof(int) * ((size_t)NO + 1)) != hipSuccess ||
-        hipMalloc((void **)&deg, sizeof(long long) * ((size_t)NO + 1)) != hipSuccess || hipMalloc((void **)&status, sizeof(int)) != hipSuccess)
+    if (scratch_acquire((void **)&cnt, sizeof(int) * ((size_t)NO + 1)) != hipSuccess || scratch_acquire((void **)&inc_ptr, sizeof(int) * ((size_t)NO + 1)) != hipSuccess ||
+        scratch_acquire((void **)&deg, sizeof(long long) * ((size_t)NO + 1)) != hipSuccess || scratch_acquire((void **)&status, sizeof(int)) != hipSuccess)
       return fail();
     if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)NO + 1), s) != hipSuccess || hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess ||
         hipMemsetAsync(deg, 0, sizeof(long long) * ((size_t)NO + 1), s) != hipSuccess)
@@ -160,7 +228,7 @@ namespace pfm
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb1, cnt, inc_ptr, NO + 1, s);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, deg, d_nadj_ptr, NO + 1, s);
     const size_t tb = std::max(tb1, tb2);
-    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+    if (scratch_acquire(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
       return fail();
     size_t tbb = tb;
     if (hipcub::DeviceScan::ExclusiveSum(tmp, tbb, cnt, inc_ptr, NO + 1, s) != hipSuccess)
@@ -168,7 +236,7 @@ namespace pfm
     int n_inc = 0;
     if (hipMemcpyAsync(&n_inc, inc_ptr + NO, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       return fail();
-    if (hipMalloc((void **)&inc, sizeof(int) * (size_t)std::max(n_inc, 1)) != hipSuccess)
+    if (scratch_acquire((void **)&inc, sizeof(int) * (size_t)std::max(n_inc, 1)) != hipSuccess)
       return fail();
     if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)NO + 1), s) != hipSuccess)
       return fail();
@@ -183,10 +251,10 @@ namespace pfm
         hipMemcpyAsync(&st, status, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
         hipGetLastError() != hipSuccess)
       return fail();
-    (void)hipFree(cnt);
-    (void)hipFree(deg);
-    (void)hipFree(status);
-    (void)hipFree(tmp);
+    scratch_release(cnt);
+    scratch_release(deg);
+    scratch_release(status);
+    scratch_release(tmp);
     sc.inc_ptr = inc_ptr;
     sc.inc = inc;
     if (st != 0)
@@ -212,9 +280,9 @@ namespace pfm
   void graph_build_free(GraphScratch &sc)
   {
     if (sc.inc_ptr)
-      (void)hipFree(sc.inc_ptr);
+      scratch_release(sc.inc_ptr);
     if (sc.inc)
-      (void)hipFree(sc.inc);
+      scratch_release(sc.inc);
     sc = GraphScratch{};
   }
 
@@ -258,15 +326,15 @@ namespace pfm
     void *tmp = nullptr;
     size_t tb = 0;
     auto done = [&](int rc) {
-      (void)hipFree(deg);
-      (void)hipFree(tmp);
+      scratch_release(deg);
+      scratch_release(tmp);
       return rc;
     };
-    if (hipMalloc((void **)&deg, sizeof(long long) * (size_t)(NN + 1)) != hipSuccess)
+    if (scratch_acquire((void **)&deg, sizeof(long long) * (size_t)(NN + 1)) != hipSuccess)
       return done(PFM_ERR_HIP);
     hipLaunchKernelGGL(k_lattice_degree, dim3((unsigned)((NN + 256) / 256)), dim3(256), 0, s, deg, NX, NY, NZ);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, deg, d_ptr, (int)(NN + 1), s);
-    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+    if (scratch_acquire(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
       return done(PFM_ERR_HIP);
     if (hipcub::DeviceScan::ExclusiveSum(tmp, tb, deg, d_ptr, (int)(NN + 1), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
         hipGetLastError() != hipSuccess)
@@ -287,15 +355,15 @@ namespace pfm
     size_t tb = 0;
     auto done = [&](int rc) {
       for (void *q : {(void *)key, (void *)key2, (void *)cell, tmp})
-        (void)hipFree(q);
+        scratch_release(q);
       return rc;
     };
-    if (hipMalloc((void **)&key, (size_t)NC) != hipSuccess || hipMalloc((void **)&key2, (size_t)NC) != hipSuccess ||
-        hipMalloc((void **)&cell, sizeof(int32_t) * (size_t)NC) != hipSuccess)
+    if (scratch_acquire((void **)&key, (size_t)NC) != hipSuccess || scratch_acquire((void **)&key2, (size_t)NC) != hipSuccess ||
+        scratch_acquire((void **)&cell, sizeof(int32_t) * (size_t)NC) != hipSuccess)
       return done(PFM_ERR_HIP);
     hipLaunchKernelGGL(k_lattice_cell_colour, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, s, d_vertex0, d_box_of_local, NC, NX, NY, key, cell);
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key, key2, cell, d_order, (int)NC, 0, 3, s);
-    if (hipMalloc(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
+    if (scratch_acquire(&tmp, std::max<size_t>(tb, 16)) != hipSuccess)
       return done(PFM_ERR_HIP);
     if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, key, key2, cell, d_order, (int)NC, 0, 3, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
         hipGetLastError() != hipSuccess)

@@ -1211,6 +1211,16 @@ namespace
     const int64_t NC = m->n_cells;
     if (m->dim != 2 || NC == 0 || getenv("PFM_NO_PATCH"))
       return pl;
+    // PFM_CTX_TIMING=1: the phases of this classification on stderr (it runs on a thread of its own)
+    const bool ptime = getenv("PFM_CTX_TIMING") != nullptr;
+    auto pt0 = std::chrono::steady_clock::now();
+    auto pmark = [&](const char *what) {
+      if (!ptime)
+        return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[pfm_ctx_create]     plan: %-22s %6.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - pt0).count());
+      pt0 = t1;
+    };
     const double *X = m->coords;
     double xmin, ymin, xmax, ymax;
     {
@@ -1239,6 +1249,7 @@ namespace
         }
     }
     const double tol = 1e-9 * std::max(xmax - xmin, ymax - ymin);
+    pmark("bounds");
     // level of a cell (by its size), lattice position of its lower-left vertex
     struct Level
     {
@@ -1292,8 +1303,9 @@ namespace
     if (levels.empty())
       return pl;
     const int NL = (int)levels.size();
-    std::vector<int8_t> cell_level((size_t)NC);
-    std::vector<int32_t> cix((size_t)NC), ciy((size_t)NC);
+    pmark("levels");
+    pfm::raw_vector<int8_t> cell_level((size_t)NC); // (written by the loop below: the pages are first touched by its threads)
+    pfm::raw_vector<int32_t> cix((size_t)NC), ciy((size_t)NC);
     {
       std::vector<Level> part((size_t)ntc * NL);
       std::atomic<bool> too_far{false};
@@ -1345,7 +1357,8 @@ namespace
           }
     }
     // incident cells per node: inc[4 n + a] = the cell of which n is vertex a (-1 none, -2 two cells claim the corner)
-    std::vector<int32_t> inc((size_t)N * 4);
+    pmark("cell levels");
+    pfm::raw_vector<int32_t> inc((size_t)N * 4);
     parallel_for((int64_t)N * 4, [&](int64_t b, int64_t e) { std::fill(inc.begin() + b, inc.begin() + e, -1); });
     parallel_for(NC, [&](int64_t cb, int64_t ce) {
       for (int64_t k = cb; k < ce; ++k)
@@ -1357,13 +1370,20 @@ namespace
               __atomic_store_n(slot, -2, __ATOMIC_RELAXED);
           }
     }, 8192);
-    std::vector<uint8_t> is_parent((size_t)N, 0);
+    pfm::raw_vector<uint8_t> is_parent((size_t)N), dup((size_t)N);
+    pfm::raw_vector<int8_t> node_level((size_t)N); // of regular nodes: the common level of their four cells
+    std::vector<uint8_t> regular((size_t)N); // (handed over to the plan)
+    parallel_for(N, [&](int64_t b, int64_t e) {
+      std::fill(is_parent.begin() + b, is_parent.begin() + e, (uint8_t)0);
+      std::fill(dup.begin() + b, dup.begin() + e, (uint8_t)0);
+      std::fill(node_level.begin() + b, node_level.begin() + e, (int8_t)-1);
+      std::fill(regular.begin() + b, regular.begin() + e, (uint8_t)0);
+    });
     if (m->n_hanging > 0)
       for (int64_t j = 0; j < m->hn_ptr[m->n_hanging]; ++j)
         is_parent[m->hn_parents[j]] = 1;
     // two nodes at one lattice position (the lips of a slit, meshes/unit_slit.inp): neither they nor their neighbours are
     // regular.  One table per level (node at a lattice position), all in one array.
-    std::vector<uint8_t> dup((size_t)N, 0);
     {
       std::vector<long long> off((size_t)NL + 1, 0), Wn((size_t)NL, 0);
       for (int L = 0; L < NL; ++L)
@@ -1381,7 +1401,7 @@ namespace
             }
           off[(size_t)L + 1] = off[L] + sz;
         }
-      std::vector<int32_t> node_at((size_t)off[NL]);
+      pfm::raw_vector<int32_t> node_at((size_t)off[NL]);
       parallel_for(off[NL], [&](int64_t b, int64_t e) { std::fill(node_at.begin() + b, node_at.begin() + e, -1); });
       parallel_for(NC, [&](int64_t cb, int64_t ce) {
         for (int64_t k = cb; k < ce; ++k)
@@ -1402,8 +1422,7 @@ namespace
       }, 8192);
     }
     auto hanging = [&](int32_t n) { return (!hn_index.empty() && hn_index[n] >= 0) || dup[n] != 0; };
-    std::vector<uint8_t> regular((size_t)N, 0);
-    std::vector<int8_t> node_level((size_t)N, -1); // of regular nodes: the common level of their four cells
+    pmark("incident cells, duplicates");
     int64_t n_regular = 0;
     {
       const int nt = chunks_for(NO, 8192);
@@ -1441,6 +1460,7 @@ namespace
     }
     if (n_regular == 0)
       return pl;
+    pmark("regular nodes");
     // blocks: block (bx, by) of a level owns the lattice nodes [7 bx, 7 bx + 6] x [7 by, 7 by + 6] and holds the cells
     // [7 bx - 1, 7 bx + 6] x [7 by - 1, 7 by + 6]; node (i, j) of the lattice = upper-right vertex of cell (i - 1, j - 1)
     std::vector<int32_t> blk_cells, blk_nodes;
@@ -1452,7 +1472,7 @@ namespace
         const long long W = lv.ix1 - lv.ix0 + 1, Hh = lv.iy1 - lv.iy0 + 1;
         if ((double)W * (double)Hh > 4.0e8)
           continue; // a level whose bounding box is mostly empty: not worth a dense table
-        std::vector<int32_t> at((size_t)(W * Hh));
+        pfm::raw_vector<int32_t> at((size_t)(W * Hh));
         parallel_for(W * Hh, [&](int64_t b, int64_t e) { std::fill(at.begin() + b, at.begin() + e, -1); });
         parallel_for(NC, [&](int64_t cb, int64_t ce) {
           for (int64_t k = cb; k < ce; ++k)
@@ -1511,11 +1531,13 @@ namespace
           }
       }
     const int n_blocks = (int)(blk_cells.size() / 64);
+    pmark("blocks");
     if (n_blocks == 0)
       return pl;
     // only the rows some block really writes are the patch kernel's (a level without a table above keeps its rows general)
     {
-      std::vector<uint8_t> covered((size_t)N, 0);
+      std::vector<uint8_t> covered((size_t)N);
+      parallel_for(N, [&](int64_t b, int64_t e) { std::fill(covered.begin() + b, covered.begin() + e, (uint8_t)0); });
       const int nt = chunks_for(n_blocks, 64);
       std::vector<int64_t> cnt((size_t)nt, 0);
       parallel_chunks(nt, [&](int t) {
@@ -1536,6 +1558,7 @@ namespace
       regular.swap(covered);
     }
     // the rows of the general family (zeroed before every Jacobian; the patch kernel stores its rows whole)
+    pmark("covered");
     std::vector<int32_t> rows_general = parallel_select(0, NO, [&](int64_t n) { return !regular[n]; });
     pl.hang.resize((size_t)N);
     parallel_for(N, [&](int64_t nb, int64_t ne) {
@@ -1546,6 +1569,7 @@ namespace
     pl.blk_cells.swap(blk_cells);
     pl.blk_nodes.swap(blk_nodes);
     pl.rows_general.swap(rows_general);
+    pmark("rows, flags");
     pl.n_regular = n_regular;
     pl.n_blocks = n_blocks;
     return pl;
@@ -2075,8 +2099,8 @@ extern "C"
       if (hipSetDevice(device) != hipSuccess)
         return bad(hipGetLastError(), "hipSetDevice");
       const size_t cb = sizeof(int32_t) * std::max<size_t>((size_t)NC * nv, 1), xb = sizeof(double) * (size_t)N * dim;
-      if (hipMalloc((void **)&up.raw, cb) != hipSuccess || hipMalloc((void **)&up.conn, cb) != hipSuccess ||
-          hipMalloc((void **)&up.rawx, xb) != hipSuccess || hipMalloc((void **)&up.xs, xb) != hipSuccess)
+      if (scratch_acquire((void **)&up.raw, cb) != hipSuccess || hipMalloc((void **)&up.conn, cb) != hipSuccess ||
+          scratch_acquire((void **)&up.rawx, xb) != hipSuccess || hipMalloc((void **)&up.xs, xb) != hipSuccess)
         return bad(hipGetLastError(), "hipMalloc");
       hipError_t e2 = NC > 0 ? h2d(up.raw, m->cell_nodes, sizeof(int32_t) * (size_t)NC * nv) : hipSuccess;
       if (e2 != hipSuccess)
@@ -2098,9 +2122,13 @@ extern "C"
         if (t.joinable())
           t.join();
         if (!taken)
-          for (void *q : {(void *)u.raw, (void *)u.conn, (void *)u.rawx, (void *)u.xs})
-            if (q)
-              (void)hipFree(q);
+          {
+            scratch_release(u.raw);
+            scratch_release(u.rawx);
+            for (void *q : {(void *)u.conn, (void *)u.xs})
+              if (q)
+                (void)hipFree(q);
+          }
       }
     } upload_joiner{upload_thread, up};
     try
@@ -2267,8 +2295,8 @@ extern "C"
           c->device_bytes += (int64_t)(sizeof(int32_t) * (size_t)NC * nv + sizeof(double) * (size_t)N * dim);
           if (up.err != hipSuccess)
             {
-              (void)hipFree(raw);
-              (void)hipFree(rawx);
+              scratch_release(raw);
+              scratch_release(rawx);
               throw HipFail{up.err, up.what};
             }
           const int rct = up.rct, rcx = up.rcx;
@@ -2317,15 +2345,15 @@ extern "C"
             }
           catch (...)
             {
-              (void)hipFree(raw);
-              (void)hipFree(rawx);
+              scratch_release(raw);
+              scratch_release(rawx);
               throw;
             }
           clk.mark("  row pointers to the host");
           const hipError_t es = hipDeviceSynchronize();
           clk.mark("  device synchronize");
-          (void)hipFree(raw);
-          (void)hipFree(rawx);
+          scratch_release(raw);
+          scratch_release(rawx);
           if (rcg == PFM_ERR_UNSUPPORTED)
             return fail(c, PFM_ERR_UNSUPPORTED, "node with more than 254 neighbours");
           if (rct != PFM_OK || rcx != PFM_OK || rcg != PFM_OK || es != hipSuccess)

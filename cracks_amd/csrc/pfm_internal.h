@@ -214,6 +214,12 @@ namespace pfm
                        const int32_t *d_hn_parents, const long long *d_nadj_ptr, int32_t *d_nadj, const GraphScratch &sc, hipStream_t s);
   void graph_build_free(GraphScratch &sc);
   // row tables (CartView::nbr_mask, row_perm) of one level lattice of the 3-D cartesian overlay, from the current row order
+  // Device scratch of the context build (raw mesh tables before their transposition, incidence lists and scan space of the
+  // node graph): buffers up to 32 MB are kept between builds (64 MB at most) -- a hipMalloc / hipFree pair costs 0.1-0.4 ms and
+  // the free synchronises the device, a rebuild at 2.7e5 cells made eight of them.  Users run on the NULL stream, so a buffer
+  // handed back while its last kernel is still queued is safe to hand out again.  Contents undefined.
+  hipError_t scratch_acquire(void **p, size_t bytes);
+  void scratch_release(void *p);
   int launch_lattice_row_ptr(long long *d_ptr, int NX, int NY, int NZ, hipStream_t s);
   int launch_lattice_colour_order(int32_t *d_order, const int32_t *d_vertex0, const int32_t *d_box_of_local, long long NC, int NX, int NY, hipStream_t s);
   int launch_check_row_lengths(const uint8_t *d_mark, const long long *d_ptr, int32_t NO, int want, int *d_bad, hipStream_t s);
