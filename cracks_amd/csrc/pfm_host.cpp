@@ -1008,9 +1008,42 @@ namespace
     bool overflow = false;  // more than 62 classes were needed: such cells sit in the atomic class although no vertex hangs
     bool cancelled = false; // the caller lost interest (cancel): ptr and order are not filled
   };
+  // the distinct constraint-resolved nodes of a cell (a vertex that does not hang is its own, a hanging one brings its
+  // parents); returns their number, or max_nodes + 1 when there are more
+  template <class NodeOf>
+  int resolved_nodes(int64_t cell, int nv, NodeOf node_of, const int32_t *hn_index, const int64_t *hn_ptr, const int32_t *hn_parents, int32_t *out,
+                     int max_nodes)
+  {
+    int R = 0;
+    for (int a = 0; a < nv; ++a)
+      {
+        const int32_t A = node_of(cell, a);
+        const int32_t k = hn_index ? hn_index[A] : -1;
+        const int64_t rb = k < 0 ? 0 : hn_ptr[k], re = k < 0 ? 1 : hn_ptr[k + 1];
+        for (int64_t r = rb; r < re; ++r)
+          {
+            const int32_t P = k < 0 ? A : hn_parents[r];
+            bool known = false;
+            for (int t = 0; t < R; ++t)
+              known = known || out[t] == P;
+            if (known)
+              continue;
+            if (R == max_nodes)
+              return max_nodes + 1;
+            out[R++] = P;
+          }
+      }
+    return R;
+  }
+
+  // hn_ptr / hn_parents != nullptr (3-D, round 5): a cell at a hanging vertex is coloured like any other, over its
+  // constraint-resolved nodes -- the cell kernel reduces its element matrix and residual to those nodes before it adds
+  // (K' = C^T K C, DevView::cres), so cells of one class that share no resolved node write disjoint entries and need no
+  // atomics: every class adds in a fixed order and the assembly is bitwise reproducible.  Only a cell with more than 16
+  // resolved nodes (or one that finds no colour) stays in the last class.
   template <class NodeOf>
   void greedy_colours(int64_t NC, int nv, int32_t N, NodeOf node_of, const int32_t *hn_index, const uint8_t *subset, const std::atomic<bool> *cancel,
-                      Colours &out)
+                      Colours &out, const int64_t *hn_ptr = nullptr, const int32_t *hn_parents = nullptr)
   {
     constexpr uint8_t NONE = 255, ATOMIC = 254;
     pfm::raw_vector<uint8_t> col((size_t)NC);
@@ -1030,19 +1063,28 @@ namespace
           }
         uint64_t mask = 0;
         bool hanging = false;
-        int32_t nd[8];
+        int32_t nd[16];
+        int nn = nv;
         for (int a = 0; a < nv; ++a)
           {
             nd[a] = node_of(cell, a);
-            mask |= used[nd[a]];
             hanging = hanging || (hn_index && hn_index[nd[a]] >= 0);
           }
+        bool colourable = !hanging;
+        if (hanging && hn_ptr)
+          {
+            nn = resolved_nodes(cell, nv, node_of, hn_index, hn_ptr, hn_parents, nd, 16);
+            colourable = nn <= 16;
+          }
+        if (colourable)
+          for (int a = 0; a < nn; ++a)
+            mask |= used[nd[a]];
         int k = 63;
-        if (!hanging && ~mask != 0)
+        if (colourable && ~mask != 0)
           k = __builtin_ctzll(~mask);
         if (k < 62)
           {
-            for (int a = 0; a < nv; ++a)
+            for (int a = 0; a < nn; ++a)
               used[nd[a]] |= 1ull << k;
             n_col = std::max(n_col, k + 1);
             col[cell] = (uint8_t)k;
@@ -1050,7 +1092,7 @@ namespace
         else
           {
             col[cell] = ATOMIC;
-            out.overflow = out.overflow || !hanging;
+            out.overflow = out.overflow || !hanging || (hn_ptr && colourable); // a cell that should have had a colour and found none
           }
       }
     // counting sort, chunked over the host threads
@@ -1090,7 +1132,7 @@ namespace
   // latency-bound waves, 15 % of a Jacobian at 2.7e5 cells -- runs next to the others.  false: no such cell (ring empty).
   template <class NodeOf>
   bool ring_cells(int64_t NC, int nv, int32_t N, NodeOf node_of, const int32_t *hn_index, const int64_t *hn_ptr, const int32_t *hn_parents,
-                  std::vector<uint8_t> &ring)
+                  std::vector<uint8_t> &ring, bool hanging_coloured = false)
   {
     ring.clear();
     if (!hn_index)
@@ -1104,6 +1146,12 @@ namespace
           bool hanging = false;
           for (int a = 0; a < nv; ++a)
             hanging = hanging || hn_index[node_of(cell, a)] >= 0;
+          if (hanging && hanging_coloured)
+            {
+              // (greedy_colours: such a cell sits in a plain class unless it has more than 16 resolved nodes)
+              int32_t tmp[16];
+              hanging = resolved_nodes(cell, nv, node_of, hn_index, hn_ptr, hn_parents, tmp, 16) > 16;
+            }
           at_hanging[cell] = hanging ? 1 : 0;
           if (!hanging)
             continue;
@@ -1163,8 +1211,21 @@ namespace
         if (hipMemcpy(hn.data(), v.hn_index, sizeof(int32_t) * hn.size(), hipMemcpyDeviceToHost) != hipSuccess)
           throw HipFail{hipGetLastError(), "hanging index D2H"};
       }
+    pfm::raw_vector<long long> hp;
+    pfm::raw_vector<int32_t> hpar;
+    if (c->hanging_coloured && v.hn_index && c->n_hanging > 0)
+      {
+        hp.resize((size_t)c->n_hanging + 1);
+        if (hipMemcpy(hp.data(), v.hn_ptr, sizeof(long long) * hp.size(), hipMemcpyDeviceToHost) != hipSuccess)
+          throw HipFail{hipGetLastError(), "hanging table D2H"};
+        hpar.resize((size_t)hp.back());
+        if (!hpar.empty() && hipMemcpy(hpar.data(), v.hn_parents, sizeof(int32_t) * hpar.size(), hipMemcpyDeviceToHost) != hipSuccess)
+          throw HipFail{hipGetLastError(), "hanging table D2H"};
+      }
+    static_assert(sizeof(long long) == sizeof(int64_t), "hanging row pointers");
     Colours col;
-    greedy_colours(NC, nv, v.n_nodes, [&](int64_t cell, int a) { return conn[(size_t)a * NC + cell]; }, v.hn_index ? hn.data() : nullptr, nullptr, nullptr, col);
+    greedy_colours(NC, nv, v.n_nodes, [&](int64_t cell, int a) { return conn[(size_t)a * NC + cell]; }, v.hn_index ? hn.data() : nullptr, nullptr, nullptr, col,
+                   hp.empty() ? nullptr : reinterpret_cast<const int64_t *>(hp.data()), hp.empty() ? nullptr : hpar.data());
     v.color_cells = dev_upload(c, col.order.data(), col.order.size());
     c->color_ptr.swap(col.ptr);
     if (col.overflow)
@@ -1946,7 +2007,8 @@ namespace
         }
     });
     Colours red; // (see finish_patches2d)
-    greedy_colours(NC, 8, m->n_nodes, [&](int64_t cell, int a) { return m->cell_nodes[8 * cell + a]; }, hn_index, need.data(), nullptr, red);
+    greedy_colours(NC, 8, m->n_nodes, [&](int64_t cell, int a) { return m->cell_nodes[8 * cell + a]; }, hn_index, need.data(), nullptr, red,
+                   c->hanging_coloured ? m->hn_ptr : nullptr, c->hanging_coloured ? m->hn_parents : nullptr);
     if (red.overflow)
       return;
     c->color_ptr_reduced.swap(red.ptr);
@@ -2192,6 +2254,18 @@ extern "C"
         // the general family only (finish_patches2d / 3d), the lists over all cells are then made on first use.
         const int32_t *hn_idx = hn_index.empty() ? nullptr : hn_index.data();
         auto node_of = [m, nv](int64_t cell, int a) { return m->cell_nodes[cell * nv + a]; };
+        // PFM_HANGING_COLOURED=1 (read at every pfm_ctx_create): the 3-D cells at hanging vertices in plain colour classes
+        // (greedy_colours) instead of the one class with FP64 atomics -- every assembly of such a mesh is then bitwise
+        // reproducible; it costs some thirty small launches per assembly (1.1e6-cell overlay mesh: Jacobian 4.45 -> 5.1 ms,
+        // residual only 0.6 -> 1.3 ms), so the default keeps the atomic class.  Needs the records of DevView::cres, i.e.
+        // hanging nodes with at most four parents.
+        bool hanging_coloured = dim == 3 && hn_idx && !lattice_ok && getenv("PFM_HANGING_COLOURED") != nullptr;
+        for (int32_t k = 0; k < m->n_hanging && hanging_coloured; ++k)
+          hanging_coloured = m->hn_ptr[k + 1] - m->hn_ptr[k] <= 4;
+        c->hanging_coloured = hanging_coloured;
+        c->n_hanging = m->n_hanging;
+        const int64_t *col_hn_ptr = hanging_coloured ? m->hn_ptr : nullptr;
+        const int32_t *col_hn_parents = hanging_coloured ? m->hn_parents : nullptr;
         Colours full;
         std::atomic<bool> colour_cancel{false};
         std::exception_ptr colour_err;
@@ -2239,7 +2313,7 @@ extern "C"
                   });
                 }
               else
-                greedy_colours(NC, nv, N, node_of, hn_idx, nullptr, &colour_cancel, full);
+                greedy_colours(NC, nv, N, node_of, hn_idx, nullptr, &colour_cancel, full, col_hn_ptr, col_hn_parents);
             }
           catch (...)
             {
@@ -2370,7 +2444,7 @@ extern "C"
           std::rethrow_exception(patch_err);
         clk.mark("overlay plan (wait)");
         std::vector<uint8_t> ring;
-        const bool any_ring = !lattice_ok && ring_cells(NC, nv, N, node_of, hn_idx, m->hn_ptr, m->hn_parents, ring);
+        const bool any_ring = !lattice_ok && ring_cells(NC, nv, N, node_of, hn_idx, m->hn_ptr, m->hn_parents, ring, hanging_coloured);
         v.cell_ring = any_ring ? dev_upload(c, ring.data(), ring.size()) : nullptr;
         v.color_cells = nullptr;
         v.hcell = nullptr;

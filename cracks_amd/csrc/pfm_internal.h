@@ -270,6 +270,8 @@ struct pfm_ctx
   // cell kernel (v.cslot) are 1.1 + 1.1 + 0.65 GB at 1e7 cells and are only needed by pfm_pattern_get / _bind and by the
   // general family: built on first use (ensure_host_graph, ensure_general_tables in pfm_host.cpp)
   bool graph_positional = false; // uniform box, node n at lattice position n, no ghosts: row pointers and colour lists are made on the device
+  bool hanging_coloured = false; // 3-D: cells at hanging vertices sit in plain colour classes (reduced scatter, no atomics)
+  int32_t n_hanging = 0;
   bool full_colours_lazy = false; // overlay context: the colour lists over ALL cells are made when the general family first runs without the overlay
   bool colours_lazy = false;     // DevView::color_cells is filled when the general family is first used (ensure_general_tables)
   bool graph_lazy = false;    // h_nadj not materialised yet (h_nadj_ptr is)

@@ -222,11 +222,14 @@ namespace pfm
       constexpr int QST = 50; // doubles per (q-point slot, cell) of the 3-D exchange buffer: 49 used, stride free of bank conflicts for 16-byte reads
       // KRED (the class of the 3-D cells at hanging vertices): the scatter first forms C^T K C over the cell's constraint-resolved
       // nodes in LDS (below); the cell's part of the exchange buffer is the head of a region that holds its 8 x 8 x 13 matrix
-      constexpr bool KRED = Q3 && ATOMIC;
+      constexpr bool KRED = Q3 && !PATCH; // (round 5, second step: in the plain classes as well, see the scatter)
       constexpr int KCMP = 13;                      // Kuu 3 x 3, Kpu 3, Kpp
       constexpr int KCELL = KRED ? nv * nv * KCMP : NSLOT * QST; // doubles per cell of s_q
       __shared__ __attribute__((aligned(16))) double s_q[(dim == 3 && !SPLIT) ? (KRED ? CPB * KCELL : NSLOT * CPB * QST) : 2];
       auto sq_at = [&](int slot, int cell_in_wg) { return KRED ? cell_in_wg * KCELL + slot * QST : (slot * CPB + cell_in_wg) * QST; };
+      __shared__ double s_rr[(dim == 3 && !PATCH) ? CPB : 1][nv][nc]; // residual entries of a cell at hanging vertices, by vertex
+      __shared__ uint8_t s_icnt[KRED ? CPB : 1][16], s_ia[KRED ? CPB : 1][16][8];
+      __shared__ double s_iw[KRED ? CPB : 1][16][8];
 
       const int tid = threadIdx.x;
       const int a = tid % nv, part = Q3 ? (tid / nv) % NPART : 0, cl0 = tid / LPC;
@@ -1291,7 +1294,23 @@ namespace pfm
         }
 
       // =============================== scatter through the constraints (cracks.cc:2439-2464)
-      if constexpr (!ATOMIC)
+      // 3-D cell at a hanging vertex with a record in DevView::cres: its matrix and residual are reduced to its distinct
+      // constraint-resolved nodes in LDS and every value is added ONCE (below).  Such cells sit in plain colour classes
+      // (pfm_host.cpp: greedy_colours over the resolved nodes): plain read-modify-write in a fixed order, bitwise reproducible.
+      const uint8_t *rec = nullptr;
+      int RN = 0xff;
+      if constexpr (dim == 3 && !PATCH)
+        if (v.cres)
+          {
+            const int hc3 = v.hcell[cell];
+            if (hc3 >= 0)
+              {
+                rec = v.cres + (long long)hc3 * PFM_CRES_BYTES;
+                RN = (int)rec[PFM_CRES_R];
+              }
+          }
+      const bool red = RN <= 16;
+      if (!ATOMIC && !red)
         {
           // Colour class without hanging vertices: the rows of node A are touched by this thread only during this
           // launch.  Every batch of read-modify-writes loads all its old values before the first store (the adds of a
@@ -1433,6 +1452,15 @@ namespace pfm
         }
       const uint8_t *cs = v.cslot + (long long)cell * nv * nv;
       constexpr int MPH = dim == 3 ? 4 : 2;
+      bool add_atomically = ATOMIC;
+      if constexpr (RING)
+        add_atomically = add_atomically || v.cell_ring[cell] != 0;
+      auto add_rt = [&](double *p, double x) __attribute__((always_inline)) {
+        if (add_atomically)
+          unsafeAtomicAdd(p, x);
+        else
+          *p += x;
+      };
       const int hc = v.cslot_h ? v.hcell[cell] : -1;
       const uint8_t *csh = hc >= 0 ? v.cslot_h + (long long)hc * (nv * MPH * nv * MPH) : nullptr;
       const int kA = v.hn_index ? v.hn_index[A] : -1;
@@ -1441,7 +1469,64 @@ namespace pfm
 
       // residual
       const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
-      for (long long r = rb; r < (resid_lane ? re : rb); ++r)
+      if constexpr (dim == 3 && !PATCH)
+        if (red)
+          {
+            // R' = C^T R: the entries by vertex into LDS, lane i takes resolved node i (the lanes of a cell sit in one wave)
+            if (resid_lane)
+              {
+#pragma unroll
+                for (int c = 0; c < nc; ++c)
+                  s_rr[cl][a][c] = R[c];
+              }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int32_t *rnode = reinterpret_cast<const int32_t *>(rec);
+            for (int i = a + nv * part; i < RN; i += LPC)
+              {
+                const int P = rnode[i];
+                if (P >= v.n_owned || (v.row_patch && v.row_patch[P]))
+                  continue;
+                double acc[nc];
+#pragma unroll
+                for (int c = 0; c < nc; ++c)
+                  acc[c] = 0.0;
+                for (int a2 = 0; a2 < nv; ++a2)
+                  {
+                    const int A2 = v.conn[(long long)a2 * v.n_cells + cell];
+                    const int k2 = v.hn_index[A2];
+                    if (k2 < 0)
+                      {
+                        if (A2 == P)
+#pragma unroll
+                          for (int c = 0; c < nc; ++c)
+                            acc[c] += s_rr[cl][a2][c];
+                      }
+                    else
+                      for (long long r = v.hn_ptr[k2]; r < v.hn_ptr[k2 + 1]; ++r)
+                        if (v.hn_parents[r] == P)
+                          {
+                            const double w = v.hn_weights[r];
+#pragma unroll
+                            for (int c = 0; c < nc; ++c)
+                              acc[c] = fma(w, s_rr[cl][a2][c], acc[c]);
+                          }
+                  }
+                const unsigned fP = v.node_flags[P];
+#pragma unroll
+                for (int c = 0; c < nc; ++c)
+                  {
+                    const long long di = dof_index<dim>(v, P, c);
+                    const bool con = (fP >> c) & 1u;
+                    if (!con)
+                      add_rt(res_pde + di, acc[c]);
+                    if (residual_only && (!con || !total_via_update))
+                      add_rt(res_tot + di, acc[c]);
+                  }
+              }
+          }
+      for (long long r = rb; r < ((resid_lane && !red) ? re : rb); ++r)
         {
           const int P = kA < 0 ? A : v.hn_parents[r];
           const double wP = kA < 0 ? 1.0 : v.hn_weights[r];
@@ -1475,13 +1560,10 @@ namespace pfm
           bool reduced = false;
           if constexpr (KRED)
             {
-              const uint8_t *rec = (v.cres && hc >= 0) ? v.cres + (long long)hc * PFM_CRES_BYTES : nullptr;
-              const int R = rec ? (int)rec[PFM_CRES_R] : 0xff;
-              if (R <= 16)
+              const int R = RN;
+              if (red)
                 {
                   reduced = true;
-                  __shared__ uint8_t s_icnt[CPB][16], s_ia[CPB][16][8];
-                  __shared__ double s_iw[CPB][16][8];
                   const int32_t *rnode = reinterpret_cast<const int32_t *>(rec);
                   double *const Kc = s_q + cl * KCELL; // (the q-loop of this hex is over: its lanes sit in one wave)
                   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1560,16 +1642,16 @@ namespace pfm
 #pragma unroll
                           for (int d = 0; d < 3; ++d)
                             if (!((fQ >> d) & 1u))
-                              add_to<true>(val_ptr<dim>(v, vals, P, c, slot, d), acc[3 * c + d]);
+                              add_rt(val_ptr<dim>(v, vals, P, c, slot, d), acc[3 * c + d]);
                         }
                       if (!((fP >> 3) & 1u))
                         {
 #pragma unroll
                           for (int d = 0; d < 3; ++d)
                             if (!((fQ >> d) & 1u))
-                              add_to<true>(val_ptr<dim>(v, vals, P, 3, slot, d), acc[9 + d]);
+                              add_rt(val_ptr<dim>(v, vals, P, 3, slot, d), acc[9 + d]);
                           if (!((fQ >> 3) & 1u))
-                            add_to<true>(val_ptr<dim>(v, vals, P, 3, slot, 3), acc[12]);
+                            add_rt(val_ptr<dim>(v, vals, P, 3, slot, 3), acc[12]);
                         }
                     }
                 }
@@ -1647,7 +1729,7 @@ namespace pfm
 #pragma unroll
               for (int c = 0; c < nc; ++c)
                 if (kA >= 0 || ((fA >> c) & 1u))
-                  add_to<ATOMIC>(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
+                  add_rt(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
             }
         }
     }

@@ -107,3 +107,30 @@ def test_overlay_rows_follow_a_bound_pattern():
     assert ctx.kernel_path == 3
     check_against_oracle(c, ctx)
     ctx.close()
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+def test_cells_at_hanging_vertices_in_plain_colour_classes_are_bitwise_reproducible(blocked, monkeypatch):
+    """PFM_HANGING_COLOURED=1 (read by pfm_ctx_create): the hexes at hanging vertices are coloured over their
+    constraint-resolved nodes and add without atomics (the element matrix and the residual are reduced to those nodes
+    first).  Same entries as the oracle, with the overlay and through the general family alone, heterogeneous material
+    included -- and two assemblies of the same state agree in every bit, which the class with FP64 atomics cannot promise."""
+    monkeypatch.setenv("PFM_HANGING_COLOURED", "1")
+    c = refined_block_case((12, 10, 12), blocked, het=True)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 3
+    check_against_oracle(c, ctx)
+    for path in (None, 0):
+        if path is not None:
+            ctx.force_path(path)
+            check_against_oracle(c, ctx)
+        first = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+        for rep in range(3):
+            again = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+            for x, y in zip(first[0], again[0]):
+                assert np.array_equal(x, y)
+            assert np.array_equal(first[1], again[1])
+        r1 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+        r2 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
+        assert np.array_equal(r1[1], r2[1]) and np.array_equal(r1[2], r2[2])
+    ctx.close()

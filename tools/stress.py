@@ -4,7 +4,8 @@ leave bit-identical outputs and a stable amount of free device memory; (2) 60 co
 40^3 box must give the memory back.  `python tools/stress.py 64 general`: the same box forced onto the general family.
 `python tools/stress.py 24 hanging`: a 3-D box with a refined block (hanging nodes on its faces and edges): the cells at
 hanging vertices form the ATOMIC class of the general family (FP64 atomic adds, no fixed order) -- 100 assemblies, reports
-whether the outputs are bitwise equal run to run and, if not, the largest deviation relative to the row's largest entry."""
+whether the outputs are bitwise equal run to run and, if not, the largest deviation relative to the row's largest entry.
+`PFM_HANGING_COLOURED=1 python tools/stress.py 24 hanging`: the same with those cells in plain colour classes (bitwise)."""
 import os
 import sys
 
@@ -61,7 +62,8 @@ def main():
                     worst = max(worst, float(((x - y).abs().max() / x.abs().max().clamp_min(1e-300)).item()))
         print(f"general family with hanging nodes ({g.n_cells} cells, {g.hn_nodes.size} hanging nodes, kernel path {a.ctx.kernel_path}): "
               f"100 assemblies, {differing} output arrays differed from the first run, largest deviation {worst:.2e} of the array's "
-              f"largest entry" + (" (bitwise reproducible)" if differing == 0 else " (atomic class: bounded, not bitwise)"))
+              f"largest entry" + (" (bitwise reproducible)" if differing == 0 else " (atomic class: bounded, not bitwise)")
+              + (" [PFM_HANGING_COLOURED=1]" if os.environ.get("PFM_HANGING_COLOURED") else ""))
         assert worst < 1e-13
         return
     a = problem(n)
