@@ -993,7 +993,8 @@ namespace
   struct PatchPlan
   {
     std::vector<uint8_t> regular, hang; // per node: row of the patch kernel; hanging or duplicated position
-    std::vector<int32_t> blk_cells, blk_nodes, rows_general;
+    pfm::raw_vector<int32_t> blk_cells, blk_nodes;
+    std::vector<int32_t> rows_general;
     int64_t n_regular = 0;
     int n_blocks = 0;
   };
@@ -1047,7 +1048,8 @@ namespace
   {
     constexpr uint8_t NONE = 255, ATOMIC = 254;
     pfm::raw_vector<uint8_t> col((size_t)NC);
-    std::vector<uint64_t> used((size_t)N, 0);
+    pfm::raw_vector<uint64_t> used((size_t)N);
+    parallel_for(N, [&](int64_t b, int64_t e) { std::fill(used.begin() + b, used.begin() + e, (uint64_t)0); });
     int n_col = 0;
     for (int64_t cell = 0; cell < NC; ++cell)
       {
@@ -1137,7 +1139,8 @@ namespace
     ring.clear();
     if (!hn_index)
       return false;
-    std::vector<uint8_t> touched((size_t)N, 0), at_hanging((size_t)NC);
+    pfm::raw_vector<uint8_t> touched((size_t)N), at_hanging((size_t)NC);
+    parallel_for(N, [&](int64_t b, int64_t e) { std::fill(touched.begin() + b, touched.begin() + e, (uint8_t)0); });
     std::atomic<bool> any_atomic{false}, any_ring{false};
     parallel_for(NC, [&](int64_t cb, int64_t ce) {
       bool mine = false;
@@ -1524,7 +1527,7 @@ namespace
     pmark("regular nodes");
     // blocks: block (bx, by) of a level owns the lattice nodes [7 bx, 7 bx + 6] x [7 by, 7 by + 6] and holds the cells
     // [7 bx - 1, 7 bx + 6] x [7 by - 1, 7 by + 6]; node (i, j) of the lattice = upper-right vertex of cell (i - 1, j - 1)
-    std::vector<int32_t> blk_cells, blk_nodes;
+    pfm::raw_vector<int32_t> blk_cells, blk_nodes;
     for (int L = 0; L < NL; ++L)
       {
         const Level &lv = levels[L];
@@ -1585,11 +1588,21 @@ namespace
               pn[(size_t)t].insert(pn[(size_t)t].end(), nodes, nodes + 81);
             }
         });
-        for (int t = 0; t < nt; ++t)
-          {
-            blk_cells.insert(blk_cells.end(), pc[(size_t)t].begin(), pc[(size_t)t].end());
-            blk_nodes.insert(blk_nodes.end(), pn[(size_t)t].begin(), pn[(size_t)t].end());
-          }
+        {
+          // the chunks' pieces behind one another, copied by the chunks' threads
+          std::vector<size_t> oc((size_t)nt + 1, blk_cells.size()), on((size_t)nt + 1, blk_nodes.size());
+          for (int t = 0; t < nt; ++t)
+            {
+              oc[(size_t)t + 1] = oc[(size_t)t] + pc[(size_t)t].size();
+              on[(size_t)t + 1] = on[(size_t)t] + pn[(size_t)t].size();
+            }
+          blk_cells.resize(oc[(size_t)nt]);
+          blk_nodes.resize(on[(size_t)nt]);
+          parallel_chunks(nt, [&](int t) {
+            std::copy(pc[(size_t)t].begin(), pc[(size_t)t].end(), blk_cells.begin() + (std::ptrdiff_t)oc[(size_t)t]);
+            std::copy(pn[(size_t)t].begin(), pn[(size_t)t].end(), blk_nodes.begin() + (std::ptrdiff_t)on[(size_t)t]);
+          });
+        }
       }
     const int n_blocks = (int)(blk_cells.size() / 64);
     pmark("blocks");
@@ -1645,7 +1658,8 @@ namespace
     if (pl.n_blocks == 0)
       return;
     std::vector<uint8_t> &regular = pl.regular;
-    std::vector<int32_t> &blk_cells = pl.blk_cells, &blk_nodes = pl.blk_nodes, &rows_general = pl.rows_general;
+    pfm::raw_vector<int32_t> &blk_cells = pl.blk_cells, &blk_nodes = pl.blk_nodes;
+    std::vector<int32_t> &rows_general = pl.rows_general;
     const int n_blocks = pl.n_blocks;
     const int64_t n_regular = pl.n_regular;
     // a regular node has the nine nodes of its 2 x 2 cells in its row and nothing else, by construction; checked against the
@@ -1701,15 +1715,37 @@ namespace
             return;
           }
       }
-    v.patch_cells = dev_upload(c, blk_cells.data(), blk_cells.size());
-    v.patch_nodes = dev_upload(c, blk_nodes.data(), blk_nodes.size());
-    c->d_node_slots = dev_alloc<unsigned long long>(c, (size_t)std::max<int32_t>(NO, 1));
-    v.node_slots = c->d_node_slots;
-    c->d_color_cells_reduced = dev_upload(c, order_red.data(), order_red.size());
     c->n_rows_general = (int32_t)rows_general.size();
     if (rows_general.empty())
       rows_general.push_back(0);
-    c->d_rows_general = dev_upload(c, rows_general.data(), rows_general.size());
+    {
+      // the overlay's tables in ONE device allocation (a hipMalloc costs 0.05-0.1 ms; the build made five of them here)
+      auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+      const size_t b_cells = al(sizeof(int32_t) * blk_cells.size()), b_nodes = al(sizeof(int32_t) * blk_nodes.size());
+      const size_t b_slots = al(sizeof(unsigned long long) * (size_t)std::max<int32_t>(NO, 1));
+      const size_t b_order = al(sizeof(int32_t) * order_red.size()), b_rows = al(sizeof(int32_t) * rows_general.size());
+      char *slab = dev_alloc<char>(c, b_cells + b_nodes + b_slots + b_order + b_rows);
+      auto put = [&](char *d, const void *h, size_t bytes) {
+        const hipError_t e = h2d(d, h, bytes);
+        if (e != hipSuccess)
+          throw HipFail{e, "hipMemcpy H2D"};
+      };
+      char *at = slab;
+      put(at, blk_cells.data(), sizeof(int32_t) * blk_cells.size());
+      v.patch_cells = reinterpret_cast<const int32_t *>(at);
+      at += b_cells;
+      put(at, blk_nodes.data(), sizeof(int32_t) * blk_nodes.size());
+      v.patch_nodes = reinterpret_cast<const int32_t *>(at);
+      at += b_nodes;
+      c->d_node_slots = reinterpret_cast<unsigned long long *>(at);
+      v.node_slots = c->d_node_slots;
+      at += b_slots;
+      put(at, order_red.data(), sizeof(int32_t) * order_red.size());
+      c->d_color_cells_reduced = reinterpret_cast<int32_t *>(at);
+      at += b_order;
+      put(at, rows_general.data(), sizeof(int32_t) * rows_general.size());
+      c->d_rows_general = reinterpret_cast<int32_t *>(at);
+    }
     c->n_patch_blocks = n_blocks;
     c->n_patch_rows = n_regular;
     c->patch_slots_valid = false;
