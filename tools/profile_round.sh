@@ -140,3 +140,13 @@ for f in ('bench_216cube','bench_216cube_residual_only','bench_2d_1000sq_residua
         d=json.load(open('$O/'+f+'.json')); r=d['roofline']; print(f, 'ms/step %.3f kernel_ms %.3f median %.3f frac %.4f value %.3e ctx_create %s' % (d['ms_per_step'], r['kernel_ms'], r['kernel_ms_median'], r['frac'], d['value'], d['config'].get('ctx_create_s')))
     except Exception as e: print(f, 'FAILED', e)
 "
+# round 5: robustness runs, context phase clocks, the bitwise mode of the 3-D hanging-node cells
+cd $R
+python tools/stress.py 216 > $O/stress_216.txt 2>&1
+python tools/stress.py 64 general > $O/stress_64_general.txt 2>&1
+python tools/stress.py 24 hanging > $O/stress_24_hanging.txt 2>&1
+PFM_HANGING_COLOURED=1 python tools/stress.py 24 hanging > $O/stress_24_hanging_coloured.txt 2>&1
+PFM_CTX_TIMING=1 python tools/ctx_timing.py c5 > $O/ctx_timing_config5.txt 2>&1
+PFM_CTX_TIMING=1 python tools/ctx_timing.py 216 > $O/ctx_timing_216cube.txt 2>&1
+PFM_HANGING_COLOURED=1 python -c "import json, torch, bench; print(json.dumps(bench.overlay_3d(torch.device('cuda:0'), 0, 8)))" > $O/overlay3d_hanging_coloured.json 2>/dev/null
+for w in 2 8; do python tools/bench_extra.py rank --world $w --out $O/rank_share_w$w.json > /dev/null 2>&1; done
