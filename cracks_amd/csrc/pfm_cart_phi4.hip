@@ -45,6 +45,10 @@ namespace pfm
     constexpr int NPN = PN * PN, NPH = PH * PH;     // 49 owned nodes, 81 halo nodes per plane
     constexpr int NT4 = 4 * PT * PT;                // 4 roles x 64 cells
     constexpr int SLAB_PU = NPN * 27, SLAB_PP = NPN * 9;
+#ifndef PFM_PHI_ONEPUSH
+#define PFM_PHI_ONEPUSH 1
+#endif
+    constexpr bool ONEPUSH = PFM_PHI_ONEPUSH != 0; // (phi,u) roles: one LDS add per entry and cell (pu_role_poly)
 
 
     template <int NF /* 6 with the old phase fields (penalisation term: gamma != 0), else 4 */>
@@ -134,6 +138,22 @@ namespace pfm
           Dy[0] = (nz0 * (a01 - a00) + nz1 * (b01 - b00)) * ihy;
           Dy[1] = (nz0 * (a11 - a10) + nz1 * (b11 - b10)) * ihy;
         }
+    }
+
+    // (NA ? -a : a) + (NB ? -b : b) as one v_add_f64 that stays where it is written
+    template <bool NA, bool NB>
+    __device__ __forceinline__ double add_signed(double a, double b)
+    {
+      double r;
+      if constexpr (NA && NB)
+        asm volatile("v_add_f64 %0, -%1, -%2" : "=v"(r) : "v"(a), "v"(b));
+      else if constexpr (NA)
+        asm volatile("v_add_f64 %0, -%1, %2" : "=v"(r) : "v"(a), "v"(b));
+      else if constexpr (NB)
+        asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+      else
+        asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+      return r;
     }
 
     static_assert(sizeof(Lds4<4>) <= 64 * 1280, "two workgroups per CU: 64 allocation granules of LDS each");
@@ -556,7 +576,7 @@ namespace pfm
     }
     constexpr int ipow3(int a) { return a == 0 ? 1 : (a == 1 ? 3 : 9); }
 
-    template <int D, bool HET>
+    template <int D, bool HET, bool ONEPUSH>
     __device__ __forceinline__ void pu_role_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
                                                  double cell_muh, double cell_la, bool cell_ok, const PushDst &dst, int nl0, int cx, int cy)
     {
@@ -570,19 +590,49 @@ namespace pfm
       });
       if (cell_ok)
         {
-          double F[4][8]; // u_x u_y u_z phi
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
+          double F0[4][8]; // u_x u_y u_z phi
+          if constexpr (!ONEPUSH)
             {
-              load_cell_field_raw(Ulo + f * NPH, Uhi + f * NPH, F[f]);
-              monomials(F[f]);
-            }
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            F[3][i] *= S.vol; // JxW = vol w w w, and the weights are inside the constants s_j[W]
+              for (int f = 0; f < 4; ++f)
+                {
+                  load_cell_field_raw(Ulo + f * NPH, Uhi + f * NPH, F0[f]);
+                  monomials(F0[f]);
+                }
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                F0[3][i] *= S.vol; // JxW = vol w w w, and the weights are inside the constants s_j[W]
+            }
+          // ONEPUSH (round 6): the three k-parts of an entry are added in registers and pushed ONCE -- 64 instead of 192
+          // LDS adds per cell and role (the LDS pipe of a CU, shared by two workgroups, was the busiest unit of this kernel:
+          // 640 ds_add_f64 per workgroup and step).  The 3 x 18 numbers stay live (no negated copies: the sign is an
+          // operand modifier of the add); k = D first, the only part that needs all three displacement fields.
+          double Call[ONEPUSH ? 3 : 1][18];
           static_for<3>([&](auto Kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(Kc)::value;
+            constexpr int kseq = decltype(Kc)::value;
+            constexpr int k = !ONEPUSH ? kseq : (kseq == 0 ? D : (kseq == 1 ? (D == 0 ? 1 : 0) : (D == 2 ? 1 : 2)));
             constexpr int a1 = k == 0 ? 1 : 0, a2 = k == 2 ? 1 : 2; // the other axes, ascending
+            // ONEPUSH: the fields a part needs are read from the nodal ring again (volatile reads: not merged with the last
+            // part's), so that at most three of the four fields' coefficients are live next to the finished parts
+            double Fk[4][8];
+            if constexpr (ONEPUSH)
+              static_for<4>([&](auto Fc) __attribute__((always_inline)) {
+                constexpr int f = decltype(Fc)::value;
+                if constexpr (k == D || f == D || f == k || f == 3)
+                  {
+                    const double *lo = Ulo + f * NPH, *hi = Uhi + f * NPH;
+                    Fk[f][0] = lds_read64(lo), Fk[f][1] = lds_read64(lo + 1), Fk[f][2] = lds_read64(lo + PH), Fk[f][3] = lds_read64(lo + PH + 1);
+                    Fk[f][4] = lds_read64(hi), Fk[f][5] = lds_read64(hi + 1), Fk[f][6] = lds_read64(hi + PH), Fk[f][7] = lds_read64(hi + PH + 1);
+                    monomials(Fk[f]);
+                    if constexpr (f == 3)
+                      {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                          Fk[3][i] *= S.vol;
+                      }
+                  }
+              });
+            double(&F)[4][8] = ONEPUSH ? Fk : F0;
             const double ihk = S.ih[k];
             const double sDk = c_muh * ihk * ihk, skD = c_muh * S.ih[D] * ihk;
             const double sl[3] = {c_la * S.ih[0] * ihk, c_la * S.ih[1] * ihk, c_la * S.ih[2] * ihk};
@@ -619,36 +669,73 @@ namespace pfm
                   A[idx] = acc;
                 }
             });
-            double c[27];
-            static_for<8>([&](auto Ia) __attribute__((always_inline)) {
-              constexpr int ia = decltype(Ia)::value;
-              if constexpr (a_nz(D, k, ia))
-                static_for<8>([&](auto Ip) __attribute__((always_inline)) {
-                  constexpr int ip = decltype(Ip)::value;
-                  constexpr int pw = pow_of(ia, ip);
-                  if constexpr (pair_first(D, k, ia, ip))
-                    c[pw] = A[ia] * F[3][ip];
-                  else
-                    c[pw] = fma(A[ia], F[3][ip], c[pw]);
-                });
-            });
-            static_for<27>([&](auto Pw) __attribute__((always_inline)) {
-              if constexpr (!pow_any(D, k, decltype(Pw)::value))
-                c[decltype(Pw)::value] = 0.0;
-            });
             // contraction: the special axis k first (2 weights n_al), then a1, a2 (3 weights m_g each)
             double R1[2][3][3], R2[2][3][3];
-            static_for<2>([&](auto Wc) __attribute__((always_inline)) {
-              constexpr int w = decltype(Wc)::value;
+            if constexpr (!ONEPUSH)
+              {
+                double c[27];
+                static_for<8>([&](auto Ia) __attribute__((always_inline)) {
+                  constexpr int ia = decltype(Ia)::value;
+                  if constexpr (a_nz(D, k, ia))
+                    static_for<8>([&](auto Ip) __attribute__((always_inline)) {
+                      constexpr int ip = decltype(Ip)::value;
+                      constexpr int pw = pow_of(ia, ip);
+                      if constexpr (pair_first(D, k, ia, ip))
+                        c[pw] = A[ia] * F[3][ip];
+                      else
+                        c[pw] = fma(A[ia], F[3][ip], c[pw]);
+                    });
+                });
+                static_for<27>([&](auto Pw) __attribute__((always_inline)) {
+                  if constexpr (!pow_any(D, k, decltype(Pw)::value))
+                    c[decltype(Pw)::value] = 0.0;
+                });
+                static_for<2>([&](auto Wc) __attribute__((always_inline)) {
+                  constexpr int w = decltype(Wc)::value;
 #pragma unroll
-              for (int j = 0; j < 3; ++j)
+                  for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int l = 0; l < 3; ++l)
-                  {
-                    const int b = j * ipow3(a1) + l * ipow3(a2);
-                    R1[w][j][l] = c[b] * G1Sx<0, w>::v + c[b + ipow3(k)] * G1Sx<1, w>::v + c[b + 2 * ipow3(k)] * G1Sx<2, w>::v;
-                  }
-            });
+                    for (int l = 0; l < 3; ++l)
+                      {
+                        const int b = j * ipow3(a1) + l * ipow3(a2);
+                        R1[w][j][l] = c[b] * G1Sx<0, w>::v + c[b + ipow3(k)] * G1Sx<1, w>::v + c[b + 2 * ipow3(k)] * G1Sx<2, w>::v;
+                      }
+                });
+              }
+            else
+              {
+                // the 27 coefficients of the product polynomial are formed three at a time (the powers 0, 1, 2 of t_k at fixed
+                // powers of the other two variables) and contracted along k at once: 3 instead of 27 of them are live
+                static_for<9>([&](auto JL) __attribute__((always_inline)) {
+                  constexpr int j = decltype(JL)::value % 3, l = decltype(JL)::value / 3;
+                  double c3[3] = {0.0, 0.0, 0.0};
+                  static_for<3>([&](auto Pk) __attribute__((always_inline)) {
+                    constexpr int pk = decltype(Pk)::value;
+                    constexpr int pw = j * ipow3(a1) + l * ipow3(a2) + pk * ipow3(k);
+                    if constexpr (pow_any(D, k, pw))
+                      {
+                        bool any = false;
+                        static_for<8>([&](auto Ia) __attribute__((always_inline)) {
+                          constexpr int ia = decltype(Ia)::value;
+                          if constexpr (a_nz(D, k, ia))
+                            static_for<8>([&](auto Ip) __attribute__((always_inline)) {
+                              constexpr int ip = decltype(Ip)::value;
+                              if constexpr (pow_of(ia, ip) == pw)
+                                {
+                                  c3[pk] = any ? fma(A[ia], F[3][ip], c3[pk]) : A[ia] * F[3][ip];
+                                  any = true;
+                                }
+                            });
+                        });
+                      }
+                  });
+                  R1[0][j][l] = c3[0] * G1Sx<0, 0>::v + c3[1] * G1Sx<1, 0>::v + c3[2] * G1Sx<2, 0>::v;
+                  R1[1][j][l] = c3[0] * G1Sx<0, 1>::v + c3[1] * G1Sx<1, 1>::v + c3[2] * G1Sx<2, 1>::v;
+                  if constexpr (l == 0 || l == 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                __builtin_amdgcn_sched_barrier(0); // the fields are dead from here on
+              }
             static_for<3>([&](auto Gc) __attribute__((always_inline)) {
               constexpr int g = decltype(Gc)::value;
 #pragma unroll
@@ -668,12 +755,24 @@ namespace pfm
                 for (int g1 = 0; g1 < 3; ++g1)
                   {
                     const double x = R2[w][g1][0] * G1Sx<0, 2 + g2>::v + R2[w][g1][1] * G1Sx<1, 2 + g2>::v + R2[w][g1][2] * G1Sx<2, 2 + g2>::v;
-                    Cp[w + 2 * (g1 + 3 * g2)] = x;
-                    Cn[w + 2 * (g1 + 3 * g2)] = -x;
+                    if constexpr (ONEPUSH)
+                      {
+                        double xv = x;
+                        asm volatile("" : "+v"(xv)); // finished HERE: not sunk (with its three operands) into the vertex blocks
+                        Call[ONEPUSH ? k : 0][w + 2 * (g1 + 3 * g2)] = xv;
+                      }
+                    else
+                      {
+                        Cp[w + 2 * (g1 + 3 * g2)] = x;
+                        Cn[w + 2 * (g1 + 3 * g2)] = -x;
+                      }
                   }
             });
             // the k-part of the cell's entries, vertex by vertex in the order of a lexicographic cell loop (three adds per
             // entry and cell, k = 0, 1, 2: a fixed order)
+            if constexpr (ONEPUSH)
+              __builtin_amdgcn_sched_barrier(0); // the parts one after the other: their temporaries must not overlap
+            if constexpr (!ONEPUSH)
             static_for<8>([&](auto A) __attribute__((always_inline)) {
               constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
               if (vok[decltype(A)::value])
@@ -687,11 +786,40 @@ namespace pfm
                     constexpr int ci = k == 0 ? ax + 2 * (gy + 3 * gz) : (k == 1 ? ay + 2 * (gx + 3 * gz) : az + 2 * (gx + 3 * gy));
                     constexpr int bk = k == 0 ? bx : (k == 1 ? by : bz);
                     double *slab = (az == 0) ? (oz == 0 ? dst.lo_z0 : dst.lo_p1) : (oz == -1 ? dst.hi_m1 : dst.hi_z0);
-                    lds_add(&slab[nb + o9 * 3], bk ? Cp[ci] : Cn[ci]);
+#ifdef PFM_PHI_ABLATE_PUSH // measurement only (wrong values): two of the three parts are computed but not pushed
+                    const double pushed = bk ? Cp[ci] : Cn[ci];
+                    if constexpr (k != 0)
+                      asm volatile("" ::"v"(pushed));
+                    else
+#else
+                    const double pushed = bk ? Cp[ci] : Cn[ci];
+#endif
+                    lds_add(&slab[nb + o9 * 3], pushed);
                   });
                 }
             });
           });
+          if constexpr (ONEPUSH)
+            static_for<8>([&](auto A) __attribute__((always_inline)) {
+              constexpr int ax = 1 - (decltype(A)::value & 1), ay = 1 - ((decltype(A)::value >> 1) & 1), az = decltype(A)::value >> 2;
+              if (vok[decltype(A)::value])
+                {
+                  const int nb = (nl0 + ax + PN * ay) * 27 + D;
+                  static_for<8>([&](auto B) __attribute__((always_inline)) {
+                    constexpr int bx = decltype(B)::value & 1, by = (decltype(B)::value >> 1) & 1, bz = decltype(B)::value >> 2;
+                    constexpr int ox = bx - ax, oy = by - ay, oz = bz - az;
+                    constexpr int gx = ax + bx, gy = ay + by, gz = az + bz;
+                    constexpr int o9 = (ox + 1) + 3 * (oy + 1);
+                    const double c0 = Call[0][ax + 2 * (gy + 3 * gz)], c1 = Call[ONEPUSH ? 1 : 0][ay + 2 * (gx + 3 * gz)],
+                                 c2 = Call[ONEPUSH ? 2 : 0][az + 2 * (gx + 3 * gy)];
+                    // fixed order: x, y, z part.  The adds are opaque to the compiler: as plain expressions the partial sums shared
+                    // between vertex blocks are hoisted in front of the first block, all 64 entries at once (128 registers)
+                    const double e = add_signed<!bz, false>(c2, add_signed<!bx, !by>(c0, c1));
+                    double *slab = (az == 0) ? (oz == 0 ? dst.lo_z0 : dst.lo_p1) : (oz == -1 ? dst.hi_m1 : dst.hi_z0);
+                    lds_add(&slab[nb + o9 * 3], e);
+                  });
+                }
+            });
         }
     }
 
@@ -807,8 +935,12 @@ namespace pfm
             for (int gx = 0; gx < 3; ++gx)
 #pragma unroll
               for (int gy = 0; gy < 3; ++gy)
-                M[gx + 3 * gy + 9 * g] = (R2[gx][gy][0] * G1Sx<0, 2 + g>::v + R2[gx][gy][1] * G1Sx<1, 2 + g>::v + R2[gx][gy][2] * G1Sx<2, 2 + g>::v) +
-                                         S.lapM[gx + 3 * gy + 9 * g];
+                {
+                  double mv = (R2[gx][gy][0] * G1Sx<0, 2 + g>::v + R2[gx][gy][1] * G1Sx<1, 2 + g>::v + R2[gx][gy][2] * G1Sx<2, 2 + g>::v) +
+                              S.lapM[gx + 3 * gy + 9 * g];
+                  asm volatile("" : "+v"(mv)); // finished here (pu_role_poly: not sunk into the vertex blocks with its operands)
+                  M[gx + 3 * gy + 9 * g] = mv;
+                }
           });
         }
       static_for<8>([&](auto A) __attribute__((always_inline)) {
@@ -850,6 +982,8 @@ namespace pfm
       // of the co-resident workgroup's arithmetic they finish sooner and cost it nothing measurable; -0.2 ms at 216^3).
       // PFM_NO_PRIO=1 switches them off (A/B runs): the launcher then passes the chunk length negated
       const bool PRIO = zc_in > 0;
+      // nullptr: the structurally zero (u,phi) block is cleared by a fill next to this launch (pfm_host.cpp, PFM_UP_FILL)
+      const bool zero_up = __builtin_amdgcn_readfirstlane(vals_up != nullptr);
       const int zc = zc_in < 0 ? -zc_in : zc_in;
       const MatScal &S = *Sp; // per-launch scalars live in device memory: loaded where used, not pinned in SGPRs
       long long tclk = 0;
@@ -1014,6 +1148,8 @@ namespace pfm
           // wait for its own stores to drain, they have the whole next role phase for that
           if (nst >= 28)
             asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+          else if (nst >= 14) // (the zeros of the (u,phi) block come from a fill on another stream: 2 unconditional stores per y-line)
+            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
           else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           nst = 0;
@@ -1055,7 +1191,7 @@ namespace pfm
             if constexpr (OLDF)
               pu_role<d, HET, true>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
             else
-              pu_role_poly<d, HET>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
+              pu_role_poly<d, HET, ONEPUSH>(Ulo, Uhi, S, c_muh, c_la, cell_ok, dst, nl0, cx, cy);
           };
           if (role == 0)
             pu(std::integral_constant<int, 0>{});
@@ -1304,15 +1440,18 @@ namespace pfm
                     {
                       double *bpu = vals_pu + 3 * off0[ny], *bup = vals_up + 3 * off0[ny], *bpp = vals_pp + off0[ny];
                       bpu[uq] = val[ny][0];
-                      bup[uq] = 0.0;
+                      if (zero_up)
+                        bup[uq] = 0.0;
                       bpu[uq + NT4] = val[ny][1];
-                      bup[uq + NT4] = 0.0;
+                      if (zero_up)
+                        bup[uq + NT4] = 0.0;
                       spu[0][ny * (PN * 27)] = 0.0; // these slabs are the next planes' accumulators
                       spu[1][ny * (PN * 27)] = 0.0;
                       if (act2)
                         {
                           bpu[uq + 2 * NT4] = val[ny][2];
-                          bup[uq + 2 * NT4] = 0.0;
+                          if (zero_up)
+                            bup[uq + 2 * NT4] = 0.0;
                           spu[2][ny * (PN * 27)] = 0.0;
                         }
                       if (actp)
@@ -1321,7 +1460,7 @@ namespace pfm
                           spp[ny * (PN * 9)] = 0.0;
                         }
                     }
-                  nst = 4 * PN;
+                  nst = zero_up ? 4 * PN : 2 * PN;
                 }
               else if (t < 2 * 108)
                 {
@@ -1404,7 +1543,8 @@ namespace pfm
                                   else
                                     {
                                       vals_pu[3 * off + sl * 3 + fe_d] = val;
-                                      vals_up[3 * off + sl * 3 + fe_d] = 0.0; // any bijection onto the node's 3 rows
+                                      if (zero_up)
+                                        vals_up[3 * off + sl * 3 + fe_d] = 0.0; // any bijection onto the node's 3 rows
                                     }
                                 }
                               else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
@@ -1491,7 +1631,7 @@ namespace pfm
   const bool oldf = Sh.gamma_fac != 0.0 || Sh.monolithic;
 #define PFM_PHI4_(NC, HETV, RESV, OLDV)                                                                                           \
   hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV, OLDV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),      \
-                     (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 ? d_values[1] : nullptr), zc, nullptr, res_pde)
+                     (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 && !cv.up_by_fill ? d_values[1] : nullptr), zc, nullptr, res_pde)
 #define PFM_PHI4(NC, HETV, RESV)                                                                                                  \
   do                                                                                                                              \
     {                                                                                                                             \
@@ -1515,18 +1655,22 @@ namespace pfm
       }
     else if (het)
       PFM_PHI4(3, true, false); // heterogeneous material: the residual kernel runs
-    else if (res)
-      PFM_PHI4(3, false, true);
-    else if (getenv("PFM_PHI_CLK")) // profiling only
+    else if (getenv("PFM_PHI_CLK") && !oldf) // profiling only
       {
         static unsigned long long *d_dbg = nullptr;
         const size_t nd = (size_t)xcd_grid(nb) * 16;
         if (!d_dbg && hipMalloc((void **)&d_dbg, nd * sizeof(unsigned long long)) != hipSuccess)
           return PFM_ERR_HIP;
         (void)hipMemsetAsync(d_dbg, 0, nd * sizeof(unsigned long long), s);
-        if (atoi(getenv("PFM_PHI_CLK")) == 2)
+        if (atoi(getenv("PFM_PHI_CLK")) == 2 && res)
+          hipLaunchKernelGGL((k_cart_phi4<3, 2, false, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+                             d_values[0], d_values[1], zc, d_dbg, res_pde);
+        else if (atoi(getenv("PFM_PHI_CLK")) == 2)
           hipLaunchKernelGGL((k_cart_phi4<3, 2>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], d_values[1], zc, d_dbg, nullptr);
+        else if (res)
+          hipLaunchKernelGGL((k_cart_phi4<3, 1, false, true>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
+                             d_values[0], d_values[1], zc, d_dbg, res_pde);
         else
           hipLaunchKernelGGL((k_cart_phi4<3, 1>), dim3(xcd_grid(nb)), dim3(NT4), 0, s, v, cv, S, d_values[2], d_values[3],
                              d_values[0], d_values[1], zc, d_dbg, nullptr);
@@ -1544,6 +1688,8 @@ namespace pfm
         fprintf(stderr, " request-next=%.0f copy-loop=%.0f copy-barrier=%.0f", (double)h[10] / nb, (double)h[8] / nb, (double)h[9] / nb);
         fprintf(stderr, "\n");
       }
+    else if (res)
+      PFM_PHI4(3, false, true);
     else
       PFM_PHI4(3, false, false);
 #undef PFM_PHI4

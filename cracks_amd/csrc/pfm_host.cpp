@@ -2641,6 +2641,10 @@ extern "C"
                     (void *)c->cv.patch_count})
       if (q)
         (void)hipFree(q);
+    if (c->fill_stream)
+      (void)hipStreamDestroy(c->fill_stream);
+    if (c->ev_fill)
+      (void)hipEventDestroy(c->ev_fill);
     if (c->atomic_stream)
       (void)hipStreamDestroy(c->atomic_stream);
     if (c->ev_atomic)
@@ -3661,7 +3665,13 @@ extern "C"
       {
         if (!c->side_stream)
           {
-            if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+            // PFM_SIDE_PRIO (A/B runs): -1 = lowest, 1 = highest dispatch priority for the stream of the phase-field kernel
+            static const int side_prio = getenv("PFM_SIDE_PRIO") ? atoi(getenv("PFM_SIDE_PRIO")) : 0;
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            const hipError_t es = side_prio == 0 ? hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)
+                                                 : hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, side_prio > 0 ? prio_hi : prio_lo);
+            if (es != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
               return fail(c, PFM_ERR_HIP, "side stream");
@@ -3729,6 +3739,28 @@ extern "C"
         c->scal_dirty = false;
       }
     pfm::CartView cv_launch = c->cv;
+    // Blocked layout, Jacobian pair: the structurally zero (u,phi) block (cracks.cc:2333-2337: sigma_LinU = 0 for a
+    // phase-field trial function; 81 doubles per node, 6.6 GB at 216^3) is cleared by a plain fill on a third stream instead
+    // of by 21 of the 49 store instructions of every copy-out of k_cart_phi4: the fill's workgroups need no LDS and sit in the
+    // wave slots the two LDS-bound kernels leave free.  Measured at 216^3 (profiles/r06/ab_up_fill.txt): 10.95 -> 11.35 ms per
+    // assembly -- the fill takes memory bandwidth in a burst and dispatch slots from the pair, the copy-out it shortens was not
+    // what the phase-field kernel waits for.  OFF by default (PFM_UP_FILL=1: A/B runs); the kernel writes the zeros itself.
+    static const bool up_fill_on = getenv("PFM_UP_FILL") && atoi(getenv("PFM_UP_FILL")) != 0;
+    const bool up_fill = pair && fork && up_fill_on && c->n_blocks == 4 && d_values[1] && c->block_nnz(1) > 0;
+    if (up_fill)
+      {
+        if (!c->fill_stream && (hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking) != hipSuccess ||
+                                hipEventCreateWithFlags(&c->ev_fill, hipEventDisableTiming) != hipSuccess))
+          return fail(c, PFM_ERR_HIP, "fill stream");
+        e = hipStreamWaitEvent(c->fill_stream, c->ev_fork, 0);
+        if (e == hipSuccess)
+          e = hipMemsetAsync(d_values[1], 0, sizeof(double) * (size_t)c->block_nnz(1), c->fill_stream);
+        if (e == hipSuccess)
+          e = hipEventRecord(c->ev_fill, c->fill_stream);
+        if (e != hipSuccess)
+          return hipfail(c, e, "fill of the (u,phi) block");
+        cv_launch.up_by_fill = 1;
+      }
     if (!pair)
       cv_launch.patch_idx = nullptr, cv_launch.patch_val = nullptr, cv_launch.patch_count = nullptr, cv_launch.patch_cap = 0;
     int rc;
@@ -3841,6 +3873,8 @@ extern "C"
         e = hipEventRecord(c->ev_join, s_res);
         if (e == hipSuccess)
           e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+        if (e == hipSuccess && up_fill)
+          e = hipStreamWaitEvent(c->stream, c->ev_fill, 0);
         if (e != hipSuccess)
           return hipfail(c, e, "join");
       }

@@ -10,6 +10,7 @@
 #include "pfm_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -341,6 +342,74 @@ namespace pfm
         out[threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
     }
 
+
+    // ---- norms of a residual vector with the constrained lines zeroed (constraints_update.set_zero, cracks.cc:2791-2794,
+    // 2947-2949): thread <-> owned node, grid-stride over a grid that depends on n_owned only; fixed-order reductions
+    constexpr int NORM_BLOCKS_MAX = 2048;
+    template <int dim>
+    __global__ __launch_bounds__(256) void k_residual_norms(DevView v, const double *__restrict__ res, double *__restrict__ partial /* [gridDim.x][2] */)
+    {
+      double sq = 0.0, mx = 0.0;
+      for (long long P = (long long)blockIdx.x * 256 + threadIdx.x; P < v.n_owned; P += (long long)gridDim.x * 256)
+        {
+          const unsigned f = v.node_flags[P];
+          const bool hanging = v.hn_index && v.hn_index[P] >= 0;
+#pragma unroll
+          for (int c = 0; c <= dim; ++c)
+            {
+              const double r = (hanging || ((f >> c) & 1u)) ? 0.0 : res[dof_of<dim>(v, (int)P, c)];
+              sq = fma(r, r, sq);
+              mx = fmax(mx, fabs(r));
+            }
+        }
+      __shared__ double s_red[4][2];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+        {
+          sq += __shfl_xor(sq, off);
+          mx = fmax(mx, __shfl_xor(mx, off));
+        }
+      if ((threadIdx.x & 63) == 0)
+        {
+          s_red[threadIdx.x >> 6][0] = sq;
+          s_red[threadIdx.x >> 6][1] = mx;
+        }
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          partial[2 * (long long)blockIdx.x] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+          partial[2 * (long long)blockIdx.x + 1] = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
+        }
+    }
+    __global__ __launch_bounds__(256) void k_reduce_norms(const double *__restrict__ partial, int n, double *__restrict__ out)
+    {
+      __shared__ double s_red[4][2];
+      double sq = 0.0, mx = 0.0;
+      for (int i = threadIdx.x; i < n; i += 256)
+        {
+          sq += partial[2 * i];
+          mx = fmax(mx, partial[2 * i + 1]);
+        }
+      for (int off = 32; off >= 1; off >>= 1)
+        {
+          sq += __shfl_xor(sq, off);
+          mx = fmax(mx, __shfl_xor(mx, off));
+        }
+      if ((threadIdx.x & 63) == 0)
+        {
+          s_red[threadIdx.x >> 6][0] = sq;
+          s_red[threadIdx.x >> 6][1] = mx;
+        }
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          const double s2 = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+          out[0] = sqrt(s2);
+          out[1] = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
+          out[2] = s2;
+        }
+    }
+
     int fail(pfm_ctx *c, int code, const std::string &msg)
     {
       if (c)
@@ -430,6 +499,37 @@ extern "C"
     if (hipMemcpyAsync(node_flags, c->v.node_flags, (size_t)c->v.n_nodes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess)
       return fail(c, PFM_ERR_HIP, "get_constraints");
+    return PFM_OK;
+  }
+
+
+  int pfm_residual_norms(pfm_ctx *c, const double *d_residual, double *out)
+  {
+    if (!c || !out || (!d_residual && c->v.n_owned > 0))
+      return PFM_ERR_BAD_ARG;
+    (void)hipSetDevice(c->device);
+    const long long nbl = ((long long)c->v.n_owned + 255) / 256;
+    const unsigned nb = (unsigned)std::min<long long>(nbl, NORM_BLOCKS_MAX);
+    if (!c->d_norm_partial)
+      {
+        if (hipMalloc((void **)&c->d_norm_partial, sizeof(double) * (2 * (size_t)NORM_BLOCKS_MAX + 4)) != hipSuccess)
+          return fail(c, PFM_ERR_NOMEM, "hipMalloc norm partial sums");
+        c->allocs.push_back(c->d_norm_partial);
+      }
+    double *d_out = c->d_norm_partial + 2 * (size_t)NORM_BLOCKS_MAX;
+    if (nb)
+      {
+        if (c->v.dim == 2)
+          hipLaunchKernelGGL(k_residual_norms<2>, dim3(nb), dim3(256), 0, c->stream, c->v, d_residual, c->d_norm_partial);
+        else
+          hipLaunchKernelGGL(k_residual_norms<3>, dim3(nb), dim3(256), 0, c->stream, c->v, d_residual, c->d_norm_partial);
+      }
+    hipLaunchKernelGGL(k_reduce_norms, dim3(1), dim3(256), 0, c->stream, c->d_norm_partial, (int)nb, d_out);
+    if (hipGetLastError() != hipSuccess)
+      return fail(c, PFM_ERR_HIP, "k_residual_norms launch");
+    if (hipMemcpyAsync(out, d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+      return fail(c, PFM_ERR_HIP, "residual norms copy");
     return PFM_OK;
   }
 

@@ -7,6 +7,8 @@
  *   assemble_diag_mass_matrix()                       cracks.cc:2514-2562   -> pfm_diag_mass_device
  *   active-set block of newton_active_set()           cracks.cc:2826-2909   -> pfm_active_set_device
  *   compute_energy(), compute_tcv()                   cracks.cc:3615-3701, 3553-3611 -> pfm_functionals
+ *   constraints_update.set_zero(residual); residual.l2_norm() / linfty_norm()
+ *                                                     cracks.cc:2791-2794, 2918-2919, 2947-2949 -> pfm_residual_norms
  */
 #ifndef PFM_NEWTON_H
 #define PFM_NEWTON_H
@@ -40,6 +42,19 @@ int pfm_diag_mass_device(pfm_ctx *ctx, double *d_mass);
 int pfm_active_set_device(pfm_ctx *ctx, const double *d_residual_total, const double *d_mass, double c,
                           double *d_solution, const double *d_old_solution, int32_t *d_cycle_counter,
                           int64_t counts[3]);
+
+/* What the line search reads after every assemble_nl_residual() (cracks.cc:2946-2949; 10-50 times per Newton step) and the
+ * Newton loop after every assembly (cracks.cc:2791-2794, 2918-2919): the norms of a residual vector with the constrained
+ * lines zeroed -- constraints_update.set_zero(system_pde_residual); system_pde_residual.l2_norm() -- without the vector
+ * ever leaving the device (24 bytes instead of 2 x 327 MB at 216^3).
+ *   d_residual: device vector over the owned dofs in the context's layout (residual_pde of pfm_assemble_device /
+ *   pfm_assemble_nl_residual_device, or residual_total); zeroed lines = the flag bits last given to pfm_set_constraints
+ *   (Dirichlet lines, active set) and every component of a hanging node.
+ *   out[0] = l2 norm, out[1] = l-infinity norm, out[2] = sum of squares -- of THIS rank's owned dofs; a partitioned caller
+ *   adds out[2] over the ranks and takes the root (Utilities::MPI::sum inside l2_norm), and the maximum of out[1].
+ * Deterministic two-stage reduction (the grid depends on n_owned only); ordered behind the assembly on the context's
+ * stream; synchronous, out is a host pointer. */
+int pfm_residual_norms(pfm_ctx *ctx, const double *d_residual, double out[3]);
 
 /* read back the flag byte of every local node (bit c: dof (node,c) has a homogeneous constraint line) */
 int pfm_get_constraints(pfm_ctx *ctx, uint8_t *node_flags);
