@@ -312,6 +312,21 @@ def extra_lines(asm3, dev, local_rank, n3: int, steps: int):
     n_nodes3 = (n3 + 1) ** 3
     wall, k_ms = time_mode(asm3, dev, True, steps, 2)
     record("residual_only_3d", 3, n3, True, wall, k_ms, n3 ** 3, 4 * n_nodes3)
+    # what the line search actually consumes (cracks.cc:2946-2949): ||set_zero(residual)||_2.  pfm_residual_norms leaves the
+    # vector on the device and returns 24 bytes; the call is synchronous like the reference's l2_norm()
+    asm3.assemble_nl_residual(solution_only=True)
+    nrm = asm3.residual_norm()
+    torch_sync = __import__("torch").cuda.synchronize
+    torch_sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        asm3.assemble_nl_residual(solution_only=True)
+        asm3.residual_norm()
+    torch_sync(dev)
+    per = (time.perf_counter() - t0) / steps
+    out["residual_only_3d"]["line_search_call"] = {
+        "what": "pfm_assemble_nl_residual_device + pfm_residual_norms, synchronous; residual stays on the device",
+        "ms_per_call": per * 1e3, "bytes_to_host": 24, "residual_l2": nrm, "DoFs_per_s": 4 * n_nodes3 / per}
     n2 = 1000
     lp = P.build_local_problem(2, (n2, n2), P.factor_ranks(1, 2), 0)
     h = (20.0 / n2) * np.sqrt(2)
@@ -548,6 +563,25 @@ def host_pointer_call(asm, dev, n_dofs: int):
     rec["bytes_over_pcie"] = moved
     rec["GBps_effective"] = moved / rec["seconds_per_assembly"] / 1e9
     rec["DoFs_per_s"] = n_dofs / rec["seconds_per_assembly"]
+    # the residual-only call in the same shape (cracks.cc:2946-2949: the line search reads system_pde_residual on the host
+    # after every assemble_nl_residual(), 10-50 times per Newton step): three vectors in, two residual vectors out
+    if pinned:
+        res_tot = np.empty(ctx.n_owned_dofs)
+        ctx.host_register(res_tot)
+
+        def call_res():
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ctx.assemble_host(sol, old, oo, True, out=(None, res, res_tot))
+            return time.perf_counter() - t0
+
+        call_res()
+        tr = float(np.median([call_res() for _ in range(5)]))
+        moved_r = 8.0 * 5 * ctx.n_owned_dofs
+        rec["residual_only"] = {"seconds_per_call": tr, "bytes_over_pcie": moved_r, "GBps_effective": moved_r / tr / 1e9,
+                                "DoFs_per_s": n_dofs / tr,
+                                "note": "pfm_assemble(residual_only=1), page-locked host vectors: 3 in, 2 out; a caller that only needs "
+                                        "the norm uses extra.residual_only_3d.line_search_call (24 bytes)"}
     ctx.host_unregister()
     return rec
 

@@ -294,6 +294,13 @@ class Context:
         self._check(self.lib.pfm_get_constraints(self._h, capi.np_ptr(flags, np.uint8)), "pfm_get_constraints")
         return flags
 
+    def residual_norms(self, res_ptr: int):
+        """(l2, linf, sum of squares) of a device residual vector with the constrained lines zeroed -- what the Newton loop
+        and the line search read after every assembly (cracks.cc:2791-2794, 2947-2949); this rank's owned dofs."""
+        out = (C.c_double * 3)()
+        self._check(self.lib.pfm_residual_norms(self._h, C.c_void_p(res_ptr), out), "pfm_residual_norms")
+        return float(out[0]), float(out[1]), float(out[2])
+
     def functionals(self, cell_owned: Optional[np.ndarray] = None, cell_lambda=None, cell_mu=None):
         """(bulk energy, crack energy, TCV) of the node state in the context (cracks.cc:3553-3701); optional per-cell
         Lame coefficients for the energy (the reference's heterogeneous case uses other ones than the assembly)."""
@@ -391,6 +398,12 @@ class Assembler:
     def assemble_nl_residual(self, solution_only: bool = False):
         """cracks.cc:2507-2512."""
         self.assemble_system(True, solution_only)
+
+    def residual_norm(self, total: bool = False) -> float:
+        """constraints_update.set_zero(residual); residual.l2_norm() (cracks.cc:2791-2794, 2947-2949) of the last assembly, without
+        moving the vector: 24 bytes come back.  Synchronous (as the reference's call)."""
+        r = self.system_total_residual if total else self.system_pde_residual
+        return self.ctx.residual_norms(r.data_ptr())[0]
 
     def synchronize(self):
         """Wait for the stream and raise what the reference would have thrown/aborted on."""

@@ -31,7 +31,7 @@ EXPORTS = [
     "pfm_ctx_device_bytes", "pfm_timing_enable", "pfm_kernel_time_ms", "pfm_kernel_times_ms",
     # include/pfm_newton.h
     "pfm_diag_mass_device", "pfm_active_set_device", "pfm_get_constraints", "pfm_functionals",
-    "pfm_functionals_material",
+    "pfm_functionals_material", "pfm_residual_norms",
 ]
 
 
@@ -137,6 +137,7 @@ def load():
     lib.pfm_active_set_device.argtypes = [vp, vp, vp, C.c_double, vp, vp, vp, C.POINTER(i64)]
     lib.pfm_get_constraints.argtypes = [vp, vp]
     lib.pfm_functionals.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.pfm_residual_norms.argtypes = [vp, vp, C.POINTER(C.c_double)]
     _LIB = lib
     return lib
 

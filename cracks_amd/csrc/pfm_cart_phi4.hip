@@ -982,8 +982,6 @@ namespace pfm
       // of the co-resident workgroup's arithmetic they finish sooner and cost it nothing measurable; -0.2 ms at 216^3).
       // PFM_NO_PRIO=1 switches them off (A/B runs): the launcher then passes the chunk length negated
       const bool PRIO = zc_in > 0;
-      // nullptr: the structurally zero (u,phi) block is cleared by a fill next to this launch (pfm_host.cpp, PFM_UP_FILL)
-      const bool zero_up = __builtin_amdgcn_readfirstlane(vals_up != nullptr);
       const int zc = zc_in < 0 ? -zc_in : zc_in;
       const MatScal &S = *Sp; // per-launch scalars live in device memory: loaded where used, not pinned in SGPRs
       long long tclk = 0;
@@ -1148,8 +1146,6 @@ namespace pfm
           // wait for its own stores to drain, they have the whole next role phase for that
           if (nst >= 28)
             asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-          else if (nst >= 14) // (the zeros of the (u,phi) block come from a fill on another stream: 2 unconditional stores per y-line)
-            asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
           else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           nst = 0;
@@ -1440,18 +1436,15 @@ namespace pfm
                     {
                       double *bpu = vals_pu + 3 * off0[ny], *bup = vals_up + 3 * off0[ny], *bpp = vals_pp + off0[ny];
                       bpu[uq] = val[ny][0];
-                      if (zero_up)
-                        bup[uq] = 0.0;
+                      bup[uq] = 0.0;
                       bpu[uq + NT4] = val[ny][1];
-                      if (zero_up)
-                        bup[uq + NT4] = 0.0;
+                      bup[uq + NT4] = 0.0;
                       spu[0][ny * (PN * 27)] = 0.0; // these slabs are the next planes' accumulators
                       spu[1][ny * (PN * 27)] = 0.0;
                       if (act2)
                         {
                           bpu[uq + 2 * NT4] = val[ny][2];
-                          if (zero_up)
-                            bup[uq + 2 * NT4] = 0.0;
+                          bup[uq + 2 * NT4] = 0.0;
                           spu[2][ny * (PN * 27)] = 0.0;
                         }
                       if (actp)
@@ -1460,7 +1453,7 @@ namespace pfm
                           spp[ny * (PN * 9)] = 0.0;
                         }
                     }
-                  nst = zero_up ? 4 * PN : 2 * PN;
+                  nst = 4 * PN;
                 }
               else if (t < 2 * 108)
                 {
@@ -1543,8 +1536,7 @@ namespace pfm
                                   else
                                     {
                                       vals_pu[3 * off + sl * 3 + fe_d] = val;
-                                      if (zero_up)
-                                        vals_up[3 * off + sl * 3 + fe_d] = 0.0; // any bijection onto the node's 3 rows
+                                      vals_up[3 * off + sl * 3 + fe_d] = 0.0; // any bijection onto the node's 3 rows
                                     }
                                 }
                               else // interleaved layout: row (node, 3) holds [u_x u_y u_z phi] per neighbour slot
@@ -1631,7 +1623,7 @@ namespace pfm
   const bool oldf = Sh.gamma_fac != 0.0 || Sh.monolithic;
 #define PFM_PHI4_(NC, HETV, RESV, OLDV)                                                                                           \
   hipLaunchKernelGGL((k_cart_phi4<NC, 0, HETV, RESV, OLDV>), grid, block, 0, s, v, cv, S, (NC == 3 ? d_values[2] : nullptr),      \
-                     (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 && !cv.up_by_fill ? d_values[1] : nullptr), zc, nullptr, res_pde)
+                     (NC == 3 ? d_values[3] : nullptr), d_values[0], (NC == 3 ? d_values[1] : nullptr), zc, nullptr, res_pde)
 #define PFM_PHI4(NC, HETV, RESV)                                                                                                  \
   do                                                                                                                              \
     {                                                                                                                             \

@@ -2641,10 +2641,6 @@ extern "C"
                     (void *)c->cv.patch_count})
       if (q)
         (void)hipFree(q);
-    if (c->fill_stream)
-      (void)hipStreamDestroy(c->fill_stream);
-    if (c->ev_fill)
-      (void)hipEventDestroy(c->ev_fill);
     if (c->atomic_stream)
       (void)hipStreamDestroy(c->atomic_stream);
     if (c->ev_atomic)
@@ -2726,6 +2722,12 @@ extern "C"
       return hipSuccess;
     if (find_pin(c, h, bytes))
       return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    // the staged copy runs on the NULL stream, which does not order itself behind a hipStreamNonBlocking stream installed
+    // through pfm_ctx_set_stream (torch side streams are of that kind): kernels still queued on `s` may read what this copy
+    // overwrites (node_flags of an assembly in flight, the staging vectors of the last state) -- wait for them first
+    const hipError_t es = hipStreamSynchronize(s);
+    if (es != hipSuccess)
+      return es;
     return h2d(d, h, bytes);
   }
 
@@ -3739,28 +3741,9 @@ extern "C"
         c->scal_dirty = false;
       }
     pfm::CartView cv_launch = c->cv;
-    // Blocked layout, Jacobian pair: the structurally zero (u,phi) block (cracks.cc:2333-2337: sigma_LinU = 0 for a
-    // phase-field trial function; 81 doubles per node, 6.6 GB at 216^3) is cleared by a plain fill on a third stream instead
-    // of by 21 of the 49 store instructions of every copy-out of k_cart_phi4: the fill's workgroups need no LDS and sit in the
-    // wave slots the two LDS-bound kernels leave free.  Measured at 216^3 (profiles/r06/ab_up_fill.txt): 10.95 -> 11.35 ms per
-    // assembly -- the fill takes memory bandwidth in a burst and dispatch slots from the pair, the copy-out it shortens was not
-    // what the phase-field kernel waits for.  OFF by default (PFM_UP_FILL=1: A/B runs); the kernel writes the zeros itself.
-    static const bool up_fill_on = getenv("PFM_UP_FILL") && atoi(getenv("PFM_UP_FILL")) != 0;
-    const bool up_fill = pair && fork && up_fill_on && c->n_blocks == 4 && d_values[1] && c->block_nnz(1) > 0;
-    if (up_fill)
-      {
-        if (!c->fill_stream && (hipStreamCreateWithFlags(&c->fill_stream, hipStreamNonBlocking) != hipSuccess ||
-                                hipEventCreateWithFlags(&c->ev_fill, hipEventDisableTiming) != hipSuccess))
-          return fail(c, PFM_ERR_HIP, "fill stream");
-        e = hipStreamWaitEvent(c->fill_stream, c->ev_fork, 0);
-        if (e == hipSuccess)
-          e = hipMemsetAsync(d_values[1], 0, sizeof(double) * (size_t)c->block_nnz(1), c->fill_stream);
-        if (e == hipSuccess)
-          e = hipEventRecord(c->ev_fill, c->fill_stream);
-        if (e != hipSuccess)
-          return hipfail(c, e, "fill of the (u,phi) block");
-        cv_launch.up_by_fill = 1;
-      }
+    // (round 6, measured and removed: clearing the structurally zero (u,phi) block with a fill on a third stream instead of
+    // by 21 of the 49 store instructions of every copy-out of k_cart_phi4 -- 10.95 -> 11.35 ms per assembly at 216^3,
+    // profiles/r06/ab_up_fill.txt: the fill takes bandwidth in a burst and dispatch slots from the pair)
     if (!pair)
       cv_launch.patch_idx = nullptr, cv_launch.patch_val = nullptr, cv_launch.patch_count = nullptr, cv_launch.patch_cap = 0;
     int rc;
@@ -3776,7 +3759,8 @@ extern "C"
           {
             // the row-owner kernels of the cartesian family on every level lattice: each level on a stream of its own, forked
             // off the context's stream (a level lattice of 6e5 nodes fills a third of the chip's dispatch slots; the levels
-            // write disjoint rows).  PFM_OVERLAY3_SEQUENTIAL=1: one after the other on the stream (A/B runs).
+            // write disjoint rows) when PFM_OVERLAY3_CONCURRENT=1 is set.  Default: one after the other on the context's
+            // stream -- measured the better of the two (profiles/r05/ov3_ab.txt: 4.56 against 4.86 ms per Jacobian)
             static const bool levels_sequential = getenv("PFM_OVERLAY3_CONCURRENT") == nullptr;
             const size_t nl = c->levels3.size();
             for (auto &lv : c->levels3)
@@ -3873,8 +3857,6 @@ extern "C"
         e = hipEventRecord(c->ev_join, s_res);
         if (e == hipSuccess)
           e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
-        if (e == hipSuccess && up_fill)
-          e = hipStreamWaitEvent(c->stream, c->ev_fill, 0);
         if (e != hipSuccess)
           return hipfail(c, e, "join");
       }
@@ -4080,6 +4062,9 @@ extern "C"
             hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) != hipSuccess)
           return fail(c, PFM_ERR_HIP, "copy stream");
       }
+    for (int b = 0; b < c->n_blocks; ++b) // (checked before the fork: no exit path leaves copy_stream unjoined)
+      if (c->block_nnz(b) > 0 && (!h_values[b] || !d_values[b]))
+        return fail(c, PFM_ERR_BAD_ARG, "pfm_values_to_host: null block");
     hipError_t e = hipEventRecord(c->ev_copy, c->stream);
     if (e == hipSuccess)
       e = hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0);
@@ -4088,8 +4073,6 @@ extern "C"
         const size_t bytes = sizeof(double) * (size_t)c->block_nnz(b);
         if (!bytes)
           continue;
-        if (!h_values[b] || !d_values[b])
-          return fail(c, PFM_ERR_BAD_ARG, "pfm_values_to_host: null block");
         if (c->n_blocks == 4 && b == 1)
           {
             // (u,phi) = 0.  A registered array is ours between the calls (nobody else writes the matrix: the reference only

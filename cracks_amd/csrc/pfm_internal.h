@@ -97,8 +97,6 @@ namespace pfm
     // launch -- hanging, parent, mixed-level or ghost nodes stay with the general family).  nullptr: every owned node of
     // the box is a row (uniform boxes).
     const int32_t *row_of_box;
-    int up_by_fill;                   // 1: the caller clears the structurally zero (u,phi) block of the blocked layout with a
-                                      // fill on a stream of its own; k_cart_phi4 then leaves it alone
     int tile_sel;                     // 0: every tile; 1: only tiles that read no ghost node ("interior"); 2: only the
                                       // others -- the two launches of pfm_assemble_overlapped, between which the ghost
                                       // import lands (cracks.cc:2147-2154 next to the cell loop instead of in front of it)
@@ -254,8 +252,6 @@ struct pfm_ctx
   hipEvent_t ov_fork = nullptr;
   hipStream_t atomic_stream = nullptr; // 3-D overlay: the general family's atomic class next to its plain classes
   hipEvent_t ev_atomic = nullptr;
-  hipStream_t fill_stream = nullptr; // clearing of the structurally zero (u,phi) block next to the Jacobian pair (PFM_UP_FILL)
-  hipEvent_t ev_fill = nullptr;
   hipStream_t side_stream = nullptr;            // residual + clearing of the (u,phi) block, concurrent with the Jacobian
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   pfm::DevView v{};

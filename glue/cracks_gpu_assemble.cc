@@ -55,6 +55,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <set>
 #include <vector>
@@ -62,6 +63,7 @@
 extern "C"
 {
 #include "pfm_assemble.h"
+#include "pfm_newton.h"
 }
 
 namespace pfm_glue_detail
@@ -110,6 +112,17 @@ namespace pfm_glue_detail
     bool flags_shipped_anywhere = false; // some rank of the communicator wants such bytes (decided collectively in rebuild)
     IndexSet relevant_dofs;              // locally relevant dofs: the lines deal.II's AffineConstraints objects can be asked about
     bool state_complete = false; // all three vectors have been scattered into this context once
+    // Opt-in switches of the host (both off: the behaviour of a plain drop-in).
+    //   pin_host_matrix:   rebuild() page-locks Epetra's value arrays (pfm_host_register) so that the 30 GB of a 3-D Jacobian
+    //                      travel as DMA at the link rate.  The arrays belong to system_pde_matrix, which setup_system()
+    //                      reinitialises (cracks.cc:1583, 1653): a host that switches this on MUST call before_setup_system()
+    //                      at the top of setup_system() -- rebuild() refuses to run over a context that still holds locks.
+    //   residual_to_host:  false = a residual-only assemble() leaves both residual vectors on the device and the caller asks
+    //                      for what the line search reads, residual_l2_norm() (cracks.cc:2946-2949): 24 bytes instead of
+    //                      2 x 8 n_dofs per call.
+    bool pin_host_matrix = false;
+    bool residual_to_host = true;
+    bool holds_host_pins = false;
 
     ~PfmGlue()
     {
@@ -118,11 +131,16 @@ namespace pfm_glue_detail
         pfm_comm_destroy(comm);
     }
 
+    // top of setup_system() (cracks.cc:1579), BEFORE system_pde_matrix.reinit / clear: drops the context and with it every
+    // page lock on arrays the matrix is about to free
+    void before_setup_system() { release(); }
+
     void release()
     {
       if (ctx)
-        pfm_ctx_destroy(ctx);
+        pfm_ctx_destroy(ctx); // (unregisters every host array of the context)
       ctx = nullptr;
+      holds_host_pins = false;
       for (double *&p : d_vec)
         {
           if (p)
@@ -148,6 +166,11 @@ namespace pfm_glue_detail
     template <class Problem>
     void rebuild(Problem &P)
     {
+      // the arrays page-locked by the last rebuild() belonged to the matrix setup_system() has just reinitialised: locked
+      // pages would have been freed under the lock and hipHostUnregister would run on dangling pointers
+      AssertThrow(!(ctx && holds_host_pins),
+                  ExcMessage("PfmGlue::rebuild: the previous context still page-locks the old matrix arrays -- call "
+                             "before_setup_system() at the top of setup_system() (INTEGRATION.md), or leave pin_host_matrix off"));
       release();
       state_complete = false;
       const auto &dh = P.dof_handler;
@@ -318,10 +341,10 @@ namespace pfm_glue_detail
                         ExcMessage("hipMalloc (matrix values)"));
             // Epetra's value array receives 35 GB per Jacobian at 1e7 cells: page-locked, the transfer is DMA at the link
             // rate (pageable memory: a fraction of it).  Best effort: if the pages cannot be locked the copy still works.
-            // The lock is released by release() (pfm_ctx_destroy) -- which therefore must run BEFORE the matrix is
-            // reinitialised in setup_system.
-            if (n_entries > 0)
-              (void)pfm_host_register(ctx, values, (int64_t)sizeof(double) * n_entries);
+            // Opt-in (pin_host_matrix): the lock must be gone BEFORE the matrix is reinitialised in setup_system --
+            // before_setup_system(), enforced at the top of this function.
+            if (pin_host_matrix && n_entries > 0 && pfm_host_register(ctx, values, (int64_t)sizeof(double) * n_entries) == PFM_OK)
+              holds_host_pins = true;
           }
 
       // ---- 6. ghost import lists (cracks.cc:2147-2154 at node level): who owns my ghost nodes, who needs my owned ones
@@ -635,6 +658,8 @@ namespace pfm_glue_detail
       AssertThrow(rc == PFM_OK, ExcMessage(pfm_last_error(ctx)));
 
       // results into the Trilinos objects (owned rows are complete: no compress(add), cracks.cc:2470-2475)
+      if (residual_only && !residual_to_host)
+        return; // the caller reads residual_l2_norm(): the vectors stay on the device
       AssertThrow(hipMemcpy(h_res[0].data(), d_res[0], sizeof(double) * nd, hipMemcpyDeviceToHost) == hipSuccess, ExcMessage("D2H"));
       scatter_owned(h_res[0], P.system_pde_residual);
       if (residual_only)
@@ -657,6 +682,17 @@ namespace pfm_glue_detail
           PFM_CALL(ctx, pfm_values_to_host(ctx, d_val, h_val));
         }
       // the AMG set-up of cracks.cc:2477-2497 follows in the caller, unchanged
+    }
+
+    // constraints_update.set_zero(system_pde_residual); system_pde_residual.l2_norm()  (cracks.cc:2791-2794, 2947-2949) of the
+    // last assemble(), from the device copy: the rank's sum of squares comes back (24 bytes), the ranks' sums are added
+    // as l2_norm() adds them.  total = true: the same for system_total_residual.
+    template <class Problem>
+    double residual_l2_norm(const Problem &P, const bool total = false)
+    {
+      double out[3] = {0.0, 0.0, 0.0};
+      PFM_CALL(ctx, pfm_residual_norms(ctx, d_res[total ? 1 : 0], out));
+      return std::sqrt(Utilities::MPI::sum(out[2], P.mpi_com));
     }
 
     // global dof of (local node, component)
@@ -717,6 +753,9 @@ namespace pfm_glue_detail
 //
 // and the two call sites:
 //   setup_system():            ... diag mass (cracks.cc:1675);  pfm_glue.rebuild(*this);
+//   setup_system(), first line: pfm_glue.before_setup_system();   // required with pin_host_matrix, harmless without
 //   assemble_system(bool ro):  pfm_glue.assemble(*this, ro);  if (!direct_solver && !ro) { AMG set-up, cracks.cc:2477-2497 }
+//   line search (cracks.cc:2946-2949) with pfm_glue.residual_to_host = false:
+//                              assemble_nl_residual();  new_newton_residual = pfm_glue.residual_l2_norm(*this);
 
 #endif // PFM_WITH_DEALII

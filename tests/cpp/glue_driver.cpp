@@ -190,7 +190,25 @@ static int run(const std::string &dir, std::istringstream &meta)
       }
 
   pfm_glue_detail::PfmGlue<dim> glue;
+  glue.pin_host_matrix = true;
   glue.rebuild(P);
+  {
+    // a second setup_system(): without before_setup_system() the glue must refuse (the locks of the first rebuild are on
+    // arrays the host is about to free), with it the rebuild goes through
+    bool refused = false;
+    try
+      {
+        glue.rebuild(P);
+      }
+    catch (const std::exception &)
+      {
+        refused = true;
+      }
+    if (!refused)
+      throw std::runtime_error("rebuild() over a context that holds page locks was not refused");
+    glue.before_setup_system();
+    glue.rebuild(P);
+  }
   auto dump = [&](const TrilinosWrappers::MPI::BlockVector &v, const std::string &name) {
     std::vector<double> x;
     for (int b = 0; b < nb1; ++b)
@@ -201,6 +219,14 @@ static int run(const std::string &dir, std::istringstream &meta)
   glue.assemble(P, /*residual_only=*/true, /*only_solution_changed=*/true); // the line-search form: same state, same result
   dump(P.system_pde_residual, "out_res_pde_ro.bin");
   dump(P.system_total_residual, "out_res_tot_ro.bin");
+  {
+    // the line search without the vectors (residual_to_host = false): the norms come from the device copy
+    glue.residual_to_host = false;
+    glue.assemble(P, /*residual_only=*/true, /*only_solution_changed=*/true);
+    const double n_pde = glue.residual_l2_norm(P), n_tot = glue.residual_l2_norm(P, true);
+    glue.residual_to_host = true;
+    write_bin(dir + "/out_norms.bin", std::vector<double>{n_pde, n_tot}.data(), (size_t)2);
+  }
   glue.assemble(P, /*residual_only=*/false);
   dump(P.system_pde_residual, "out_res_pde.bin");
   for (int r = 0; r < nb1; ++r)

@@ -191,6 +191,10 @@ def test_glue_rebuild_and_assemble_match_the_oracle(name, maker, tmp_path):
     res_pde = np.fromfile(os.path.join(d, "out_res_pde_ro.bin"))[to_mock]
     res_tot = np.fromfile(os.path.join(d, "out_res_tot_ro.bin"))[to_mock]
     assert linf_scaled(res_pde, ro.residual_pde) < TOL and linf_scaled(res_tot, ro.residual_total) < TOL
+    # the line search without host vectors (PfmGlue::residual_to_host = false + residual_l2_norm): set_zero + l2 on the device
+    n_pde, n_tot = np.fromfile(os.path.join(d, "out_norms.bin"))
+    assert n_pde == pytest.approx(np.linalg.norm(c.cu.set_zero(ro.residual_pde)), rel=1e-12)
+    assert n_tot == pytest.approx(np.linalg.norm(c.cu.set_zero(ro.residual_total)), rel=1e-12)
     # full call: every matrix entry (constrained rows included) and the residual
     rf = O.assemble(mesh, lay, c.params, c.sol, c.old, c.oldold, c.cu, c.ch, False, rp, ci, c.cell_lambda, c.cell_mu)
     assert rf.err == 0

@@ -147,3 +147,41 @@ def test_gpu_active_set(case):
     # the displacement bits are untouched
     want_flags = node_flags_from_dof_flags(lay, cu_flag, case.ch.flag)
     assert np.array_equal(flags & ((1 << dim) - 1), want_flags & ((1 << dim) - 1))
+
+
+# ---- pfm_residual_norms: what the Newton loop / line search read after an assembly (cracks.cc:2791-2794, 2947-2949)
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", cases.ALL_KATS, ids=lambda f: f.__name__)
+def test_gpu_step0_golden_norm_without_a_host_vector(make):
+    """The reference prints ||set_zero(system_pde_residual)||_2 of step 0 in its Newton tables (tests/*.output, first row):
+    seven goldens, to the 7 printed digits, from the device residual alone -- 24 bytes come back."""
+    case = make()
+    asm = _gpu_assembler(case)
+    asm.assemble_nl_residual()
+    l2 = asm.residual_norm()
+    assert l2 == pytest.approx(case.golden_residual0, rel=5e-7)
+    # and the second-call form of the line search (only `solution` changed)
+    asm.assemble_nl_residual(solution_only=True)
+    assert asm.residual_norm() == l2  # bitwise: deterministic reduction, deterministic kernels (no hanging-node atomics in a residual)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _cases() + [cases.perturbed(cases.kat_miehe_tension())], ids=lambda c: c.name)
+def test_gpu_residual_norms_mask_and_values(case):
+    """Norms of an ARBITRARY device vector: the constrained lines (Dirichlet, active set, hanging nodes) must be zeroed by the
+    call itself, whatever the vector holds there."""
+    import torch
+
+    asm = _gpu_assembler(case)
+    rng = np.random.default_rng(7)
+    r = rng.standard_normal(case.layout.n_dofs) * 10.0 ** rng.integers(-3, 4, case.layout.n_dofs)
+    d = torch.from_numpy(r).to(asm.dev)
+    asm.ctx.set_stream(torch.cuda.current_stream(asm.dev).cuda_stream)
+    l2, linf, sq = asm.ctx.residual_norms(d.data_ptr())
+    z = case.cu.set_zero(r.copy())
+    z[case.ch.flag.astype(bool)] = 0.0
+    assert l2 == pytest.approx(np.linalg.norm(z), rel=1e-13)
+    assert linf == np.abs(z).max()
+    assert sq == pytest.approx(float(z @ z), rel=1e-13)
+    again = asm.ctx.residual_norms(d.data_ptr())
+    assert again == (l2, linf, sq)
