@@ -733,7 +733,22 @@ def main():
     # what RCCL itself counted on the communicator the exchange used (None: no in-library RCCL transport in this run)
     rccl = halo.rccl_info() if (world > 1 and halo is not None) else None
     tt = torch.tensor([elapsed, k_ms, k_med, exchange_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+    per_rank = None
     if world > 1:
+        # every rank's own numbers (outside the timed region): compute imbalance shows as max - min of the kernel time,
+        # exchange cost as elapsed - kernel time
+        allr = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allr, tt)
+        rows = np.array([[float(x) for x in r.cpu()] for r in allr])
+        per_rank = {"kernel_ms": {"min": float(rows[:, 1].min()), "max": float(rows[:, 1].max()), "all": [round(float(x), 4) for x in rows[:, 1]]},
+                    "ms_per_step": {"min": float(rows[:, 0].min() * 1e3 / args.steps), "max": float(rows[:, 0].max() * 1e3 / args.steps)},
+                    "exchange_ms": {"min": float(rows[:, 3].min()), "max": float(rows[:, 3].max())},
+                    "owned_nodes": None}
+        nn = torch.tensor([float(lp.n_owned), float(lp.mesh.n_cells)], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+        alln = [torch.zeros_like(nn) for _ in range(world)]
+        dist.all_gather(alln, nn)
+        per_rank["owned_nodes"] = [int(x[0]) for x in alln]
+        per_rank["local_cells"] = [int(x[1]) for x in alln]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, k_ms, k_med, exchange_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
     checksum = None
@@ -781,12 +796,16 @@ def main():
         for _ in range(args.warmup):
             asm2.assemble_system(False)
         asm2.synchronize()
+        asm2.ctx.timing_enable(True)
         fence()
         t2 = time.perf_counter()
         for _ in range(args.steps):
             asm2.assemble_system(False)
         fence()
         el2 = time.perf_counter() - t2
+        asm2.synchronize()
+        k2_ms, _ = asm2.ctx.kernel_time_ms()
+        asm2.ctx.timing_enable(False)
         xs = []
         for _ in range(10):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -796,9 +815,14 @@ def main():
             e1.synchronize()
             xs.append(e0.elapsed_time(e1))
         t3 = torch.tensor([el2, float(np.median(xs)), float(len(lp2.peers))], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+        k2 = torch.tensor([k2_ms], dtype=torch.float64, device="cpu" if smoke_gloo else dev)
+        k2all = [torch.zeros_like(k2) for _ in range(world)]
+        dist.all_gather(k2all, k2)
+        k2v = [float(x[0]) for x in k2all]
         dist.all_reduce(t3, op=dist.ReduceOp.MAX)
         cubic = {"partition": "x".join(str(k) for k in p_cubic), "ms_per_step": 1e3 * float(t3[0]) / args.steps,
-                 "value": n_dofs / (float(t3[0]) / args.steps), "exchange_ms": float(t3[1]), "max_peers": int(t3[2])}
+                 "value": n_dofs / (float(t3[0]) / args.steps), "exchange_ms": float(t3[1]), "max_peers": int(t3[2]),
+                 "per_rank_kernel_ms": {"min": min(k2v), "max": max(k2v), "all": [round(x, 4) for x in k2v]}}
         asm = asm2
 
     if rank == 0:
@@ -849,6 +873,8 @@ def main():
             # ncclCommCount / ncclGetVersion of the communicator the ghost exchange ran on (rank 0's view; null in gloo runs)
             out["rccl_nranks"] = rccl["rccl_nranks"] if rccl else None
             out["rccl_version"] = rccl["rccl_version"] if rccl else None
+            out["per_rank"] = per_rank
+            out["per_rank_kernel_ms"] = per_rank["kernel_ms"] if per_rank else None
         if cubic is not None:
             out["cubic_partition"] = cubic
         if checksum is not None:

@@ -274,10 +274,15 @@ def test_bench_multiprocess_flow_reproduces_single_rank_sums(world, cells, extra
     # what the driver's SCALE record needs beside the value: the cut, the measured ghost import, and -- where the headline
     # cut is z-slabs -- the same steps on the near-cubic grid a p4est host would hand over
     assert many["config"]["partition"] and many["config"]["peers"] >= 1 and many["exchange_ms"] > 0.0
+    # every rank's own kernel time (gathered outside the timed region): compute imbalance apart from exchange cost
+    pr = many["per_rank_kernel_ms"]
+    assert len(pr["all"]) == world and 0.0 < pr["min"] <= pr["max"]
+    assert len(many["per_rank"]["owned_nodes"]) == world and sum(many["per_rank"]["owned_nodes"]) == (cells + 1) ** (2 if extra else 3)
     if world == 2 and not extra:
         assert many["config"]["partition"] == "1x1x2"
         cp = many["cubic_partition"]
         assert cp["partition"] == "2x1x1" and cp["ms_per_step"] > 0 and cp["exchange_ms"] > 0 and cp["max_peers"] == 1
+        assert len(cp["per_rank_kernel_ms"]["all"]) == 2 and cp["per_rank_kernel_ms"]["min"] > 0
     a, b = np.array(one["checksum"]), np.array(many["checksum"])
     assert a.shape == b.shape and np.abs(a).max() > 0
     scale = np.abs(a).reshape(-1, 2)[:, 1].repeat(2)  # each pair is (sum, sum of absolute values)
