@@ -228,6 +228,50 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
     for th in threads:
         th.join()
     assert not errs
+    # (iii) a second sample size on the all-cores leg ("time the CPU on 1e5-1e6 cells and report
+    # DoFs/s, size-independent"): the same mesh kind at 46^3 = 97 336 cells (3-D) / 320^2 (2-D) SHARED by the threads is not
+    # what the oracle offers (one call = one mesh, serial), so every thread assembles its own copy once -- the DoFs/s of
+    # that leg next to the small sample's shows whether the figure depends on the working set (cache-resident 20^3
+    # against 46^3: 37 k against 4.1e5 DoFs, 2x2 block CSR of 44 MB per thread)
+    second = None
+    try:
+        n2 = (46 if not residual_only else 64) if dim == 3 else 320
+        mesh2 = M.box_mesh(dim, n2)
+        h2 = mesh2.min_cell_diameter()
+        lay2 = M.DofLayout(mesh2.n_nodes, dim, blocked=True)
+        u2, phi2, po2, poo2, _ = synthetic_state(mesh2, np.arange(mesh2.n_nodes), h2, dim)
+        sol2, old2, oo2 = lay2.pack(u2, phi2), lay2.pack(np.zeros_like(u2), po2), lay2.pack(np.zeros_like(u2), poo2)
+        cu2 = M.update_constraints(mesh2, lay2, M.sneddon_dirichlet_dofs(mesh2, lay2))
+        ch2 = M.hanging_constraints(mesh2, lay2)
+        prm2 = O.PfmParams.from_buffer_copy(bytes(sneddon_params(h2, dim)))
+        rp2 = ci2 = None
+        if not residual_only:
+            rp2, ci2 = M.dof_sparsity(mesh2, lay2)
+        nth2 = min(ncore, 32)  # (0.35 GB of CSR values per thread)
+        barrier2 = threading.Barrier(nth2 + 1)
+        errs2 = []
+
+        def worker2():
+            barrier2.wait()
+            rr = O.assemble(mesh2, lay2, prm2, sol2, old2, oo2, cu2, ch2, residual_only, rp2, ci2)
+            if rr.err != 0:
+                errs2.append(rr.err)
+            barrier2.wait()
+
+        th2 = [threading.Thread(target=worker2) for _ in range(nth2)]
+        for th in th2:
+            th.start()
+        barrier2.wait()
+        t20 = time.perf_counter()
+        barrier2.wait()
+        t2 = time.perf_counter() - t20
+        for th in th2:
+            th.join()
+        assert not errs2
+        second = {"value": nth2 * lay2.n_dofs / t2, "unit": "DoFs/s", "cores": nth2,
+                  "sample": f"{nth2} threads x 1 assembly of {n2}^{dim} cells ({lay2.n_dofs} DoFs) each, wall {t2:.1f} s"}
+    except Exception as e:  # the second size must not take the baseline away
+        second = {"error": f"{type(e).__name__}: {e}"}
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -239,6 +283,7 @@ def cpu_baseline(dim: int, residual_only: bool, target_seconds: float = 15.0):
     return {"value": lay.n_dofs / t, "unit": "DoFs/s", "cores": 1, "kind": "port",
             "all_cores": {"value": ncore * reps * lay.n_dofs / t_all, "unit": "DoFs/s", "cores": ncore,
                           "sample": f"{ncore} threads{quota_note} x {reps} assemblies of the same sample each, wall {t_all:.1f} s"},
+            "all_cores_second_size": second,
             "sample": f"{n}^{dim} cells ({lay.n_dofs} DoFs), median of {len(times)} assemblies, "
                       f"{build_note}, 1 thread of {os.cpu_count()} ({model}); excludes Trilinos "
                       f"insertion overhead the real reference pays"}

@@ -87,3 +87,23 @@ def test_constrained_rows_get_only_a_positive_diagonal():
     node, comp = c.layout.node_comp_of_dof()
     Ad = A.toarray()
     assert not Ad[np.ix_(comp < 2, comp == 2)].any()
+
+
+@pytest.mark.parametrize("dim,n", [(2, 10), (3, 6), (2, 17), (3, 8)])
+def test_refine_cells_array_version_equals_the_loop_version(dim, n):
+    """cracks_amd.mesh.refine_cells (array operations) against the loop version it replaced: the same mesh node for node
+    and cell for cell -- every test mesh and golden built from it is unchanged."""
+    from cracks_amd import mesh as M
+
+    m = M.box_mesh(dim, n)
+    rng = np.random.default_rng(dim * 100 + n)
+    x = m.coords[m.cells].mean(axis=1)
+    for fl in (rng.random(m.n_cells) < 0.3, rng.random(m.n_cells) < 0.7, np.ones(m.n_cells, bool), np.zeros(m.n_cells, bool),
+               (np.abs(x) < 5.0).all(axis=1)):
+        a, b = M._refine_cells_loops(m, fl), M.refine_cells(m, fl)
+        assert np.array_equal(a.cells, b.cells) and np.array_equal(a.coords, b.coords)
+        assert a.boundary_nodes.keys() == b.boundary_nodes.keys()
+        for k in a.boundary_nodes:
+            assert np.array_equal(a.boundary_nodes[k], b.boundary_nodes[k])
+        assert np.array_equal(a.hn_nodes, b.hn_nodes) and np.array_equal(a.hn_ptr, b.hn_ptr)
+        assert np.array_equal(a.hn_parents, b.hn_parents) and np.array_equal(a.hn_weights, b.hn_weights)
