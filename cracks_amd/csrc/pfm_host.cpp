@@ -2512,7 +2512,13 @@ extern "C"
                     v.hcell = dev_upload(c, hcell.data(), hcell.size());
                     v.cslot_h = dev_alloc<uint8_t>(c, hcells.size() * (size_t)(nv * MPH * nv * MPH));
                     if (dim == 3)
-                      v.cres = dev_alloc<uint8_t>(c, hcells.size() * (size_t)pfm::PFM_CRES_BYTES);
+                      {
+                        v.cres = dev_alloc<uint8_t>(c, hcells.size() * (size_t)pfm::PFM_CRES_BYTES);
+                        c->n_hcells = (int64_t)hcells.size();
+                        // round 6 default: scratch + ordered gather instead of FP64 atomics (ensure_hang_gather, on first use);
+                        // PFM_HANGING_ATOMIC=1 keeps the atomic class, PFM_HANGING_COLOURED=1 the colour classes of round 5
+                        c->hang_gather = !hanging_coloured && getenv("PFM_HANGING_ATOMIC") == nullptr;
+                      }
                   }
               }
           }
@@ -3010,6 +3016,78 @@ extern "C"
   }
 
   int pfm_state_set_solution(pfm_ctx *c, const double *sol, int on_device) { return state_set_impl(c, sol, nullptr, nullptr, on_device); }
+
+  // Gather tables and scratch of the cells at hanging vertices (DevView::hs_*, pfm_ctx::d_hg_*), from the records of
+  // DevView::cres (built on the device): every (cell, resolved node) and (cell, hanging vertex) pair is listed under its
+  // destination row, rows ascending, the entries of a row in ascending (cell, index) order -- the order k_hanging_gather adds in.
+  // false: some cell has more than 16 resolved nodes (no record): the context keeps the atomic class.
+  static bool ensure_hang_gather(pfm_ctx *c)
+  {
+    if (c->hang_gather_ready)
+      return true;
+    if (!c->hang_gather || !c->v.cres || c->n_hcells == 0)
+      return false;
+    (void)hipSetDevice(c->device);
+    const int64_t nh = c->n_hcells;
+    pfm::raw_vector<uint8_t> rec((size_t)nh * pfm::PFM_CRES_BYTES);
+    if (hipMemcpy(rec.data(), c->v.cres, rec.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      throw HipFail{hipGetLastError(), "cres D2H"};
+    const int32_t NO = c->v.n_owned;
+    std::vector<int32_t> cnt((size_t)NO + 1, 0);
+    std::vector<long long> off((size_t)nh + 1, 0);
+    for (int64_t hc = 0; hc < nh; ++hc)
+      {
+        const uint8_t *r = rec.data() + (size_t)hc * pfm::PFM_CRES_BYTES;
+        const int R = r[pfm::PFM_CRES_R];
+        if (R > 16)
+          {
+            c->hang_gather = false;
+            return false;
+          }
+        off[(size_t)hc + 1] = off[(size_t)hc] + (long long)R * R * 13;
+        const int32_t *node = reinterpret_cast<const int32_t *>(r), *hv = reinterpret_cast<const int32_t *>(r + pfm::PFM_CRES_HV);
+        for (int i = 0; i < R; ++i)
+          if (node[i] < NO)
+            ++cnt[(size_t)node[i]];
+        for (int a = 0; a < 8; ++a)
+          if (hv[a] >= 0 && hv[a] < NO)
+            ++cnt[(size_t)hv[a]];
+      }
+    std::vector<int32_t> rows, row_of((size_t)NO, -1);
+    std::vector<long long> ptr(1, 0);
+    for (int32_t n = 0; n < NO; ++n)
+      if (cnt[(size_t)n])
+        {
+          row_of[(size_t)n] = (int32_t)rows.size();
+          rows.push_back(n);
+          ptr.push_back(ptr.back() + cnt[(size_t)n]);
+        }
+    std::vector<pfm::HgEntry> list((size_t)std::max<long long>(ptr.back(), 1));
+    std::vector<long long> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t hc = 0; hc < nh; ++hc)
+      {
+        const uint8_t *r = rec.data() + (size_t)hc * pfm::PFM_CRES_BYTES;
+        const int R = r[pfm::PFM_CRES_R];
+        const int32_t *node = reinterpret_cast<const int32_t *>(r), *hv = reinterpret_cast<const int32_t *>(r + pfm::PFM_CRES_HV);
+        for (int i = 0; i < R; ++i)
+          if (node[i] < NO)
+            list[(size_t)fill[(size_t)row_of[(size_t)node[i]]]++] = pfm::HgEntry{(int32_t)(hc * 32 + i), R, off[(size_t)hc] + (long long)i * R * 13};
+        for (int a = 0; a < 8; ++a)
+          if (hv[a] >= 0 && hv[a] < NO)
+            list[(size_t)fill[(size_t)row_of[(size_t)hv[a]]]++] = pfm::HgEntry{(int32_t)(hc * 32 + 16 + a), R, 0};
+      }
+    c->n_hg_rows = (int64_t)rows.size();
+    if (rows.empty())
+      rows.push_back(0);
+    c->d_hg_rows = dev_upload(c, rows.data(), rows.size());
+    c->d_hg_ptr = dev_upload(c, ptr.data(), ptr.size());
+    c->d_hg_list = dev_upload(c, list.data(), list.size());
+    c->v.hs_off = dev_upload(c, off.data(), off.size());
+    c->v.hs_K = dev_alloc<double>(c, (size_t)std::max<long long>(off.back(), 1));
+    c->v.hs_RD = dev_alloc<double>(c, (size_t)nh * pfm::PFM_HS_RD);
+    c->hang_gather_ready = true;
+    return true;
+  }
 
   static int assemble_impl(pfm_ctx *c, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot, int phase);
 
@@ -3616,6 +3694,23 @@ extern "C"
             return fail(c, PFM_ERR_NOMEM, "host allocation failed");
           }
       }
+    // 3-D cells at hanging vertices: scratch + ordered gather instead of atomics (round 6; DevView::hs_*)
+    bool gather = false;
+    if (!cart && c->v.dim == 3 && c->hang_gather && !split && phase != 1)
+      {
+        try
+          {
+            gather = ensure_hang_gather(c);
+          }
+        catch (const HipFail &f)
+          {
+            return hipfail(c, f.e, f.what);
+          }
+        catch (const std::bad_alloc &)
+          {
+            return fail(c, PFM_ERR_NOMEM, "host allocation failed");
+          }
+      }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing && phase == 2)
       ev1 = c->ev_pool[c->ev_used - 1].second; // opened by phase 1
@@ -3810,10 +3905,14 @@ extern "C"
           rc = launch_assemble_patches(c->v, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->n_patch_blocks, c->stream);
         pfm::DevView vg = c->v;
         vg.color_cells = c->d_color_cells_reduced;
+        if (gather)
+          vg.cell_ring = nullptr; // nobody adds atomically: the cells at hanging vertices only write their scratch
+        else
+          vg.hs_K = nullptr, vg.hs_off = nullptr, vg.hs_RD = nullptr;
         // 3-D overlay Jacobian: the class of the cells at hanging vertices (FP64 atomics, 4.7 of the general family's 6 ms at
         // 1.1e6 cells) on a third stream next to the plain classes (DevView::cell_ring makes that safe)
         hipStream_t s_atomic = nullptr;
-        if (overlay3 && fork_general && !residual_only && c->v.cell_ring && c->n_general_cells > 0)
+        if (overlay3 && fork_general && !residual_only && (c->v.cell_ring || gather) && c->n_general_cells > 0)
           {
             int prio_lo = 0, prio_hi = 0; // (numerically lower = higher priority) the long pole gets its workgroups dispatched first
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -3841,6 +3940,10 @@ extern "C"
       {
         pfm::DevView vg = c->v;
         vg.row_patch = nullptr; // no overlay in this assembly: the general family writes every row
+        if (gather)
+          vg.cell_ring = nullptr;
+        else
+          vg.hs_K = nullptr, vg.hs_off = nullptr, vg.hs_RD = nullptr;
         rc = launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr,
                                      fork_general ? c->side_stream : nullptr);
       }
@@ -3851,6 +3954,15 @@ extern "C"
           e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
         if (e != hipSuccess)
           return hipfail(c, e, "join (general family)");
+      }
+    if (gather && rc == PFM_OK && !cart)
+      {
+        // behind every class and every level kernel (joined above): the rows the cells at hanging vertices reach, in list order
+        pfm::DevView vg = c->v;
+        if (!patches)
+          vg.row_patch = nullptr;
+        rc = launch_hanging_gather(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->d_hg_rows, c->d_hg_ptr, c->d_hg_list,
+                                   c->n_hg_rows, c->stream);
       }
     if (fork)
       {

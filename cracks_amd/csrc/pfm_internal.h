@@ -15,7 +15,14 @@
 namespace pfm
 {
   // Device-side view of the static mesh tables and the node state (SoA, HBM resident).
-  constexpr int PFM_CRES_SLOT = 64, PFM_CRES_R = 320, PFM_CRES_BYTES = 336;
+  constexpr int PFM_CRES_SLOT = 64, PFM_CRES_R = 320, PFM_CRES_HV = 336, PFM_CRES_CELL = 368, PFM_CRES_BYTES = 376;
+  struct HgEntry // one contribution to a row of the gather tables (pfm_ctx::d_hg_list)
+  {
+    int32_t code; // hc * 32 + index: index < 16 = resolved node i of cell hc, 16 + a = the row of the cell's hanging vertex a
+    int32_t R;    // resolved nodes of the cell
+    long long koff; // first double of row i of the cell's K' in DevView::hs_K
+  };
+  constexpr int PFM_HS_RD = 96; // doubles per cell of DevView::hs_RD: residual of 16 resolved nodes x 4, placeholder of 8 vertices x 4
   struct DevView
   {
     int dim, layout, n_nodes, n_owned;
@@ -41,7 +48,15 @@ namespace pfm
     // 3-D: per such cell a record of PFM_CRES_BYTES: int32 node[16] (its distinct constraint-resolved nodes, -1 unused),
     // uint8 slot[16][16] at PFM_CRES_SLOT (slot of node j in the row of node i), uint8 R at PFM_CRES_R (0xff: more than 16).
     // The cell kernel forms C^T K C over these nodes before it adds (k_assemble_general, KRED).  nullptr: no such cells.
-    const uint8_t *cres;
+    const uint8_t *cres;         // (round 6: + int32 hv[8] at PFM_CRES_HV, the cell's hanging vertices' nodes (-1: does not hang),
+                                 // and the cell id at PFM_CRES_CELL)
+    // Round 6, the default on 3-D meshes with hanging nodes: the cells at hanging vertices do not add into the outputs at all.
+    // Their kernel writes K' = C^T K C, R' = C^T R and the placeholder diagonals into per-cell scratch (hs_K at hs_off[hc]:
+    // R x R x 13 doubles; hs_RD: PFM_HS_RD doubles per cell), and k_hanging_gather adds them row by row in a fixed order
+    // (pfm_ctx::d_hg_*): no atomics, no colour classes, bitwise reproducible.  nullptr: the atomic class of round 5.
+    double *hs_K;
+    const long long *hs_off;
+    double *hs_RD;
     const uint8_t *node_flags; // [n_nodes] bit c: dof (node,c) has a homogeneous constraint line
     const uint8_t *cell_ring;  // [n_cells] or nullptr: 1 = a cell of a plain colour class that shares a (constraint-resolved) node
                                // with a cell of the atomic class: it adds atomically too, so that the atomic class may run NEXT
@@ -239,6 +254,9 @@ namespace pfm
   int launch_assemble_patches(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *d_res_pde,
                               double *d_res_tot, int n_blocks, hipStream_t s);
   // fills DevView::node_slots from the current order of the node-graph rows (context creation, pfm_pattern_bind)
+  // rows [0, n_rows) of the gather tables: one wave per destination row, its entries in list order (fixed): plain adds
+  int launch_hanging_gather(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot,
+                            const int32_t *rows, const long long *ptr, const HgEntry *list, int64_t n_rows, hipStream_t s);
   int launch_zero_rows(const DevView &v, double *const *d_values, const int32_t *rows, int n_rows, hipStream_t s);
   int launch_patch_slots(const DevView &v, unsigned long long *d_slots, int n_blocks, hipStream_t s);
 } // namespace pfm
@@ -335,6 +353,15 @@ struct pfm_ctx
   uint8_t *d_cell_ring_reduced = nullptr;
   // scratch of the Newton-side sweeps (pfm_newton.hip)
   unsigned long long *d_counts = nullptr;
+  // gather tables of the cells at hanging vertices (DevView::hs_*): destination rows, their entry lists (hc * 32 + index:
+  // index < 16 = resolved node i of cell hc, 16 + a = the hanging vertex a's own row), ascending per row
+  int32_t *d_hg_rows = nullptr;
+  long long *d_hg_ptr = nullptr;
+  pfm::HgEntry *d_hg_list = nullptr;
+  int64_t n_hg_rows = 0;
+  int64_t n_hcells = 0;           // cells at hanging vertices (records of DevView::cres)
+  bool hang_gather = false;       // decided at pfm_ctx_create (PFM_HANGING_ATOMIC=1: off)
+  bool hang_gather_ready = false; // tables and scratch exist
   double *d_norm_partial = nullptr; // pfm_residual_norms: [2048][2] block partials + the 3 results
   double *d_partial = nullptr;
   int64_t n_partial = 0;

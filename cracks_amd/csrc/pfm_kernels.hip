@@ -203,7 +203,8 @@ namespace pfm
     // separated phases (phase = vertex index: a node receives exactly one cell per phase, the order of the adds is fixed) --
     // masked and written ONCE: no colour classes, no read-modify-write of global memory, no atomics.  Same q-loop, same
     // formulas as every other instantiation.
-    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, bool RING = false /* DevView::cell_ring is set */, bool PATCH = false>
+    template <int dim, bool FULL, bool SPLIT, bool ATOMIC, bool RING = false /* DevView::cell_ring is set */, bool PATCH = false,
+              bool SCR = false /* 3-D cells at hanging vertices: reduced matrix / residual into DevView::hs_* instead of the outputs */>
     __global__ __launch_bounds__(256, (dim == 3 && FULL) ? 2 : 1) void k_assemble_general(DevView v, pfm_params prm, Vals vals,
                                                               double *res_pde, double *res_tot,
                                                               int residual_only, long long class_begin, long long class_size)
@@ -1513,6 +1514,14 @@ namespace pfm
                               acc[c] = fma(w, s_rr[cl][a2][c], acc[c]);
                           }
                   }
+                if constexpr (SCR)
+                  {
+                    double *o = v.hs_RD + (long long)v.hcell[cell] * PFM_HS_RD + i * 4;
+#pragma unroll
+                    for (int c = 0; c < nc; ++c)
+                      o[c] = acc[c]; // unmasked: k_hanging_gather applies the flags
+                    continue;
+                  }
                 const unsigned fP = v.node_flags[P];
 #pragma unroll
                 for (int c = 0; c < nc; ++c)
@@ -1633,6 +1642,14 @@ namespace pfm
                             for (int t = 0; t < KCMP; ++t)
                               acc[t] = fma(w, k[t], acc[t]);
                           }
+                      if constexpr (SCR)
+                        {
+                          double *o = v.hs_K + v.hs_off[v.hcell[cell]] + (long long)pq * KCMP;
+#pragma unroll
+                          for (int t = 0; t < KCMP; ++t)
+                            o[t] = acc[t]; // unmasked: k_hanging_gather applies the flags
+                          continue;
+                        }
                       const unsigned fP = v.node_flags[P], fQ = v.node_flags[Q];
 #pragma unroll
                       for (int c = 0; c < 3; ++c)
@@ -1723,6 +1740,20 @@ namespace pfm
           for (int m = 1; m < LPC; m <<= 1)
             dsum += __shfl_xor(dsum, m, LPC);
           const double avg = dsum / (double)dpc;
+          if constexpr (SCR)
+            {
+              if (reduced)
+                {
+                  if (diag_lane)
+                    {
+                      double *o = v.hs_RD + (long long)v.hcell[cell] * PFM_HS_RD + 64 + a * 4;
+#pragma unroll
+                      for (int c = 0; c < nc; ++c)
+                        o[c] = diag[c] != 0.0 ? diag[c] : avg;
+                    }
+                  return;
+                }
+            }
           if (diag_lane && A < v.n_owned && !(v.row_patch && v.row_patch[A]) && (kA >= 0 || fA))
             {
               const int slot = (int)cs[a * nv + a];
@@ -1731,6 +1762,189 @@ namespace pfm
                 if (kA >= 0 || ((fA >> c) & 1u))
                   add_rt(val_ptr<dim>(v, vals, A, c, slot, c), diag[c] != 0.0 ? diag[c] : avg);
             }
+        }
+    }
+
+
+    // ------------------------------------------------------------ round 6: the cells at hanging vertices, deterministically
+    // One wave per destination row (node P).  Its entries -- (cell hc at a hanging vertex, index) in ascending order,
+    // pfm_ctx::d_hg_list -- are summed into the row's accumulators in LDS (13 values per neighbour slot + 4 residual entries)
+    // and added to the outputs once, behind the plain colour classes (stream order).  Four entries are FETCHED at a time (16
+    // lanes each: lane j < R holds the 13 values of the node pair (i, j) of K' = C^T K C, the flags of node j and the slot of
+    // j in the row), then ADDED one entry after the other: distinct nodes j are distinct slots, so the lanes of an entry hit
+    // distinct accumulators, and the summation order of every value is the order of the list -- no atomics, bitwise
+    // reproducible.  Masks (constraint flags of row and column) as in the atomic class; lane 15 of an entry's group adds the
+    // placeholder diagonal of a constrained vertex (deal.II distribute_local_to_global) and the residual entries.
+    // Rows of more than HG_DEG neighbours (none on 2:1 meshes of hexes) take the entries one by one with plain
+    // read-modify-writes of the outputs (same order).
+    constexpr int HG_DEG = 64;
+    template <bool FULL>
+    __global__ __launch_bounds__(256) void k_hanging_gather(DevView v, pfm_params prm, Vals vals, double *__restrict__ res_pde,
+                                                            double *__restrict__ res_tot, int residual_only,
+                                                            const int32_t *__restrict__ rows, const long long *__restrict__ ptr,
+                                                            const HgEntry *__restrict__ list, long long n_rows)
+    {
+      constexpr int dim = 3, nc = 4, KCMP = 13;
+      __shared__ double s_acc[4][FULL ? HG_DEG * KCMP : 1];
+      __shared__ double s_res[4][nc];
+      const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+      const long long r = (long long)blockIdx.x * 4 + w;
+      if (r >= n_rows)
+        return;
+      const int P = rows[r];
+      if (v.row_patch && v.row_patch[P])
+        return; // a regular row: the level lattices of the overlay write it
+      const unsigned fP = v.node_flags[P];
+      const bool total_via_update = !(prm.outer_solver == PFM_SOLVER_ACTIVE_SET);
+      const int deg = (int)(v.nadj_ptr[P + 1] - v.nadj_ptr[P]);
+      const long long e0 = ptr[r], e1 = ptr[r + 1];
+      const bool fast = deg <= HG_DEG;
+      double *acc = s_acc[w], *racc = s_res[w];
+      if (FULL && fast)
+        for (int n = lane; n < deg * KCMP; n += 64)
+          acc[n] = 0.0;
+      if (lane < nc)
+        racc[lane] = 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      auto add_value = [&](int slot, int t, double x) __attribute__((always_inline)) {
+        if (fast)
+          acc[slot * KCMP + t] += x;
+        else
+          {
+            const int c = t < 9 ? t / 3 : 3, d = t < 9 ? t - 3 * c : t - 9;
+            *val_ptr<dim>(v, vals, P, c, slot, d) += x;
+          }
+      };
+      for (long long eb = e0; eb < e1; eb += 4)
+        {
+          // ---- fetch: group g <-> entry eb + g
+          const long long e = eb + g;
+          const bool have = e < e1;
+          HgEntry en{0, 0, 0};
+          if (have)
+            en = list[e];
+          const int hc = en.code >> 5, idx = en.code & 31, R = en.R;
+          const uint8_t *rec = v.cres + (long long)hc * PFM_CRES_BYTES;
+          const double *RD = v.hs_RD + (long long)hc * PFM_HS_RD;
+          double kv[KCMP];
+          int slot = 0xff;
+          unsigned fQ = 0;
+          const bool pair = FULL && have && idx < 16 && j < R;
+          if (pair)
+            {
+              slot = (int)rec[PFM_CRES_SLOT + 16 * idx + j];
+              fQ = v.node_flags[reinterpret_cast<const int32_t *>(rec)[j]];
+              const double *src = v.hs_K + en.koff + (long long)j * KCMP;
+#pragma unroll
+              for (int t = 0; t < KCMP; ++t)
+                kv[t] = src[t];
+            }
+          // lane 15 of the group: residual entries of resolved node idx; placeholder diagonal of the vertex that IS node P
+          double rv[nc] = {0.0, 0.0, 0.0, 0.0}, dv[nc] = {0.0, 0.0, 0.0, 0.0};
+          int dslot = 0xff;
+          unsigned dmask = 0;
+          if (have && j == 15)
+            {
+              if (idx < 16)
+                {
+#pragma unroll
+                  for (int c = 0; c < nc; ++c)
+                    rv[c] = RD[idx * 4 + c];
+                }
+              if (FULL && (idx >= 16 || fP != 0u))
+                {
+                  const int cell = *reinterpret_cast<const int32_t *>(rec + PFM_CRES_CELL);
+                  int a = idx >= 16 ? idx - 16 : -1;
+                  if (a < 0)
+                    for (int a2 = 0; a2 < 8; ++a2)
+                      if (v.conn[(long long)a2 * v.n_cells + cell] == P)
+                        a = a2;
+                  if (a >= 0)
+                    {
+                      dslot = (int)v.cslot[(long long)cell * 64 + a * 8 + a];
+                      dmask = idx >= 16 ? 0xfu : fP; // the row of a hanging vertex: every component
+#pragma unroll
+                      for (int c = 0; c < nc; ++c)
+                        dv[c] = RD[64 + a * 4 + c];
+                    }
+                }
+            }
+          // ---- add: one entry after the other, in list order
+#pragma unroll 1
+          for (int gg = 0; gg < 4; ++gg)
+            {
+              if (g == gg)
+                {
+                  if (pair && slot != 0xff)
+                    {
+#pragma unroll
+                      for (int c = 0; c < 3; ++c)
+                        if (!((fP >> c) & 1u))
+                          {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d)
+                              if (!((fQ >> d) & 1u))
+                                add_value(slot, 3 * c + d, kv[3 * c + d]);
+                          }
+                      if (!((fP >> 3) & 1u))
+                        {
+#pragma unroll
+                          for (int d = 0; d < 3; ++d)
+                            if (!((fQ >> d) & 1u))
+                              add_value(slot, 9 + d, kv[9 + d]);
+                          if (!((fQ >> 3) & 1u))
+                            add_value(slot, 12, kv[12]);
+                        }
+                    }
+                  if (have && j == 15)
+                    {
+                      if (idx < 16)
+                        {
+#pragma unroll
+                          for (int c = 0; c < nc; ++c)
+                            racc[c] += rv[c];
+                        }
+                    }
+                }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              // the placeholder goes in behind the pairs of its entry (every pair lane skips a constrained row component, so
+              // these accumulators receive placeholders only -- in list order)
+              if (FULL && g == gg && have && j == 15 && dslot != 0xff)
+                {
+#pragma unroll
+                  for (int c = 0; c < nc; ++c)
+                    if ((dmask >> c) & 1u)
+                      add_value(dslot, c < 3 ? 4 * c : 12, dv[c]);
+                }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+      // ---- the row's sums into the outputs (behind the plain classes: stream order)
+      if (FULL && fast)
+        for (int n = lane; n < deg * KCMP; n += 64)
+          {
+            const int slot = n / KCMP, t = n - slot * KCMP;
+            const int c = t < 9 ? t / 3 : 3, d = t < 9 ? t - 3 * c : t - 9;
+            const double x = acc[n];
+            if (x != 0.0)
+              *val_ptr<dim>(v, vals, P, c, slot, d) += x;
+          }
+      if (lane < nc)
+        {
+          const int c = lane;
+          const long long di = dof_index<dim>(v, P, c);
+          const bool con = (fP >> c) & 1u;
+          const double x = racc[c];
+          if (!con)
+            res_pde[di] += x;
+          if (residual_only && (!con || !total_via_update))
+            res_tot[di] += x;
         }
     }
 
@@ -1944,6 +2158,12 @@ namespace pfm
           for (int t = 0; t < 16; ++t)
             reinterpret_cast<int32_t *>(rec)[t] = t < R ? node[t] : -1;
           rec[PFM_CRES_R] = over ? (uint8_t)0xff : (uint8_t)R;
+          for (int a = 0; a < 8; ++a)
+            {
+              const int A = v.conn[(long long)a * v.n_cells + cell];
+              reinterpret_cast<int32_t *>(rec + PFM_CRES_HV)[a] = v.hn_index[A] >= 0 ? A : -1;
+            }
+          *reinterpret_cast<int32_t *>(rec + PFM_CRES_CELL) = (int32_t)cell;
         }
       uint8_t *out = rec + PFM_CRES_SLOT + 16 * i;
       for (int j = 0; j < 16; ++j)
@@ -2092,6 +2312,23 @@ namespace pfm
       }
     if (v.cres && v.dim == 3)
       hipLaunchKernelGGL(k_build_cres, dim3((unsigned)((v.n_cells * 16 + bs - 1) / bs)), dim3(bs), 0, s, v, const_cast<uint8_t *>(v.cres));
+    return check_launch();
+  }
+
+  int launch_hanging_gather(const DevView &v, const pfm_params &p, int residual_only, double *const *d_values, double *d_res_pde, double *d_res_tot,
+                            const int32_t *rows, const long long *ptr, const HgEntry *list, int64_t n_rows, hipStream_t s)
+  {
+    if (n_rows == 0)
+      return PFM_OK;
+    Vals vals{};
+    if (!residual_only)
+      for (int b = 0; b < (v.layout == PFM_LAYOUT_BLOCKED ? 4 : 1); ++b)
+        vals.b[b] = d_values[b];
+    const dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    if (residual_only)
+      hipLaunchKernelGGL(k_hanging_gather<false>, grid, block, 0, s, v, p, vals, d_res_pde, d_res_tot, residual_only, rows, ptr, list, (long long)n_rows);
+    else
+      hipLaunchKernelGGL(k_hanging_gather<true>, grid, block, 0, s, v, p, vals, d_res_pde, d_res_tot, residual_only, rows, ptr, list, (long long)n_rows);
     return check_launch();
   }
 
@@ -2292,17 +2529,22 @@ namespace pfm
     hipStream_t s_main = s;
     for (int kk = 0; kk < n_classes; ++kk)
       {
-        const int k = (s_atomic && v.cell_ring) ? (kk == 0 ? n_classes - 1 : kk - 1) : kk;
+        // (DevView::hs_K: that class only writes its scratch -- it may run next to anything)
+        const bool side = s_atomic && (v.cell_ring || v.hs_K);
+        const int k = side ? (kk == 0 ? n_classes - 1 : kk - 1) : kk;
         const long long c0 = color_ptr[k], cn = color_ptr[k + 1] - c0;
         if (cn == 0)
           continue;
         const bool atomic = k == n_classes - 1;
-        s = (atomic && s_atomic && v.cell_ring) ? s_atomic : s_main;
+        s = (atomic && side) ? s_atomic : s_main;
         const dim3 grid((unsigned)((cn + cpb - 1) / cpb)), block(256);
 #define PFM_LAUNCH(DIM, FULLV, SPLITV)                                                                                       \
   do                                                                                                                         \
     {                                                                                                                        \
-      if (atomic)                                                                                                            \
+      if (atomic && DIM == 3 && !(SPLITV) && v.hs_K)                                                                         \
+        hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, false, true, false, false, DIM == 3>), grid, block, 0, s, v, p,    \
+                           vals, res_pde, res_tot, residual_only, c0, cn);                                                   \
+      else if (atomic)                                                                                                       \
         hipLaunchKernelGGL((k_assemble_general<DIM, FULLV, SPLITV, true>), grid, block, 0, s, v, p, vals, res_pde, res_tot,  \
                            residual_only, c0, cn);                                                                           \
       else if (v.cell_ring)                                                                                                  \

@@ -109,13 +109,18 @@ def test_overlay_rows_follow_a_bound_pattern():
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["default: scratch + ordered gather", "PFM_HANGING_COLOURED", "PFM_HANGING_ATOMIC"])
 @pytest.mark.parametrize("blocked", [True, False])
-def test_cells_at_hanging_vertices_in_plain_colour_classes_are_bitwise_reproducible(blocked, monkeypatch):
-    """PFM_HANGING_COLOURED=1 (read by pfm_ctx_create): the hexes at hanging vertices are coloured over their
-    constraint-resolved nodes and add without atomics (the element matrix and the residual are reduced to those nodes
-    first).  Same entries as the oracle, with the overlay and through the general family alone, heterogeneous material
-    included -- and two assemblies of the same state agree in every bit, which the class with FP64 atomics cannot promise."""
-    monkeypatch.setenv("PFM_HANGING_COLOURED", "1")
+def test_cells_at_hanging_vertices_modes(blocked, mode, monkeypatch):
+    """The three ways the hexes at hanging vertices reach the outputs (read by pfm_ctx_create):
+    default (round 6): their reduced element matrices / residuals go to per-cell scratch and k_hanging_gather adds them row
+    by row in list order; PFM_HANGING_COLOURED=1 (round 5): plain colour classes over the constraint-resolved nodes;
+    PFM_HANGING_ATOMIC=1: the class with FP64 atomics.  Same entries as the oracle in every mode, with the overlay and through
+    the general family alone, heterogeneous material included -- and in the first two, assemblies of the same state agree in
+    every bit, which the atomic class cannot promise."""
+    if mode.startswith("PFM_"):
+        monkeypatch.setenv(mode, "1")
+    bitwise = mode != "PFM_HANGING_ATOMIC"
     c = refined_block_case((12, 10, 12), blocked, het=True)
     ctx = make_context(c)
     assert ctx.kernel_path == 3
@@ -127,10 +132,12 @@ def test_cells_at_hanging_vertices_in_plain_colour_classes_are_bitwise_reproduci
         first = ctx.assemble_host(c.sol, c.old, c.oldold, False)
         for rep in range(3):
             again = ctx.assemble_host(c.sol, c.old, c.oldold, False)
-            for x, y in zip(first[0], again[0]):
-                assert np.array_equal(x, y)
-            assert np.array_equal(first[1], again[1])
+            if bitwise:
+                for x, y in zip(first[0], again[0]):
+                    assert np.array_equal(x, y)
+                assert np.array_equal(first[1], again[1])
         r1 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
         r2 = ctx.assemble_host(c.sol, c.old, c.oldold, True)
-        assert np.array_equal(r1[1], r2[1]) and np.array_equal(r1[2], r2[2])
+        if bitwise:
+            assert np.array_equal(r1[1], r2[1]) and np.array_equal(r1[2], r2[2])
     ctx.close()

@@ -2,10 +2,11 @@
 """One-off robustness run on the GPU box: (1) 200 Jacobian assemblies of the 3-D Sneddon 216^3 bench problem must
 leave bit-identical outputs and a stable amount of free device memory; (2) 60 context create/destroy cycles on a
 40^3 box must give the memory back.  `python tools/stress.py 64 general`: the same box forced onto the general family.
-`python tools/stress.py 24 hanging`: a 3-D box with a refined block (hanging nodes on its faces and edges): the cells at
-hanging vertices form the ATOMIC class of the general family (FP64 atomic adds, no fixed order) -- 100 assemblies, reports
-whether the outputs are bitwise equal run to run and, if not, the largest deviation relative to the row's largest entry.
-`PFM_HANGING_COLOURED=1 python tools/stress.py 24 hanging`: the same with those cells in plain colour classes (bitwise)."""
+`python tools/stress.py 24 hanging`: a 3-D box with a refined block (hanging nodes on its faces and edges) -- 100 assemblies,
+reports whether the outputs are bitwise equal run to run and, if not, the largest deviation relative to the row's largest
+entry.  Default since round 6: the cells at hanging vertices write scratch, k_hanging_gather adds in list order (bitwise).
+`PFM_HANGING_ATOMIC=1 python tools/stress.py 24 hanging`: the class with FP64 atomic adds of rounds 4-5 (no fixed order);
+`PFM_HANGING_COLOURED=1 ...`: those cells in plain colour classes (round 5, bitwise, some thirty small launches)."""
 import os
 import sys
 
