@@ -32,6 +32,7 @@
 #include "pfm_dma.h"
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -64,6 +65,7 @@ namespace pfm
       double pu[5][SLAB_PU]; // staged (phi,u) rows: [0,1] oz=-1 ring, [2,3] oz=0 ring, [4] oz=+1; [node][o9][d]
       double pp[5][SLAB_PP]; // staged (phi,phi) rows, same slabs; [node][o9]
       double ex[2][NPN][2];  // per node: placeholder sum, (u,u) placeholder patch
+      double rs[2][NPN];     // per node (RES): K_phiphi phi, pushed cell by cell (round 6)
     };
 
 
@@ -823,11 +825,12 @@ namespace pfm
         }
     }
 
-    template <bool HET>
+    template <bool HET, bool RESV>
     __device__ __forceinline__ void pp_role_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const MatScal &S,
                                                  double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
                                                  double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
-                                                 double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8])
+                                                 double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8],
+                                                 double (&Kphi)[8] /* RESV: sum_b K_phiphi[a][b] phi_b of this cell, by vertex a */)
     {
       double M[27]; // M[g_x + 3 g_y + 9 g_z]
 #pragma unroll
@@ -936,6 +939,9 @@ namespace pfm
 #pragma unroll
               for (int gy = 0; gy < 3; ++gy)
                 {
+                  // (S.lapM: 27 scalar loads, one round trip each, in the longest role of the workgroup.  Measured and not
+                  // kept, round 6: the 18 constants lapP / lapQ in one s_load batch (inline asm, 36 SGPRs) + 27 FMAs -- 10.53 ->
+                  // 10.70 ms per assembly, profiles/r06/ab_phi4_variants.txt: the scalar registers it pins cost more)
                   double mv = (R2[gx][gy][0] * G1Sx<0, 2 + g>::v + R2[gx][gy][1] * G1Sx<1, 2 + g>::v + R2[gx][gy][2] * G1Sx<2, 2 + g>::v) +
                               S.lapM[gx + 3 * gy + 9 * g];
                   asm volatile("" : "+v"(mv)); // finished here (pu_role_poly: not sunk into the vertex blocks with its operands)
@@ -961,6 +967,22 @@ namespace pfm
 #pragma unroll
       for (int a = 0; a < 8; ++a)
         Mdiag[a] = M[2 * (a & 1) + 3 * 2 * ((a >> 1) & 1) + 9 * 2 * (a >> 2)];
+      if constexpr (RESV)
+        {
+          // the cell's part of K_phiphi phi, from the moments in registers (round 6: the rows used to be read back from LDS
+          // behind the pushes -- a wait for the LDS queue of the whole workgroup in the middle of the longest role)
+          double Pf[8];
+          load_cell_field_raw(Ulo + 3 * NPH, Uhi + 3 * NPH, Pf);
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+            {
+              double acc = 0.0;
+#pragma unroll
+              for (int b = 0; b < 8; ++b)
+                acc = fma(M[((a & 1) + (b & 1)) + 3 * (((a >> 1) & 1) + ((b >> 1) & 1)) + 9 * ((a >> 2) + (b >> 2))], Pf[b], acc);
+              Kphi[a] = acc;
+            }
+        }
     }
 
     // =====================================================================================
@@ -1122,6 +1144,8 @@ namespace pfm
         (&s.pp[0][0])[i] = 0.0;
       for (int i = t; i < 2 * NPN * 2; i += NT4)
         (&s.ex[0][0][0])[i] = 0.0;
+      for (int i = t; i < 2 * NPN; i += NT4)
+        (&s.rs[0][0])[i] = 0.0;
       if (t < 4)
         s.anyflag[t] = 0;
       dma_plane(kA - 1, 0);
@@ -1131,7 +1155,6 @@ namespace pfm
       if (t < NPH && s.flag[(kA - 1) & 3][2 * t])
         s.anyflag[(kA - 1) & 3] = 1;
       int nst = 0;       // lower bound of the vector-memory instructions this wave has issued behind its last requests
-      double r_m1 = 0.0; // RES, wave 3, lane <-> node: the oz = -1 part of K_phiphi phi of the next plane
 #pragma unroll 1
       for (int ck = kA - 1; ck < kB; ++ck)
         {
@@ -1197,11 +1220,22 @@ namespace pfm
             pu(std::integral_constant<int, 2>{});
           else
             {
-              double Mdiag[8];
+              double Mdiag[8], Kphi[8];
+              // the flag bytes of the cell's vertices BEFORE the pushes: an LDS read behind them waits for the whole queue
+              unsigned anyflag = 0;
+              if (cell_ok)
+                {
+#pragma unroll
+                  for (int a = 0; a < 8; ++a)
+                    anyflag |= s.flag[(ck + (a >> 2)) & 3][2 * (hb + (a & 1) + PH * ((a >> 1) & 1))];
+                }
               if constexpr (OLDF)
                 pp_role<HET, true>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
               else
-                pp_role_poly<HET>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
+                pp_role_poly<HET, RES>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag, Kphi);
+              if constexpr (CLK == 2)
+                if (lane == 0)
+                  dbg[(size_t)blockIdx.x * 16 + 8] += (unsigned long long)(clock64() - tclk); // role 3: moments + pushes
               double avg = 0.0, patch = 0.0;
               if (cell_ok)
                 {
@@ -1210,14 +1244,12 @@ namespace pfm
                   // g(q) >= kappa > 0, so the (u,u) diagonal cannot vanish.
                   double dsum = 0.0;
                   bool zero_diag = false;
-                  unsigned anyflag = 0;
 #pragma unroll
                   for (int a = 0; a < 8; ++a)
                     {
                       const double dg = fabs(Mdiag[a]);
                       dsum += dg;
                       zero_diag = zero_diag || dg == 0.0;
-                      anyflag |= s.flag[(ck + (a >> 2)) & 3][2 * (hb + (a & 1) + PH * ((a >> 1) & 1))];
                     }
                   const bool g_positive = S.kappa > 0.0 && S.kappa <= 1.0;
                   if (anyflag != 0 && (zero_diag || !g_positive))
@@ -1291,53 +1323,14 @@ namespace pfm
                     double *ex = &s.ex[az == 0 ? cp : np][nl0 + ax + PN * ay][0];
                     lds_add(&ex[0], (dg != 0.0) ? dg : avg);
                     lds_add(&ex[1], patch);
+                    if constexpr (RES)
+                      if (cell_ok)
+                        lds_add(&s.rs[az == 0 ? cp : np][nl0 + ax + PN * ay], Kphi[ax + 2 * ay + 4 * az]);
                   }
               });
-              if constexpr (RES)
-                {
-                  // Phase-field rows of the residual from the (phi,phi) rows of the matrix: with the unclamped phase field
-                  // of the staggered scheme every term of cracks.cc:2412-2431 but -G_c/eps N_a is the matching term of
-                  // cracks.cc:2370-2383 times phi_b, i.e.  R_phi = G_c/eps sum_q N_a JxW - K_phiphi phi  (UNMASKED rows).
-                  // All (phi,phi) pushes come from this wave, so its staged rows are complete here without a barrier;
-                  // lane <-> node; the oz = -1 part of a plane is formed one step earlier, while phi of the plane below is
-                  // still in the ring, and carried in a register.
-                  int lq = lane;
-                  asm volatile("" : "+v"(lq));
-                  const int nl = min(lq, NPN - 1), nx = nl % PN, ny = nl / PN, hn = (nx + 1) + PH * (ny + 1);
-                  const double *phi_lo = &s.U[lo][3][hn], *phi_hi = &s.U[hi][3][hn];
-                  if (ck >= kA)
-                    {
-                      double sum = r_m1;
-                      const double *z0 = s.pp[2 + cp] + nl * 9, *p1 = s.pp[4] + nl * 9;
-#pragma unroll
-                      for (int o9 = 0; o9 < 9; ++o9)
-                        {
-                          const int nb = (o9 % 3 - 1) + PH * (o9 / 3 - 1);
-                          sum = fma(z0[o9], phi_lo[nb], sum);
-                          sum = fma(p1[o9], phi_hi[nb], sum);
-                        }
-                      const long long off = s.off[cp][nl];
-                      if (lq < NPN && off >= 0)
-                        {
-                          const int gi = i0 + nx, gj = j0 + ny;
-                          const int ncell = ((gi > 0) + (gi < cv.NX - 1)) * ((gj > 0) + (gj < cv.NY - 1)) * ((ck > 0) + (ck < cv.NZ - 1));
-                          const double mass = S.gc_eps * (S.vol * 0.125) * (double)ncell;
-                          const bool con = (s.flag[ck & 3][2 * hn] >> 3) & 1u;
-                          const int row = cart_local_id(cv, gi, gj, ck);
-                          const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + 3 : (long long)v.n_owned * 3 + row;
-                          res_pde[di] = con ? 0.0 : mass - sum;
-                        }
-                    }
-                  if (ck + 1 < kB)
-                    {
-                      const double *m1 = s.pp[np] + nl * 9;
-                      double sum = 0.0;
-#pragma unroll
-                      for (int o9 = 0; o9 < 9; ++o9)
-                        sum = fma(m1[o9], phi_lo[(o9 % 3 - 1) + PH * (o9 / 3 - 1)], sum);
-                      r_m1 = sum;
-                    }
-                }
+              if constexpr (CLK == 2)
+                if (lane == 0)
+                  dbg[(size_t)blockIdx.x * 16 + 9] += (unsigned long long)(clock64() - tclk); // ... + placeholders
             }
           if constexpr (CLK == 2)
             {
@@ -1555,6 +1548,27 @@ namespace pfm
                   s.ex[cp][nl][0] = 0.0;
                   s.ex[cp][nl][1] = 0.0;
                   const long long off = s.off[cp][nl];
+                  if constexpr (RES)
+                    {
+                      // Phase-field rows of the residual from the (phi,phi) entries: with the unclamped phase field of the
+                      // staggered scheme every term of cracks.cc:2412-2431 but -G_c/eps N_a is the matching term of
+                      // cracks.cc:2370-2383 times phi_b, i.e.  R_phi = G_c/eps sum_q N_a JxW - K_phiphi phi  (UNMASKED entries),
+                      // K_phiphi phi summed cell by cell in the order of the pushes (s.rs)
+                      const double sum = s.rs[cp][nl];
+                      s.rs[cp][nl] = 0.0;
+                      if (off >= 0)
+                        {
+                          const int nx = nl % PN, ny = nl / PN, hn = (nx + 1) + PH * (ny + 1);
+                          const int gi = i0 + nx, gj = j0 + ny;
+                          const int ncell = ((gi > 0) + (gi < cv.NX - 1)) * ((gj > 0) + (gj < cv.NY - 1)) * ((ck > 0) + (ck < cv.NZ - 1));
+                          const double mass = S.gc_eps * (S.vol * 0.125) * (double)ncell;
+                          const bool con = (s.flag[ck & 3][2 * hn] >> 3) & 1u;
+                          // (a look-up is waited for inside its arm: cart_local_id_sync)
+                          const int row = all_lex ? (int)lex_id(gi, gj, ck) : cart_local_id_sync(cv, gi, gj, ck);
+                          const long long di = (v.layout == PFM_LAYOUT_INTERLEAVED) ? (long long)row * 4 + 3 : (long long)v.n_owned * 3 + row;
+                          res_pde[di] = con ? 0.0 : mass - sum;
+                        }
+                    }
                   if (masked && off >= 0 && patch != 0.0)
                     {
                       // constrained displacement rows whose element diagonal vanished in some cell
@@ -1678,6 +1692,8 @@ namespace pfm
         for (int i = 0; i < 4; ++i)
           fprintf(stderr, " role%d=%.0f", i, (double)h[4 + i] / nb);
         fprintf(stderr, " request-next=%.0f copy-loop=%.0f copy-barrier=%.0f", (double)h[10] / nb, (double)h[8] / nb, (double)h[9] / nb);
+        if (atoi(getenv("PFM_PHI_CLK")) == 2)
+          fprintf(stderr, " | role 3 up to: moments+pushes=%.0f placeholders=%.0f", (double)h[8] / nb, (double)h[9] / nb);
         fprintf(stderr, "\n");
       }
     else if (res)
