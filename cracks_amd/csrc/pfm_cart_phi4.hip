@@ -1319,10 +1319,15 @@ namespace pfm
                 const int hx = cx + ax, hy = cy + ay;
                 if ((az == 0 ? dst.push_lo : dst.push_hi) && hx >= 1 && hx <= PN && hy >= 1 && hy <= PN)
                   {
-                    const double dg = fabs(Mdiag[ax + 2 * ay + 4 * az]);
-                    double *ex = &s.ex[az == 0 ? cp : np][nl0 + ax + PN * ay][0];
-                    lds_add(&ex[0], (dg != 0.0) ? dg : avg);
-                    lds_add(&ex[1], patch);
+                    // (the placeholder sums are read for rows with a constraint flag only: a cell none of whose vertices
+                    // carries one -- nearly all of them -- has nothing to add)
+                    if (anyflag != 0)
+                      {
+                        const double dg = fabs(Mdiag[ax + 2 * ay + 4 * az]);
+                        double *ex = &s.ex[az == 0 ? cp : np][nl0 + ax + PN * ay][0];
+                        lds_add(&ex[0], (dg != 0.0) ? dg : avg);
+                        lds_add(&ex[1], patch);
+                      }
                     if constexpr (RES)
                       if (cell_ok)
                         lds_add(&s.rs[az == 0 ? cp : np][nl0 + ax + PN * ay], Kphi[ax + 2 * ay + 4 * az]);

@@ -589,12 +589,10 @@ namespace pfm
               if (it > 0)
                 {
                   stamp6(-1);
-                  // stores of this wave since its requests, on a regular tile: at least 2 per row component in waves 5, 6
-                  // (their third position lies outside the tile), 3 in wave 7 (two pair stores, the single values)
+                  // stores of this wave since its requests, on a regular tile: at least 2 per row component in waves 5, 6, 7
+                  // (their third position lies outside the tile; the single values are wave 0's since round 6)
                   if (!regular_prev)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                  else if (wave == 7)
-                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                   else
                     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                   stamp6(0);
@@ -928,7 +926,7 @@ namespace pfm
                   // with 16 bytes per lane), and since the barrier of a component waits for the copy-out of the last one in
                   // EVERY wave, that time is on the critical path of the plane (phase clock: 1.3k of the 3.4k cycles of a
                   // component).  thread <-> (node group g < 12, element pair ep < 40): nodes g, g + 12, g + 24, the pairs
-                  // (2 ep, 2 ep + 1) of their 81 staged values; threads 480..511: the 81st value of node t - 480.  No
+                  // (2 ep, 2 ep + 1) of their 81 staged values; threads 0..31: the 81st value of node t (the pairs start at thread 32).  No
                   // division per position, every read in flight before the first store.
                   struct __attribute__((packed, aligned(8))) D2
                   {
@@ -937,9 +935,11 @@ namespace pfm
                   constexpr int NG = 12, NIT = 3;
                   int tq = t;
                   asm volatile("" : "+v"(tq)); // (g, ep) are recomputed per component, not kept live across the node phases
-                  if (tq < NG * 40)
+                  // (round 6: the 32 single values go with wave 0, whose slot set is the lightest, instead of wave 7, whose is
+                  // the heaviest -- the wave that runs both arms of this branch was the one every barrier waited for)
+                  if (tq >= 32)
                     {
-                      const int g = tq / 40, ep = tq - g * 40;
+                      const int pq = tq - 32, g = pq / 40, ep = pq - g * 40;
                       long long rb[NIT];
                       D2 val[NIT];
 #pragma unroll
@@ -958,7 +958,7 @@ namespace pfm
                     }
                   else
                     {
-                      const int nl = tq - NG * 40;
+                      const int nl = tq;
                       vals[rowbase[nl] + (c * STG + STG - 1)] = stage[nl * STG + STG - 1];
                     }
                 }
