@@ -1629,7 +1629,9 @@ namespace pfm
     const int ntx = (OWX + PN - 1) / PN, nty = (OWY + PN - 1) / PN;
     // z-chunks: one extra cell layer per chunk is recomputed; keep that below ~4 % while filling the chip
     static const int zc_force = getenv("PFM_PHI_ZC") ? atoi(getenv("PFM_PHI_ZC")) : 0; // tuning only
-    const int zc_abs = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 6, 25, 2);
+    // (round 6: chunks of up to 48 planes as in k_cart_uu3 -- at 216^3 the model picks 31 = 217 / 7, seven equal chunks per
+    // column instead of ten of 22 with a short last one: 10.7 -> 10.4 ms per assembly, profiles/r06/zc_scan.txt)
+    const int zc_abs = zc_force > 0 ? zc_force : choose_zchunk((long long)ntx * nty, OWZ, 6, 48, 2);
     const int nch = (OWZ + zc_abs - 1) / zc_abs;
     static const bool no_prio = getenv("PFM_NO_PRIO") != nullptr; // A/B runs only
     const int zc = no_prio ? -zc_abs : zc_abs;

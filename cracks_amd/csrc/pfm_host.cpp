@@ -3912,7 +3912,9 @@ extern "C"
         // 3-D overlay Jacobian: the class of the cells at hanging vertices (FP64 atomics, 4.7 of the general family's 6 ms at
         // 1.1e6 cells) on a third stream next to the plain classes (DevView::cell_ring makes that safe)
         hipStream_t s_atomic = nullptr;
-        if (overlay3 && fork_general && !residual_only && (c->v.cell_ring || gather) && c->n_general_cells > 0)
+        // (PFM_HANGING_COLOURED: a hanging cell in a plain class adds to its PARENTS' rows without atomics; should a cell with
+        // more than 16 resolved nodes ever sit in the atomic class next to it, that class must not run beside the plain ones)
+        if (overlay3 && fork_general && !residual_only && (c->v.cell_ring || gather) && c->n_general_cells > 0 && !c->hanging_coloured)
           {
             int prio_lo = 0, prio_hi = 0; // (numerically lower = higher priority) the long pole gets its workgroups dispatched first
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -3945,7 +3947,7 @@ extern "C"
         else
           vg.hs_K = nullptr, vg.hs_off = nullptr, vg.hs_RD = nullptr;
         rc = launch_assemble_general(vg, c->prm, residual_only, d_values, d_res_pde, d_res_tot, c->stream, c->color_ptr,
-                                     fork_general ? c->side_stream : nullptr);
+                                     (fork_general && !c->hanging_coloured) ? c->side_stream : nullptr);
       }
     if (fork_general)
       {
