@@ -146,7 +146,14 @@ python tools/stress.py 216 > $O/stress_216.txt 2>&1
 python tools/stress.py 64 general > $O/stress_64_general.txt 2>&1
 python tools/stress.py 24 hanging > $O/stress_24_hanging.txt 2>&1
 PFM_HANGING_COLOURED=1 python tools/stress.py 24 hanging > $O/stress_24_hanging_coloured.txt 2>&1
+PFM_HANGING_ATOMIC=1 python tools/stress.py 24 hanging > $O/stress_24_hanging_atomic.txt 2>&1
 PFM_CTX_TIMING=1 python tools/ctx_timing.py c5 > $O/ctx_timing_config5.txt 2>&1
 PFM_CTX_TIMING=1 python tools/ctx_timing.py 216 > $O/ctx_timing_216cube.txt 2>&1
-PFM_HANGING_COLOURED=1 python -c "import json, torch, bench; print(json.dumps(bench.overlay_3d(torch.device('cuda:0'), 0, 8)))" > $O/overlay3d_hanging_coloured.json 2>/dev/null
-for w in 2 8; do python tools/bench_extra.py rank --world $w --out $O/rank_share_w$w.json > /dev/null 2>&1; done
+# round 6: the three modes of the 3-D cells at hanging vertices on the overlay bench mesh, phase clocks of the Jacobian pair
+for e in "A=default" "PFM_HANGING_ATOMIC=1" "PFM_HANGING_COLOURED=1"; do echo "$e $(env $e python tools/ov3_time.py 10 2>/dev/null | tail -1)"; done > $O/overlay3d_hanging_modes.txt
+bash tools/kst.sh gpurun_out/$TAG/overlay3d_kernel_stats_sequential.txt PFM_GENERAL_SEQUENTIAL=1 -- python $R/tools/overlay3d_profile.py
+cd $R
+for m in 1 2; do PFM_PHI_CLK=$m python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | grep "phase clock" | tail -1; done > $O/phase_clock_k_cart_phi4.txt
+PFM_UU_CLK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | grep "phase clock" | tail -3 > $O/phase_clock_k_cart_uu3.txt
+bash tools/ab.sh "A=pair" "PFM_JAC_SEQUENTIAL=1" "A=pair" "PFM_JAC_SEQUENTIAL=1" > $O/ab_pair_vs_sequential.txt 2>&1
+(cd tools/microbench && [ -x ./fill ] && timeout 300 ./fill 32 > $O/microbench_fill_policies.txt 2>&1)
