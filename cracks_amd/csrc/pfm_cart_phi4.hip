@@ -830,7 +830,8 @@ namespace pfm
                                                  double cell_lam, double cell_mu, bool cell_ok, const PushDst &dst, double *__restrict__ pp_lo_z0,
                                                  double *__restrict__ pp_lo_p1, double *__restrict__ pp_hi_m1,
                                                  double *__restrict__ pp_hi_z0, int nl0, int cx, int cy, double (&Mdiag)[8],
-                                                 double (&Kphi)[8] /* RESV: sum_b K_phiphi[a][b] phi_b of this cell, by vertex a */)
+                                                 double (&Kphi)[8] /* RESV: sum_b K_phiphi[a][b] phi_b of this cell, by vertex a */,
+                                                 double lap_lane /* MatScal::lapM[lane] in lane < 27 */)
     {
       double M[27]; // M[g_x + 3 g_y + 9 g_z]
 #pragma unroll
@@ -939,11 +940,15 @@ namespace pfm
 #pragma unroll
               for (int gy = 0; gy < 3; ++gy)
                 {
-                  // (S.lapM: 27 scalar loads, one round trip each, in the longest role of the workgroup.  Measured and not
-                  // kept, round 6: the 18 constants lapP / lapQ in one s_load batch (inline asm, 36 SGPRs) + 27 FMAs -- 10.53 ->
-                  // 10.70 ms per assembly, profiles/r06/ab_phi4_variants.txt: the scalar registers it pins cost more)
+                  // MatScal::lapM[m] out of lane m of a register that wave 3 loaded once (v_readlane: two VALU instructions,
+                  // no memory).  Read as S.lapM[m] these were 27 scalar loads with a wait each -- 27 scalar-cache round trips in
+                  // a row, ~3.7k cycles per step in the longest role of the workgroup (phase clock, round 6).  (The 18
+                  // constants they are made of in one inline-asm s_load batch: measured, +0.17 ms -- 36 pinned scalar registers.)
+                  const int lm = gx + 3 * gy + 9 * g;
+                  const double lapm = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lap_lane), lm),
+                                                       __builtin_amdgcn_readlane(__double2loint(lap_lane), lm));
                   double mv = (R2[gx][gy][0] * G1Sx<0, 2 + g>::v + R2[gx][gy][1] * G1Sx<1, 2 + g>::v + R2[gx][gy][2] * G1Sx<2, 2 + g>::v) +
-                              S.lapM[gx + 3 * gy + 9 * g];
+                              lapm;
                   asm volatile("" : "+v"(mv)); // finished here (pu_role_poly: not sunk into the vertex blocks with its operands)
                   M[gx + 3 * gy + 9 * g] = mv;
                 }
@@ -1006,6 +1011,8 @@ namespace pfm
       const bool PRIO = zc_in > 0;
       const int zc = zc_in < 0 ? -zc_in : zc_in;
       const MatScal &S = *Sp; // per-launch scalars live in device memory: loaded where used, not pinned in SGPRs
+      // the 27 Laplace moments, one per lane (pp_role_poly reads lane m with v_readlane): a vector load before any store
+      const double lap_lane = Sp->lapM[(threadIdx.x & 63) < 27 ? (threadIdx.x & 63) : 0];
       long long tclk = 0;
       auto stamp = [&](int phase) __attribute__((always_inline)) {
         if constexpr (CLK == 1)
@@ -1232,7 +1239,8 @@ namespace pfm
               if constexpr (OLDF)
                 pp_role<HET, true>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag);
               else
-                pp_role_poly<HET, RES>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag, Kphi);
+                pp_role_poly<HET, RES>(Ulo, Uhi, S, lam, mu, cell_ok, dst, s.pp[2 + cp], s.pp[4], s.pp[np], s.pp[2 + np], nl0, cx, cy, Mdiag, Kphi,
+                                       lap_lane);
               if constexpr (CLK == 2)
                 if (lane == 0)
                   dbg[(size_t)blockIdx.x * 16 + 8] += (unsigned long long)(clock64() - tclk); // role 3: moments + pushes
