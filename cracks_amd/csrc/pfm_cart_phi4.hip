@@ -61,6 +61,7 @@ namespace pfm
       int deg[2][NPN];       // neighbour mask of the row (bit o: lattice offset o exists)
       unsigned flag[4][2 * NPH]; // constraint flag byte of the halo nodes of 4 planes, one dword per requesting lane: node hn at [2 hn]
       int irregular[2];
+      int incomplete[2];     // by plane parity: some row of the tile is not a row of this launch or has fewer than 27 neighbours
       int anyflag[4];
       double pu[5][SLAB_PU]; // staged (phi,u) rows: [0,1] oz=-1 ring, [2,3] oz=0 ring, [4] oz=+1; [node][o9][d]
       double pp[5][SLAB_PP]; // staged (phi,phi) rows, same slabs; [node][o9]
@@ -1183,6 +1184,7 @@ namespace pfm
             {
               s.anyflag[(ck + 1) & 3] = 0;
               s.irregular[cp] = 0;
+              s.incomplete[cp] = 0;
             }
           lds_barrier();
           stamp(0);
@@ -1190,6 +1192,8 @@ namespace pfm
             s.anyflag[(ck + 1) & 3] = 1;
           if (ck >= kA && t >= 128 && t < 128 + NPN && s.off[cp][t - 128] >= 0 && s.deg[cp][t - 128] != 0x7ffffff)
             s.irregular[cp] = 1;
+          if (ck >= kA && t >= 128 && t < 128 + NPN && (s.off[cp][t - 128] < 0 || ((unsigned)s.deg[cp][t - 128] & 0x7ffffffu) != 0x7ffffffu))
+            s.incomplete[cp] = 1;
 
           // ---- entries of layer ck, pushed into the rows of planes ck (lower vertices) and ck+1 (upper vertices)
           if (PRIO)
@@ -1384,6 +1388,7 @@ namespace pfm
           if (ck >= kA)
             {
               const bool regular = s.irregular[cp] == 0;
+              const bool regular_or_permuted = s.incomplete[cp] == 0; // every row of the tile present with its 27 neighbours, in any order
               const bool masked = (s.anyflag[(ck - 1) & 3] | s.anyflag[ck & 3] | s.anyflag[(ck + 1) & 3]) != 0;
               double *pu_m1 = s.pu[cp], *pu_z0 = s.pu[2 + cp], *pu_p1 = s.pu[4];
               double *pp_m1 = s.pp[cp], *pp_z0 = s.pp[2 + cp], *pp_p1 = s.pp[4];
@@ -1456,6 +1461,93 @@ namespace pfm
                       if (actp)
                         {
                           bpp[up] = val[ny][3];
+                          spp[ny * (PN * 9)] = 0.0;
+                        }
+                    }
+                  nst = 4 * PN;
+                }
+              else if (NCOL == 3 && regular_or_permuted && !masked && tile_full)
+                {
+                  // Round 6: rows that are COMPLETE (27 neighbours, no constraint flag near the plane) but whose CSR slots are a
+                  // permutation of the lattice order and / or not contiguous from node to node -- every interior tile of a level
+                  // lattice of the 3-D overlay, and of any box whose pattern the host bound in its own column order (deal.II
+                  // numbers its dofs hierarchically: pfm_pattern_bind).  The thread <-> position mapping, the LDS reads and the
+                  // store count of the blocked path above; only the destination of a value is looked up: row offset and mask
+                  // from LDS, the slot of lattice offset o from CartView::row_perm -- all look-ups of a plane first, then its
+                  // stores (a load behind a store waits for the store: vmcnt counts in order).  The generic path below costs
+                  // the kernel 31 % when it is forced on every tile.
+                  int tq = t;
+                  asm volatile("" : "+v"(tq));
+                  const bool act2 = tq < PN * 81 - 2 * NT4;
+                  const int gp = tq - 64;
+                  const bool actp = gp >= 0 && gp < PN * 27;
+                  double *spu[3];
+                  int nxq[3], oq[3], dq[3];
+#pragma unroll
+                  for (int q = 0; q < 3; ++q)
+                    {
+                      const int f = (q < 2 || act2) ? tq + NT4 * q : 0;
+                      const int nx = f / 81, e = f - nx * 81;
+                      const int o = e / 3, d = e - 3 * o;
+                      const int oz = o / 9, o9 = o - 9 * oz;
+                      spu[q] = (oz == 0 ? pu_m1 : (oz == 1 ? pu_z0 : pu_p1)) + (nx * 27 + o9 * 3 + d);
+                      nxq[q] = nx, oq[q] = o, dq[q] = d;
+                    }
+                  double *spp;
+                  int nxp, op;
+                  {
+                    const int g = actp ? gp : 0;
+                    const int nx = g / 27, o = g - nx * 27;
+                    const int oz = o / 9, o9 = o - 9 * oz;
+                    spp = (oz == 0 ? pp_m1 : (oz == 1 ? pp_z0 : pp_p1)) + (nx * 9 + o9);
+                    nxp = nx, op = o;
+                  }
+                  double val[PN][4];
+                  long long dpu[PN][3], dpp[PN];
+#pragma unroll
+                  for (int ny = 0; ny < PN; ++ny)
+                    {
+#pragma unroll
+                      for (int q = 0; q < 3; ++q)
+                        {
+                          const int row = ny * PN + nxq[q];
+                          const long long off = s.off[cp][row];
+                          int slot = oq[q];
+                          if (((unsigned)s.deg[cp][row] >> 31) && (q < 2 || act2))
+                            slot = cv.row_perm[off + slot];
+                          dpu[ny][q] = 3 * off + 3 * slot + dq[q];
+                        }
+                      {
+                        const int row = ny * PN + nxp;
+                        const long long off = s.off[cp][row];
+                        int slot = op;
+                        if (((unsigned)s.deg[cp][row] >> 31) && actp)
+                          slot = cv.row_perm[off + slot];
+                        dpp[ny] = off + slot;
+                      }
+                      val[ny][0] = spu[0][ny * (PN * 27)];
+                      val[ny][1] = spu[1][ny * (PN * 27)];
+                      val[ny][2] = act2 ? spu[2][ny * (PN * 27)] : 0.0;
+                      val[ny][3] = actp ? spp[ny * (PN * 9)] : 0.0;
+                    }
+#pragma unroll
+                  for (int ny = 0; ny < PN; ++ny)
+                    {
+                      vals_pu[dpu[ny][0]] = val[ny][0];
+                      vals_up[dpu[ny][0]] = 0.0;
+                      vals_pu[dpu[ny][1]] = val[ny][1];
+                      vals_up[dpu[ny][1]] = 0.0;
+                      spu[0][ny * (PN * 27)] = 0.0; // these slabs are the next planes' accumulators
+                      spu[1][ny * (PN * 27)] = 0.0;
+                      if (act2)
+                        {
+                          vals_pu[dpu[ny][2]] = val[ny][2];
+                          vals_up[dpu[ny][2]] = 0.0;
+                          spu[2][ny * (PN * 27)] = 0.0;
+                        }
+                      if (actp)
+                        {
+                          vals_pp[dpp[ny]] = val[ny][3];
                           spp[ny * (PN * 9)] = 0.0;
                         }
                     }
