@@ -96,6 +96,23 @@ def test_refined_block_with_heterogeneous_material_and_monolithic_scheme():
     ctx.close()
 
 
+def test_complete_rows_in_permuted_slots_take_the_blocked_copy_out():
+    """Round 6: interior tiles of a level lattice whose rows are complete (27 neighbours, no constraint flag near the plane)
+    but sit in the AMR mesh's own order go through k_cart_phi4's blocked copy-out with looked-up destinations.  No active
+    set here, so that such tiles exist (16 coarse cells per direction: the fine lattice has 33 nodes, four full tiles of 7 with
+    a margin to the seam); every entry against the oracle, canonical and bound pattern."""
+    from test_gpu_pattern import _permuted_patterns
+
+    c = refined_block_case((16, 16, 16), True, active=False)
+    ctx = make_context(c)
+    assert ctx.kernel_path == 3
+    check_against_oracle(c, ctx)
+    for b, (rp, ci, _) in enumerate(_permuted_patterns(ctx, 3, True, seed=11)):
+        ctx.pattern_bind(b, rp, ci)
+    check_against_oracle(c, ctx)
+    ctx.close()
+
+
 def test_overlay_rows_follow_a_bound_pattern():
     """pfm_pattern_bind with shuffled rows: the CSR slots of the regular rows are looked up again in the bound order."""
     from test_gpu_pattern import _permuted_patterns
