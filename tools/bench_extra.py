@@ -353,9 +353,75 @@ def rank_share(args):
                   open(os.path.join(ROOT, args.out), "w"), indent=1)
 
 
+def bound_pattern(args):
+    """What a host with its own column order pays (deal.II numbers its dofs hierarchically; Epetra's local CSR is sorted by ITS
+    local column ids): the uniform box of `--n`^3 cells assembled into the library's canonical pattern, then into the same
+    pattern with the neighbour nodes of every row shuffled (pfm_pattern_bind).  Rows are complete but their slots are a
+    permutation of the lattice order: k_cart_phi4 takes its blocked copy-out with looked-up destinations (round 6),
+    k_cart_uu3 its generic one.  The sums of the values of every block must agree (a permutation within rows)."""
+    import torch
+
+    import bench
+    from cracks_amd import partition as P
+    from cracks_amd.assembler import Assembler
+
+    n = args.n
+    lp = P.build_local_problem(3, (n,) * 3, (1, 1, 1), 0)
+    h = (20.0 / n) * np.sqrt(3.0)
+    u, phi, po, poo, flags = bench.synthetic_state(lp.mesh, lp.global_ids, h, 3)
+    asm = Assembler(lp.mesh, blocked=True, n_owned_nodes=lp.n_owned)
+    asm.set_params(bench.sneddon_params(h, 3))
+    asm.set_constraints(flags)
+    no = lp.n_owned
+    pack = lambda uu, pp: np.concatenate([uu[:no].reshape(-1), pp[:no]])
+    asm.set_vectors(pack(u, phi), pack(np.zeros_like(u), po), pack(np.zeros_like(u), poo))
+    dev = asm.dev
+
+    def measure():
+        wall, k_ms = bench.time_mode(asm, dev, False, args.steps, 3)
+        sums = [float(m.sum()) for m in asm.system_pde_matrix] + [float(m.abs().sum()) for m in asm.system_pde_matrix]
+        return wall, k_ms, sums
+
+    w0, k0, s0 = measure()
+    rng = np.random.default_rng(5)
+    ctx = asm.ctx
+    order = None
+    t0 = time.perf_counter()
+    canonical = [ctx.pattern(b) for b in range(4)]  # (all four before the first bind: a bound order shows in every block)
+    bound = []
+    for b in range(4):
+        ncr, ncc = (3 if b in (0, 1) else 1), (3 if b in (0, 2) else 1)
+        rp, ci = canonical[b]
+        deg = (np.diff(rp)[::ncr] // ncc).astype(np.int64)
+        node_ptr = np.concatenate([[0], np.cumsum(deg)])
+        if order is None:  # one shuffle of the neighbour nodes per row node, the same in every block and row component
+            node_of_slot = np.repeat(np.arange(no, dtype=np.int64), deg)
+            order = np.lexsort((rng.random(node_ptr[-1]), node_of_slot)) - node_ptr[node_of_slot]  # source slot of new slot j
+        new_ci = np.empty_like(ci)
+        for c in range(ncr):
+            start = rp[np.arange(no) * ncr + c].astype(np.int64)  # first entry of row (node, c)
+            src = (np.repeat(start, deg) + order * ncc)  # first entry of the source slot, per (node, new slot)
+            dst = (np.repeat(start, deg) + (np.arange(node_ptr[-1]) - node_ptr[np.repeat(np.arange(no), deg)]) * ncc)
+            for k in range(ncc):
+                new_ci[dst + k] = ci[src + k]
+        bound.append((rp, new_ci))
+    for b, (rp, new_ci) in enumerate(bound):
+        ctx.pattern_bind(b, rp, new_ci)
+    t_bind = time.perf_counter() - t0
+    w1, k1, s1 = measure()
+    ok = all(abs(a - b) <= 1e-9 * max(1.0, abs(a), abs(b)) for a, b in zip(s0, s1))
+    rec = {"workload": f"Sneddon 3D, {n}^3 cells, Jacobian + residual, canonical pattern against a bound pattern with shuffled rows",
+           "canonical": {"ms_per_call": w0, "kernel_ms": k0}, "bound_shuffled": {"ms_per_call": w1, "kernel_ms": k1},
+           "ratio": k1 / k0, "block_sums_agree": ok, "shuffle_and_bind_s_python": round(t_bind, 1)}
+    print(json.dumps(rec))
+    if args.out:
+        json.dump(rec, open(args.out, "w"), indent=1)
+    assert ok, (s0, s1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["config5", "pcie", "rank"])
+    ap.add_argument("what", choices=["config5", "pcie", "rank", "bound"])
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--levels", type=int, default=7)
     ap.add_argument("--meshes", type=int, default=5)
@@ -368,4 +434,4 @@ if __name__ == "__main__":
     if a.what == "config5" and (a.dist or int(os.environ.get("WORLD_SIZE", "1")) > 1):
         config5_dist(a)
     else:
-        {"config5": config5, "pcie": pcie, "rank": rank_share}[a.what](a)
+        {"config5": config5, "pcie": pcie, "rank": rank_share, "bound": bound_pattern}[a.what](a)
