@@ -99,7 +99,7 @@ def measured_hbm_traffic(dim: int, n: int, residual_only: bool):
         return None, src
     total = 0.0
     for name, d in rec["per_launch"].items():
-        if residual_only and name not in ("k_cart_residual3", "k_cart_residual2m", "k_state_set", "k_state_set_solution"):
+        if residual_only and name not in ("k_cart_residual3", "k_cart_residual3d", "k_cart_residual3x", "k_cart_residual2m", "k_state_set", "k_state_set_solution"):
             continue
         total += d.get("write_bytes", 0.0) + d.get("fetch_bytes", 0.0)
     return total, src

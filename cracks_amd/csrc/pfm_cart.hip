@@ -26,6 +26,7 @@
 // oracle is at round-off level (tests/test_gpu_parity.py, tolerance 1e-12).
 #include "pfm_internal.h"
 #include "pfm_poly.h"
+#include "pfm_dma.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -578,15 +579,30 @@ namespace pfm
     // H_g needs the 27 q-point values of pfx^2 (interpolate, clamp, square: the only thing evaluated at q-points) and a
     // three-stage contraction (243 FMAs); H_Theta comes from the 27 coefficients of Theta and the integrals of t^n (the 3-point
     // rule is exact up to t^5).  ~1500 instead of ~4000 instructions per cell; the sums are the reference's, regrouped.
-    __device__ __forceinline__ void residual_cell_poly(const double *__restrict__ Ulo, const double *__restrict__ Uhi, const Scal &S,
+    // PL: plane stride of a field in LDS.  RAW45: fields 4 and 5 hold the two old phase fields as they lie in memory (the
+    // planes of k_cart_residual3d arrive without passing through registers): the combination is formed here, per vertex
+    // LY: where the six fields of a nodal plane lie in LDS, relative to the cell's (0,0) vertex -- LY::off(f) doubles from
+    // Ulo_u / Uhi_u (displacements) or Ulo_s / Uhi_s (phase fields), LY::xs(f) / LY::ys(f) to the next node along x / y
+    template <int PL>
+    struct PlaneSoA // k_cart_residual3, k_cart_residual3d: six planes of RHX x RHY doubles, PL apart
+    {
+      static constexpr int off(int f) { return f * PL; }
+      static constexpr int xs(int) { return 1; }
+      static constexpr int ys(int) { return RHX; }
+    };
+    template <class LY, bool RAW45>
+    __device__ __forceinline__ void residual_cell_poly(const double *__restrict__ Ulo_u, const double *__restrict__ Uhi_u,
+                                                       const double *__restrict__ Ulo_s, const double *__restrict__ Uhi_s, const Scal &S,
                                                        double lam, double mu, double (&M)[2][2][2][4])
     {
       const double c_g = S.c_g, c_r2 = S.c_r2, c_r3 = S.c_r3, vol = S.vol;
       const double(&ih)[3] = S.ih;
       const double(&vih)[3] = S.vih;
       auto load8 = [&](int f, double (&a)[8]) __attribute__((always_inline)) {
-        a[0] = Ulo[f * RPL], a[1] = Ulo[f * RPL + 1], a[2] = Ulo[f * RPL + RHX], a[3] = Ulo[f * RPL + RHX + 1];
-        a[4] = Uhi[f * RPL], a[5] = Uhi[f * RPL + 1], a[6] = Uhi[f * RPL + RHX], a[7] = Uhi[f * RPL + RHX + 1];
+        const double *lo = (f < 3 ? Ulo_u : Ulo_s) + LY::off(f), *hi = (f < 3 ? Uhi_u : Uhi_s) + LY::off(f);
+        const int xs = LY::xs(f), ys = LY::ys(f);
+        a[0] = lo[0], a[1] = lo[xs], a[2] = lo[ys], a[3] = lo[ys + xs];
+        a[4] = hi[0], a[5] = hi[xs], a[6] = hi[ys], a[7] = hi[ys + xs];
       };
       auto Madd = [&](auto Psi, auto Cc, double x) __attribute__((always_inline)) {
         constexpr int psi = decltype(Psi)::value, c = decltype(Cc)::value;
@@ -601,6 +617,14 @@ namespace pfm
       {
         double W[8];
         load8(4, W); // LIN: the combined old field (load_plane)
+        if constexpr (RAW45)
+          {
+            double W5[8];
+            load8(5, W5);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              W[i] = S.use_old ? W[i] : W5[i] + S.tfac * (W[i] - W5[i]); // as store_node of k_cart_residual3 forms it
+          }
         monomials(W);
         double Pq[27];
         poly_for<3>([&](auto Qx) __attribute__((always_inline)) {
@@ -971,7 +995,7 @@ namespace pfm
                 }
               const double mu2 = 2 * mu;
               if constexpr (LIN)
-                residual_cell_poly(Ulo, Uhi, S, lam, mu, M);
+                residual_cell_poly<PlaneSoA<RPL>, false>(Ulo, Uhi, Ulo, Uhi, S, lam, mu, M);
               double Dy0[4], dDy[4]; // d/dy at x-vertex 0 and its x-difference: depend on the z-level only
 #pragma unroll 1
               for (int p = 0; p < (LIN ? 0 : 9); ++p)
@@ -1190,6 +1214,409 @@ namespace pfm
         }
     }
 
+
+    // =====================================================================================
+    // Round 6: k_cart_residual3 <LIN> with the nodal planes requested TWO steps ahead (pfm_dma.h: global -> LDS without
+    // staging registers) into a ring of three planes.  Phase clock of k_cart_residual3 at 216^3 (thread 0, cycles per
+    // step): load_plane 6357 (two global round trips in front of the barrier, every step), arithmetic 9251, emit + barrier
+    // 847, stores 2374.  Here the requests of plane ck + 2 are issued in front of the arithmetic of layer ck and are
+    // waited for at the ONE barrier of the step, behind it.  The lattice must be the whole lexicographic box of a single
+    // rank (node ids by arithmetic: an id looked up in a table is a load, and the compiler's vmcnt(0) in front of its
+    // use would wait for the requests as well) with byte offsets below 4 GiB (launcher).  Sums and their order are those
+    // of k_cart_residual3 <true>: the results are the same bits.
+    // =====================================================================================
+    constexpr int RPD = 320; // plane stride: 10 wave transfers of 64 dwords per field
+    struct LdsR3D
+    {
+      double U[3][6][RPD];       // [ring][field][halo node]; first: the transfers address LDS through M0's 16-bit offset
+      double P[2][8][RTX * RTY]; // [parity of the step][a_y * 4 + component]
+      unsigned nofs[RPD];        // lexicographic id of the halo node in plane 0 (clamped to the box)
+    };
+    static_assert(sizeof(LdsR3D) <= 81920, "two workgroups per CU");
+
+    // HET: heterogeneous material.  A template parameter, not a uniform branch: behind a branch the compiler waits for the
+    // two loads with vmcnt(0) in the middle of the arithmetic whether they were issued or not -- i.e. for the requests
+    template <bool HET>
+    __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3d(DevView v, CartView cv, Scal S, double *__restrict__ res_pde,
+                                                                  double *__restrict__ res_tot, int write_total, int zc)
+    {
+      __shared__ LdsR3D s;
+      const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
+      const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+      const int OWX = cv.NX, OWY = cv.NY;
+      const int ntx = (OWX + RNX - 1) / RNX, nty = (OWY + RNY - 1) / RNY;
+      const int bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); // XCD-aware launch, pfm_internal.h
+      if (bid >= ntx * nty * ((cv.NZ - 1 + zc) / zc))
+        return;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
+      const int i0 = tix * RNX, j0 = tiy * RNY;
+      const int kA = chunk * zc;
+      const int kB = min(kA + zc, cv.NZ); // node planes [kA, kB)
+      const int ci = i0 - 1 + cx, cj = j0 - 1 + cy;
+      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1;
+      const bool node_ok = cx < RNX && cy < RNY && (i0 + cx) < cv.NX && (j0 + cy) < cv.NY;
+      const unsigned plane = (unsigned)cv.NX * (unsigned)cv.NY;
+
+      for (int idx = t; idx < RPD; idx += RTX * RTY)
+        {
+          const int q = min(idx, RHX * RHY - 1);
+          const int gi = min(max(i0 - 1 + q % RHX, 0), cv.NX - 1), gj = min(max(j0 - 1 + q / RHX, 0), cv.NY - 1);
+          s.nofs[idx] = (unsigned)gi + (unsigned)cv.NX * (unsigned)gj;
+        }
+      // where the six fields lie: base (uniform), byte offset of node n = ((n [* 3]) << sh) + add
+      const bool fused = v.fused_solution != nullptr, il = v.layout == PFM_LAYOUT_INTERLEAVED;
+      const void *fb[6];
+      unsigned ftri[6], fsh[6], fadd[6];
+#pragma unroll
+      for (int f = 0; f < 6; ++f)
+        {
+          fb[f] = f == 0 ? v.u[0] : f == 1 ? v.u[1] : f == 2 ? v.u[2] : f == 3 ? v.phi : f == 4 ? v.phi_old : v.phi_oldold;
+          ftri[f] = 0u, fsh[f] = 3u, fadd[f] = 0u;
+          if (fused && f < 4)
+            {
+              fb[f] = (f == 3 && !il) ? v.fused_solution + 3LL * v.n_owned : v.fused_solution;
+              ftri[f] = (f < 3 && !il) ? 0xffffffffu : 0u;
+              fsh[f] = il ? 5u : 3u;
+              fadd[f] = (f < 3 || il) ? 8u * f : 0u;
+            }
+        }
+      __syncthreads();
+      auto request_plane = [&](int kz, int slot) __attribute__((always_inline)) {
+        const unsigned pk = (unsigned)min(max(kz, 0), cv.NZ - 1) * plane;
+        int lq = lane;
+        asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          {
+            const int jj = wv + 4 * r; // waves 0, 1: transfers {w, w + 4, w + 8} of every field, waves 2, 3: {w, w + 4}
+            if (jj < 10)
+              {
+                const unsigned n = s.nofs[32 * jj + (lq >> 1)] + pk;
+                unsigned bo[6];
+                void *dst[6];
+#pragma unroll
+                for (int f = 0; f < 6; ++f)
+                  {
+                    const unsigned ne = ((n & ftri[f]) << 1) + n;
+                    bo[f] = (ne << fsh[f]) + fadd[f] + 4u * (lq & 1);
+                    dst[f] = reinterpret_cast<uint32_t *>(&s.U[slot][f][0]) + 64 * jj;
+                  }
+                dma_b32x6(fb, bo, dst);
+              }
+          }
+      };
+      // single rank, solution vector read in place: the node state is what pfm_state_set_solution would have left -- every
+      // node is written once, by the tile and z-chunk that own it, from the plane that has just landed
+      auto publish_plane = [&](int kz, int slot) __attribute__((always_inline)) {
+        if (fused && kz >= kA && kz < kB)
+          {
+            int tq = t;
+            asm volatile("" : "+v"(tq));
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              {
+                const int idx = tq + r * RTX * RTY;
+                const int hx = idx % RHX, hy = idx / RHX;
+                if (idx < RHX * RHY && hx >= 1 && hx <= RNX && hy >= 1 && hy <= RNY && i0 - 1 + hx < cv.NX && j0 - 1 + hy < cv.NY)
+                  {
+                    const unsigned n = s.nofs[idx] + (unsigned)kz * plane;
+                    v.u[0][n] = s.U[slot][0][idx];
+                    v.u[1][n] = s.U[slot][1][idx];
+                    v.u[2][n] = s.U[slot][2][idx];
+                    v.phi[n] = s.U[slot][3][idx];
+                  }
+              }
+          }
+      };
+
+      double M[2][2][2][4]; // the moment basis of k_cart_residual3
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          M[a & 1][(a >> 1) & 1][a >> 2][c] = 0.0;
+
+      request_plane(kA - 1, 0);
+      request_plane(kA, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      publish_plane(kA, 1);
+      const int hb = cy * RHX + cx;
+      int sl = 0; // ring slot of plane ck
+#pragma unroll 1
+      for (int ck = kA - 1; ck < kB; ++ck)
+        {
+          const int sh = sl == 2 ? 0 : sl + 1, sn = sh == 2 ? 0 : sh + 1;
+          const int par = (ck - kA) & 1;
+          if (ck + 2 <= kB) // (slot sn held plane ck - 1: every wave is past the barrier behind that layer's arithmetic)
+            request_plane(ck + 2, sn);
+          if (col_ok && ck >= 0 && ck < cv.NZ - 1)
+            {
+              const double *Ulo = &s.U[sl][0][hb], *Uhi = &s.U[sh][0][hb];
+              double lam = S.lam, mu = S.mu;
+              if constexpr (HET) // heterogeneous material, cracks.cc:2207-2216
+                {
+                  const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+                  lam = cv.cell_lam[cidx];
+                  mu = cv.cell_mu[cidx];
+                }
+              residual_cell_poly<PlaneSoA<RPD>, true>(Ulo, Uhi, Ulo, Uhi, S, lam, mu, M);
+            }
+          const bool emit = ck >= kA;
+          if (emit)
+            {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                {
+                  const double l01 = M[0][1][0][c] - M[0][1][1][c], l11 = M[1][1][0][c] - M[1][1][1][c];
+                  const double l00 = (M[0][0][0][c] - M[0][0][1][c]) - l01, l10 = (M[1][0][0][c] - M[1][0][1][c]) - l11;
+                  s.P[par][0 * 4 + c][t] = l10 + row_shl1(l00 - l10);
+                  s.P[par][1 * 4 + c][t] = l11 + row_shl1(l01 - l11);
+                }
+            }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // plane ck + 2 has landed (and the stores of the last step are out)
+          __syncthreads();
+          if (emit && node_ok)
+            {
+              const unsigned row = (unsigned)(i0 + cx) + (unsigned)cv.NX * (unsigned)(j0 + cy) + (unsigned)ck * plane;
+              const unsigned fl = v.node_flags[row];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                {
+                  const double r = -s.P[par][4 + c][t] - s.P[par][c][t + RTX];
+                  const bool con = (fl >> c) & 1u;
+                  const long long di = dof_index_c<3>(v, (int)row, c);
+                  res_pde[di] = con ? 0.0 : r; // constrained scatter = masked store (cracks.cc:2440-2456)
+                  if (write_total)
+                    res_tot[di] = (con && S.total_via_update) ? 0.0 : r;
+                }
+            }
+          publish_plane(ck + 2, sn);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              {
+                M[a & 1][a >> 1][0][c] = M[a & 1][a >> 1][1][c];
+                M[a & 1][a >> 1][1][c] = 0.0;
+              }
+          sl = sh;
+        }
+    }
+
+
+    // =====================================================================================
+    // k_cart_residual3x: k_cart_residual3d for the solution vector of a single rank in the BLOCKED layout, read in place,
+    // with 16-byte transfers.  A transfer instruction costs the wave ~150 cycles whatever its width (phase clock of
+    // k_cart_residual3d: 60 dword transfers per plane, 2750 cycles per step in the wave that issues 18 of them), so
+    // the plane is fetched in 16 instead of 60:
+    //   * the displacements stay interleaved as they lie in the vector: a halo row is 17 nodes x 3 doubles = 51 doubles in
+    //     a row of 52 (26 lanes; the last double belongs to the next node), 17 rows = 442 lanes = 7 transfers;
+    //   * a phase-field plane is 17 rows of 18 doubles (9 lanes: pairs of x-neighbours; the 18th column is the next
+    //     node of the lattice row), 153 lanes = 3 transfers per field.
+    // The first / last pair of the whole lattice would reach in front of / behind the arrays: the workgroup and plane
+    // that own them fall back to dword transfers, node by node (clamped to the box like every halo node outside it).
+    // =====================================================================================
+    constexpr int XUR = 52, XSR = 18;                       // row strides (doubles) of the interleaved displacements / a phase field
+    constexpr int XUO = 0, XUN = RHY * XUR;                 // 884 doubles = 442 lanes
+    constexpr int XSN = RHY * XSR;                          // 306 doubles = 153 lanes
+    constexpr int XPL = XUN + 3 * XSN;                      // doubles per ring slot
+    struct PlaneX
+    {
+      static constexpr int off(int f) { return f < 3 ? f : (f - 3) * XSN; }
+      static constexpr int xs(int f) { return f < 3 ? 3 : 1; }
+      static constexpr int ys(int f) { return f < 3 ? XUR : XSR; }
+    };
+    struct LdsR3X
+    {
+      double U[3][XPL];          // [ring][u interleaved | phi | phi_old | phi_oldold]; first: M0 holds a 16-bit LDS offset
+      double P[2][8][RTX * RTY]; // [parity of the step][a_y * 4 + component]
+      unsigned tu[448];          // byte offset of the lane's 16 bytes of the displacement rows, plane 0
+      unsigned ts[192];          // node id of the lane's pair of a phase-field plane, plane 0
+    };
+    static_assert(sizeof(LdsR3X) <= 81920 && (XUN % 2) == 0 && (XSN % 2) == 0 && (XPL % 2) == 0, "two workgroups per CU; 16-byte lanes");
+
+    template <bool HET>
+    __global__ __launch_bounds__(RTX *RTY, 2) void k_cart_residual3x(DevView v, CartView cv, Scal S, double *__restrict__ res_pde,
+                                                                  double *__restrict__ res_tot, int write_total, int zc)
+    {
+      __shared__ LdsR3X s;
+      const int t = threadIdx.x, cx = t % RTX, cy = t / RTX;
+      const int wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+      const int ntx = (cv.NX + RNX - 1) / RNX, nty = (cv.NY + RNY - 1) / RNY;
+      const int bid = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)); // XCD-aware launch, pfm_internal.h
+      if (bid >= ntx * nty * ((cv.NZ - 1 + zc) / zc))
+        return;
+      const int tix = bid % ntx, tiy = (bid / ntx) % nty, chunk = bid / (ntx * nty);
+      const int i0 = tix * RNX, j0 = tiy * RNY;
+      const int kA = chunk * zc;
+      const int kB = min(kA + zc, cv.NZ); // node planes [kA, kB)
+      const int ci = i0 - 1 + cx, cj = j0 - 1 + cy;
+      const bool col_ok = ci >= 0 && ci < cv.NX - 1 && cj >= 0 && cj < cv.NY - 1;
+      const bool node_ok = cx < RNX && cy < RNY && (i0 + cx) < cv.NX && (j0 + cy) < cv.NY;
+      const unsigned plane = (unsigned)cv.NX * (unsigned)cv.NY;
+      const double *const sol = v.fused_solution, *const solp = v.fused_solution + 3LL * v.n_owned;
+
+      for (int q = t; q < 448; q += RTX * RTY) // (rows outside the box: the nearest row inside; columns: wherever the lattice row leads)
+        {
+          const int hy = min(q / 26, RHY - 1), pr = q % 26;
+          const int gj = min(max(j0 - 1 + hy, 0), cv.NY - 1);
+          s.tu[q] = 24u * (unsigned)(i0 - 1 + cv.NX * gj) + 16u * (unsigned)pr;
+        }
+      for (int q = t; q < 192; q += RTX * RTY)
+        {
+          const int hy = min(q / 9, RHY - 1), m = q % 9;
+          const int gj = min(max(j0 - 1 + hy, 0), cv.NY - 1);
+          s.ts[q] = (unsigned)(i0 - 1 + 2 * m + cv.NX * gj);
+        }
+      __syncthreads();
+      // 16 transfers per plane, 4 per wave: job g = wave + 4 r; jobs 0..6: displacement rows, 7..15: field (g - 7) / 3, part (g - 7) % 3
+      auto request_plane = [&](int kz, int slot) __attribute__((always_inline)) {
+        const int kc = min(max(kz, 0), cv.NZ - 1);
+        const unsigned pk = (unsigned)kc * plane;
+        int lq = lane;
+        asm volatile("" : "+v"(lq)); // recomputed per step, not kept live across the march
+        const bool edge = (kc == 0 && i0 == 0 && j0 == 0) || (kc == cv.NZ - 1 && i0 + RHX >= cv.NX - 1 && j0 + RHY - 1 >= cv.NY - 1);
+        if (!edge)
+          {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              {
+                const int g = wv + 4 * r;
+                if (g < 7)
+                  {
+                    const int q = 64 * g + lq;
+                    if (q < XUN / 2)
+                      dma_b128(sol, s.tu[q] + 24u * pk, &s.U[slot][XUO + 128 * g]);
+                  }
+                else
+                  {
+                    const int f = (g - 7) / 3, jj = (g - 7) % 3; // uniform
+                    const double *const fb = f == 0 ? solp : f == 1 ? v.phi_old : v.phi_oldold;
+                    const int q = 64 * jj + lq;
+                    if (q < XSN / 2)
+                      dma_b128(fb, 8u * (s.ts[q] + pk), &s.U[slot][XUN + f * XSN + 128 * jj]);
+                  }
+              }
+          }
+        else
+          {
+            // the planes that hold the first / the last node of the lattice, in the workgroups that reach them
+#pragma unroll 1
+            for (int g = wv; g < 28 + 30; g += 4)
+              {
+                if (g < 28)
+                  {
+                    const int d = 64 * g + lq, e = d >> 1; // dword d of the displacement rows
+                    const int hy = min(e / XUR, RHY - 1), rem = e % XUR, hx = min(rem / 3, RHX - 1), c = rem % 3;
+                    const int gi = min(max(i0 - 1 + hx, 0), cv.NX - 1), gj = min(max(j0 - 1 + hy, 0), cv.NY - 1);
+                    const unsigned n = (unsigned)gi + (unsigned)cv.NX * (unsigned)gj + pk;
+                    if (d < 2 * XUN)
+                      dma_b32(sol, 24u * n + 8u * (unsigned)c + 4u * (d & 1), reinterpret_cast<uint32_t *>(&s.U[slot][XUO]) + 64 * g);
+                  }
+                else
+                  {
+                    const int f = (g - 28) / 10, jj = (g - 28) % 10;
+                    const double *const fb = f == 0 ? solp : f == 1 ? v.phi_old : v.phi_oldold;
+                    const int d = 64 * jj + lq, e = d >> 1;
+                    const int hy = min(e / XSR, RHY - 1), hx = min(e % XSR, RHX - 1);
+                    const int gi = min(max(i0 - 1 + hx, 0), cv.NX - 1), gj = min(max(j0 - 1 + hy, 0), cv.NY - 1);
+                    const unsigned n = (unsigned)gi + (unsigned)cv.NX * (unsigned)gj + pk;
+                    if (d < 2 * XSN)
+                      dma_b32(fb, 8u * n + 4u * (d & 1), reinterpret_cast<uint32_t *>(&s.U[slot][XUN + f * XSN]) + 64 * jj);
+                  }
+              }
+          }
+      };
+      // the node state is what pfm_state_set_solution would have left: every node is written once, by the tile and
+      // z-chunk that own it, from the plane that has just landed
+      auto publish_plane = [&](int kz, int slot) __attribute__((always_inline)) {
+        if (kz >= kA && kz < kB)
+          {
+            int tq = t;
+            asm volatile("" : "+v"(tq));
+            const int hx = 1 + tq % RNX, hy = 1 + tq / RNX;
+            if (tq < RNX * RNY && i0 - 1 + hx < cv.NX && j0 - 1 + hy < cv.NY)
+              {
+                const unsigned n = (unsigned)(i0 - 1 + hx) + (unsigned)cv.NX * (unsigned)(j0 - 1 + hy) + (unsigned)kz * plane;
+                const double *pu = &s.U[slot][XUO + hy * XUR + 3 * hx];
+                v.u[0][n] = pu[0];
+                v.u[1][n] = pu[1];
+                v.u[2][n] = pu[2];
+                v.phi[n] = s.U[slot][XUN + hy * XSR + hx];
+              }
+          }
+      };
+
+      double M[2][2][2][4]; // the moment basis of k_cart_residual3
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          M[a & 1][(a >> 1) & 1][a >> 2][c] = 0.0;
+
+      const int hbu = XUO + cy * XUR + 3 * cx, hbs = XUN + cy * XSR + cx;
+      int sl = 1; // ring slot of plane ck: plane kA - 1 in slot 0.  The first two steps only request (one call site)
+#pragma unroll 1
+      for (int ck = kA - 3; ck < kB; ++ck)
+        {
+          const int sh = sl == 2 ? 0 : sl + 1, sn = sh == 2 ? 0 : sh + 1;
+          const int par = (ck - kA) & 1;
+          if (ck + 2 <= kB) // (slot sn held plane ck - 1: every wave is past the barrier behind that layer's arithmetic)
+            request_plane(ck + 2, sn);
+          if (col_ok && ck >= max(kA - 1, 0) && ck < cv.NZ - 1)
+            {
+              double lam = S.lam, mu = S.mu;
+              if constexpr (HET) // heterogeneous material, cracks.cc:2207-2216
+                {
+                  const long long cidx = ci + (long long)(cv.NX - 1) * (cj + (long long)(cv.NY - 1) * ck);
+                  lam = cv.cell_lam[cidx];
+                  mu = cv.cell_mu[cidx];
+                }
+              residual_cell_poly<PlaneX, true>(&s.U[sl][hbu], &s.U[sh][hbu], &s.U[sl][hbs], &s.U[sh][hbs], S, lam, mu, M);
+            }
+          const bool emit = ck >= kA;
+          if (emit)
+            {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                {
+                  const double l01 = M[0][1][0][c] - M[0][1][1][c], l11 = M[1][1][0][c] - M[1][1][1][c];
+                  const double l00 = (M[0][0][0][c] - M[0][0][1][c]) - l01, l10 = (M[1][0][0][c] - M[1][0][1][c]) - l11;
+                  s.P[par][0 * 4 + c][t] = l10 + row_shl1(l00 - l10);
+                  s.P[par][1 * 4 + c][t] = l11 + row_shl1(l01 - l11);
+                }
+            }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // plane ck + 2 has landed (and the stores of the last step are out)
+          __syncthreads();
+          if (emit && node_ok)
+            {
+              const unsigned row = (unsigned)(i0 + cx) + (unsigned)cv.NX * (unsigned)(j0 + cy) + (unsigned)ck * plane;
+              const unsigned fl = v.node_flags[row];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                {
+                  const double r = -s.P[par][4 + c][t] - s.P[par][c][t + RTX];
+                  const bool con = (fl >> c) & 1u;
+                  const long long di = dof_index_c<3>(v, (int)row, c);
+                  res_pde[di] = con ? 0.0 : r; // constrained scatter = masked store (cracks.cc:2440-2456)
+                  if (write_total)
+                    res_tot[di] = (con && S.total_via_update) ? 0.0 : r;
+                }
+            }
+          publish_plane(ck + 2, sn);
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              {
+                M[a & 1][a >> 1][0][c] = M[a & 1][a >> 1][1][c];
+                M[a & 1][a >> 1][1][c] = 0.0;
+              }
+          sl = sh;
+        }
+    }
+
     bool g_tab_ready[16] = {};
     int ensure_tab()
     {
@@ -1298,8 +1725,31 @@ namespace pfm
         const int nch = (int)((OWZ + zc - 1) / zc);
         const bool listed = cv.tile_sel == 2 && cv.bnd_res3 != nullptr && cv.zc_res3 == zc;
         const unsigned nt = listed ? (unsigned)cv.n_bnd_res3 : (unsigned)(ntx * nty * nch);
+        // the whole lexicographic box of a single rank, every byte offset of a node below 4 GiB: planes by transfer
+        // (read per launch: the tests compare the three kernels in one process)
+        const bool no_transfers = getenv("PFM_RES_NO_TRANSFERS") != nullptr;   // k_cart_residual3 <true>
+        const bool wide_off = getenv("PFM_RES_NO_WIDE_TRANSFERS") != nullptr;  // k_cart_residual3d instead of 3x
+        const bool whole_lex = cv.owned_lex && cv.o0[0] == 0 && cv.o0[1] == 0 && cv.o0[2] == 0 && cv.o1[0] == cv.NX - 1 &&
+                               cv.o1[1] == cv.NY - 1 && cv.o1[2] == cv.NZ - 1 && cv.tile_sel == 0 && !cv.row_of_box &&
+                               (long long)v.n_nodes == (long long)cv.NX * cv.NY * cv.NZ && v.n_owned == v.n_nodes &&
+                               (long long)v.n_nodes * 32 < (1LL << 32) && !no_transfers;
         if (nt == 0)
           ;
+        else if (!S.monolithic && S.gamma_fac == 0.0 && whole_lex && v.fused_solution && v.layout == PFM_LAYOUT_BLOCKED && v.n_nodes >= 64 &&
+                 !wide_off)
+          {
+            if (cv.cell_lam)
+              hipLaunchKernelGGL(k_cart_residual3x<true>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+            else
+              hipLaunchKernelGGL(k_cart_residual3x<false>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+          }
+        else if (!S.monolithic && S.gamma_fac == 0.0 && whole_lex)
+          {
+            if (cv.cell_lam)
+              hipLaunchKernelGGL(k_cart_residual3d<true>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+            else
+              hipLaunchKernelGGL(k_cart_residual3d<false>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
+          }
         else if (!S.monolithic && S.gamma_fac == 0.0)
           hipLaunchKernelGGL(k_cart_residual3<true>, dim3(xcd_grid(nt)), dim3(RTX * RTY), 0, s, v, cv, S, res_pde, res_tot, residual_only, zc);
         else

@@ -503,6 +503,46 @@ def test_assemble_nl_residual_device_reads_the_solution_itself(dim, n, blocked):
     assert linf_scaled(A.data, A_ref.data) < TOL and linf_scaled(bufs[0].cpu().numpy(), r.residual_pde) < TOL
 
 
+@pytest.mark.parametrize("n", [(15, 15, 2), (16, 31, 5), (14, 29, 3), (33, 16, 26), (45, 46, 7)])
+def test_residual_kernels_with_planes_by_transfer_agree(n, monkeypatch):
+    """k_cart_residual3x (blocked solution vector read in place, 16-byte global -> LDS transfers two planes ahead),
+    k_cart_residual3d (dword transfers, any layout) and k_cart_residual3 <true> (planes through registers) form the same
+    sums in the same order: same bits, on boxes whose last tile holds 1, 2 or 15 nodes, with one or several z-chunks, and in
+    the workgroups that hold the first / the last node of the lattice (dword fallback).  The node state the 3x kernel
+    publishes is the solution: a residual from the state alone (no scatter) is the same again."""
+    import torch
+
+    c = box_case(3, n, -10.0, 10.0, True)
+    ctx = make_context(c)
+    ctx.assemble_host(c.sol, c.old, c.oldold, True)
+    rng = np.random.default_rng(11)
+    sol2 = c.sol + 1e-3 * rng.standard_normal(c.sol.shape)
+    nd = c.layout.n_dofs
+    d_sol = torch.from_numpy(np.ascontiguousarray(sol2)).cuda()
+
+    def run():
+        bufs = [torch.full((nd,), 7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+        ctx.assemble_nl_residual_device(d_sol.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr())
+        ctx.sync_status()
+        return bufs[0].cpu().numpy(), bufs[1].cpu().numpy()
+
+    rx, tx = run()
+    # the published state: the plain residual-only assembly reads it
+    bufs = [torch.empty(nd, dtype=torch.float64, device="cuda") for _ in range(2)]
+    ctx.assemble_device(True, [], bufs[0].data_ptr(), bufs[1].data_ptr())
+    ctx.sync_status()
+    assert np.array_equal(bufs[0].cpu().numpy(), rx) and np.array_equal(bufs[1].cpu().numpy(), tx)
+    monkeypatch.setenv("PFM_RES_NO_WIDE_TRANSFERS", "1")
+    rd, td = run()
+    monkeypatch.setenv("PFM_RES_NO_TRANSFERS", "1")
+    ro, to = run()
+    assert np.array_equal(rx, rd) and np.array_equal(tx, td)
+    assert np.array_equal(rx, ro) and np.array_equal(tx, to)
+    c.sol = sol2
+    r, _, _ = oracle(c, True)
+    assert linf_scaled(rx, r.residual_pde) < TOL and linf_scaled(tx, r.residual_total) < TOL
+
+
 def test_bench_reports_the_config5_standin():
     """bench.py's `extra.config5_standin`: the adaptive stress-split stand-in runs through the general
     family + cartesian overlay (kernel path 3) and the record carries the times, the roofline fraction and the rebuild."""
