@@ -1691,7 +1691,7 @@ namespace pfm
     CartView cv = cv_in;
     cv.tile_sel = phase; // 0: all tiles, 1: interior, 2: boundary -- of the FIRST kernel of the sequence only (below)
     if (v.dim == 2 && !residual_only)
-      return launch_cart2d(v, cv, p, residual_only, d_values, res_pde, res_tot, s); // 2-D Jacobian + residual
+      return launch_cart2d(v, cv, p, residual_only, d_values, res_pde, res_tot, s_jac, s); // 2-D Jacobian + residual (s != s_jac: forked by the caller)
     const Scal S = make_scal(p, cv, v.dim);
     // Full 3-D assembly, staggered scheme (no q-point clamps of the phase fields, no penalty term): the unsplit law makes
     // every residual row an exact function of its own matrix row (R_u = pressure part - K_uu u, R_phi = G_c/eps mass - K_phiphi

@@ -53,68 +53,108 @@ namespace pfm
       double gce;                                                        // G_c eps
     };
 
-    __global__ __launch_bounds__(64, 2) void k_cart2d_cells(DevView v, CartView cv, Prm2 P, Cst2 K, Vals2 vals, double *__restrict__ res_pde,
-                                                            double *__restrict__ res_tot, int write_total, int total_via_update)
+    // GROUP 0: the displacement rows (c = 0, 1) of every node, GROUP 1: the phase-field row, 2: all three.  Round 6: one
+    // launch per group.  The 59 moments, the accumulators of a group and the nodal values do not fit 256 registers: the
+    // single kernel spilled 30 of them, and at two waves per SIMD under a stream of stores the scratch lines do not
+    // stay in the L2 -- counters at 1000^2: 921 MB written, 309 MB fetched for 697 MB of rows and ~90 MB of input.  Each
+    // group needs its own moments only (the compiler drops the others); the q-point states are evaluated twice, by
+    // SIMDs that were 16 % busy.
+#ifndef PFM_C2_OCC0
+#define PFM_C2_OCC0 2
+#endif
+#ifndef PFM_C2_OCC1
+#define PFM_C2_OCC1 2
+#endif
+    template <int GROUP>
+    __global__ __launch_bounds__(64, GROUP == 0 ? PFM_C2_OCC0 : GROUP == 1 ? PFM_C2_OCC1 : 2) void k_cart2d_cells(DevView v, CartView cv, Prm2 P, Cst2 K, Vals2 vals, double *__restrict__ res_pde,
+                                                            double *__restrict__ res_tot, int write_total, int total_via_update, int n_blocks_y)
     {
       const int lane = threadIdx.x, cx = lane & (B2 - 1), cy = lane >> 3;
       const int OWX = cv.o1[0] - cv.o0[0] + 1;
       const int ntx = (OWX + O2 - 1) / O2;
-      const int tix = (int)(blockIdx.x % ntx), tiy = (int)(blockIdx.x / ntx);
+      // XCD-aware launch (pfm_internal.h): neighbouring blocks read the same nodes and meet in the cache lines at the ends
+      // of their block rows, and only blocks of one XCD meet in an L2 (0.297 -> 0.285 ms at 1000^2)
+      const int bid = xcd_tile_index();
+      if (bid >= ntx * n_blocks_y)
+        return;
+      const int tix = bid % ntx, tiy = bid / ntx;
       // this lane's cell (i, j) = its lower-left node
       const int i = cv.o0[0] + tix * O2 + cx - 1, j = cv.o0[1] + tiy * O2 + cy - 1;
       const bool owner = cx >= 1 && cy >= 1 && i <= cv.o1[0] && j <= cv.o1[1];
       bool cell_ok = i >= 0 && i < cv.NX - 1 && j >= 0 && j < cv.NY - 1;
 
-      // ---- nodal data of the cell: [field][vertex b = b_x + 2 b_y], fields u_x u_y phi phi_old phi_oldold
-      double F[5][4];
-#pragma unroll
-      for (int f = 0; f < 5; ++f)
-        F[f][0] = F[f][1] = F[f][2] = F[f][3] = 0.0;
-      if (cell_ok)
+      // ---- ids first, then everything that depends on them, in two rounds of independent loads.  (Round 6: as
+      // cart_local_id() per vertex / neighbour -- arithmetic or table, decided in a branch -- the compiler waited with
+      // vmcnt(0) at every join: 4 + 9 round trips one behind the other in front of the arithmetic, a third of the wave's
+      // life at two waves per SIMD.)  The lattice table holds every node of the box: always the table, clamped index.
+      const long long NXl = cv.NX;
+      int nb[4], q[9];
+      // the whole box of a single rank, numbered lexicographically: ids by arithmetic -- one round of loads instead of two.
+      // (A uniform branch: the wait the compiler puts at its join finds nothing else in flight.)
+      const bool lex = cv.owned_lex && cv.o0[0] == 0 && cv.o0[1] == 0 && cv.o1[0] == cv.NX - 1 && cv.o1[1] == cv.NY - 1;
+      if (lex)
         {
 #pragma unroll
           for (int b = 0; b < 4; ++b)
-            {
-              const int n = cart_local_id(cv, i + (b & 1), j + (b >> 1), 0);
-              if (n < 0)
-                {
-                  cell_ok = false; // a cell this rank does not know completely touches none of its rows
-                  continue;
-                }
-              F[0][b] = v.u[0][n];
-              F[1][b] = v.u[1][n];
-              F[2][b] = v.phi[n];
-              F[3][b] = v.phi_old[n];
-              F[4][b] = v.phi_oldold[n];
-            }
-        }
-      // ---- the node of this lane: row info and the constraint flags of the 9 lattice neighbours, requested before the
-      // arithmetic (a load per neighbour inside the store loops is a chain of exposed round trips)
-      int row = 0;
-      unsigned fP = 0u, mask = 0u, fN = 0u; // fN: 3 flag bits per lattice offset o
-      long long off = 0;
-      bool writes = owner;
-      if (owner && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
-        writes = false; // overlapped assembly: the other launch owns this node's rows
-      if (writes)
-        {
-          row = cart_local_id(cv, i, j, 0);
-          fP = v.node_flags[row];
-          mask = cv.nbr_mask[row];
-          off = v.nadj_ptr[row];
-          unsigned fl[9];
+            nb[b] = cell_ok ? (i + (b & 1)) + cv.NX * (j + (b >> 1)) : 0;
 #pragma unroll
           for (int o = 0; o < 9; ++o)
             {
               const int qi = i + (o % 3) - 1, qj = j + (o / 3) - 1;
-              int q = -1;
-              if (qi >= 0 && qi < cv.NX && qj >= 0 && qj < cv.NY)
-                q = cart_local_id(cv, qi, qj, 0);
-              fl[o] = q >= 0 ? (unsigned)v.node_flags[q] & 7u : 0u;
+              q[o] = (qi >= 0 && qi < cv.NX && qj >= 0 && qj < cv.NY) ? qi + cv.NX * qj : -1;
             }
+        }
+      else
+        {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            nb[b] = cv.local_of_box[cell_ok ? (i + (b & 1)) + NXl * (j + (b >> 1)) : 0];
 #pragma unroll
           for (int o = 0; o < 9; ++o)
-            fN |= fl[o] << (3 * o);
+            {
+              const int qi = i + (o % 3) - 1, qj = j + (o / 3) - 1;
+              const bool in = qi >= 0 && qi < cv.NX && qj >= 0 && qj < cv.NY;
+              const int id = cv.local_of_box[in ? qi + NXl * qj : 0];
+              q[o] = in ? id : -1;
+            }
+        }
+      // ---- nodal data of the cell: [field][vertex b = b_x + 2 b_y], fields u_x u_y phi phi_old phi_oldold
+      double F[5][4];
+      cell_ok = cell_ok && nb[0] >= 0 && nb[1] >= 0 && nb[2] >= 0 && nb[3] >= 0; // a cell this rank does not know completely touches none of its rows
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        {
+          const int n = cell_ok ? nb[b] : 0;
+          F[0][b] = v.u[0][n];
+          F[1][b] = v.u[1][n];
+          F[2][b] = v.phi[n];
+          F[3][b] = v.phi_old[n];
+          F[4][b] = v.phi_oldold[n];
+        }
+      // ---- the node of this lane: row info and the constraint flags of the 9 lattice neighbours
+      bool writes = owner;
+      if (owner && cart_tile_skipped(cv, cart_range_has_ghost(cv, 0, i - 1, i + 1) || cart_range_has_ghost(cv, 1, j - 1, j + 1)))
+        writes = false; // overlapped assembly: the other launch owns this node's rows
+      const int row = writes ? q[4] : 0;
+      unsigned fN = 0u; // 3 flag bits per lattice offset o
+      {
+        unsigned fl[9];
+#pragma unroll
+        for (int o = 0; o < 9; ++o)
+          fl[o] = v.node_flags[q[o] >= 0 ? q[o] : 0];
+#pragma unroll
+        for (int o = 0; o < 9; ++o)
+          fN |= ((writes && q[o] >= 0) ? (fl[o] & 7u) : 0u) << (3 * o);
+      }
+      const unsigned fP_l = v.node_flags[row], mask_l = cv.nbr_mask[row];
+      const long long off_l = v.nadj_ptr[row];
+      const unsigned fP = writes ? fP_l : 0u, mask = writes ? mask_l : 0u;
+      const long long off = writes ? off_l : 0;
+      if (!cell_ok)
+        {
+#pragma unroll
+          for (int f = 0; f < 5; ++f)
+            F[f][0] = F[f][1] = F[f][2] = F[f][3] = 0.0;
         }
       double lam = P.lam, mu = P.mu;
       if (cv.cell_lam && cell_ok) // heterogeneous material, cracks.cc:2207-2216
@@ -316,13 +356,19 @@ namespace pfm
           return -(RS[Ax][Ay] + fma(sx * P.ihx, RHx[Ay], (sy * P.ihy) * RHy[Ax]));
       };
       using std::integral_constant;
-      // mean |diagonal| of the element matrix: deal.II's placeholder when a constrained row's own entry vanishes
+      // mean |diagonal| of the element matrix: deal.II's placeholder when a constrained row's own entry vanishes.  Needed
+      // in blocks with constrained rows only (!plain, below).  Two launches: the first forms it (it has the registers for the
+      // moments of both diagonal blocks) and leaves it in CartView::cell_avg for the second, which then needs none of the
+      // (u,u) moments: 256 registers + 14 spilled -> 245, none spilled.
       double avg = 0.0;
-      static_for<4>([&](auto Aa) __attribute__((always_inline)) {
-        avg += fabs(uu_entry(Aa, Aa, integral_constant<int, 0>{}, integral_constant<int, 0>{})) +
-               fabs(uu_entry(Aa, Aa, integral_constant<int, 1>{}, integral_constant<int, 1>{})) + fabs(pp_entry(Aa, Aa));
-      });
-      avg *= 1.0 / 12.0;
+      if constexpr (GROUP != 1)
+        {
+          static_for<4>([&](auto Aa) __attribute__((always_inline)) {
+            avg += fabs(uu_entry(Aa, Aa, integral_constant<int, 0>{}, integral_constant<int, 0>{})) +
+                   fabs(uu_entry(Aa, Aa, integral_constant<int, 1>{}, integral_constant<int, 1>{})) + fabs(pp_entry(Aa, Aa));
+          });
+          avg *= 1.0 / 12.0;
+        }
 
       const int deg = __popc(mask & 0x1ffu);
       const bool blocked = v.layout == PFM_LAYOUT_BLOCKED;
@@ -339,6 +385,17 @@ namespace pfm
       const bool staged = blocked && __all(chain_ok);
       // regular interior blocks (all 9 neighbours, no constraint anywhere in the stencils): slots and masks are compile-time
       const bool plain = staged && __all(!writes || (mask == 0x1ffu && fP == 0u && fN == 0u));
+      if constexpr (GROUP != 2)
+        {
+          if (!plain && cell_ok) // (wave-uniform: both launches see the same masks and flags)
+            {
+              double *const pa = cv.cell_avg + (i + (long long)(cv.NX - 1) * j);
+              if constexpr (GROUP == 0)
+                *pa = avg;
+              else
+                avg = *pa;
+            }
+        }
       const int rel = (int)(off - off_first); // position of this node's row in the block row, in entries
       const long long row_len = __shfl(off + deg, cy * B2 + n_row) - off_first; // entries of the block row
       const bool row_live = cy >= 1 && (cv.o0[1] + tiy * O2 + cy - 1) <= cv.o1[1];
@@ -353,8 +410,16 @@ namespace pfm
             const bool live = __shfl((int)row_live, (r + 1) * B2 + 1) != 0;
             if (!live)
               continue;
-            for (int k = lane; k < len; k += 64)
-              dst[scale * o_f + k] = s_rows[r][base + k];
+            // all reads of the row, then its stores (one read -> wait -> store per turn was a chain of exposed LDS latencies:
+            // 20 k of a wave's 136 k cycles per flush in the phase clock)
+            double x[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+              x[qq] = s_rows[r][min(base + lane + 64 * qq, 4 * 9 * O2 + 4)];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+              if (lane + 64 * qq < len)
+                dst[scale * o_f + lane + 64 * qq] = x[qq];
           }
         lds_barrier();
       };
@@ -374,6 +439,7 @@ namespace pfm
       };
 
       // ---- rows c = 0, 1: (u,u) block, the (u,phi) block is structurally zero (cracks.cc:2333-2337)
+      if constexpr (GROUP != 1)
       {
         double acc[9][2][2], R[2] = {0.0, 0.0}, dg[2] = {0.0, 0.0};
 #pragma unroll
@@ -486,6 +552,7 @@ namespace pfm
           }
       }
       // ---- row c = 2: (phi,u) and (phi,phi) blocks
+      if constexpr (GROUP != 0)
       {
         double apu[9][2], app[9], R2 = 0.0, dg2 = 0.0;
 #pragma unroll
@@ -576,10 +643,13 @@ namespace pfm
                 const int len = (int)__shfl(row_len, (r + 1) * B2 + 1);
                 if (__shfl((int)row_live, (r + 1) * B2 + 1) == 0)
                   continue;
-                for (int k = lane; k < 2 * len; k += 64)
-                  vals.b[2][2 * o_f + k] = s_rows[r][k];
-                for (int k = lane; k < len; k += 64)
-                  vals.b[3][o_f + k] = s_rows[r][2 * 9 * O2 + k];
+                const double x0 = s_rows[r][lane], x1 = s_rows[r][lane + 64], x2 = s_rows[r][2 * 9 * O2 + lane];
+                if (lane < 2 * len)
+                  vals.b[2][2 * o_f + lane] = x0;
+                if (lane + 64 < 2 * len)
+                  vals.b[2][2 * o_f + lane + 64] = x1;
+                if (lane < len)
+                  vals.b[3][o_f + lane] = x2;
               }
           }
       }
@@ -589,7 +659,7 @@ namespace pfm
   // 2-D cartesian boxes: Jacobian + residual without the stress split (the plain 2-D residual has its own kernel in
   // pfm_cart.hip)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
-                    double *res_pde, double *res_tot, hipStream_t s)
+                    double *res_pde, double *res_tot, hipStream_t s, hipStream_t s_phi)
   {
     int rc = ensure_g1();
     if (rc)
@@ -635,8 +705,17 @@ namespace pfm
     K.gc_eps_vol_x = P.Gc * P.eps * P.vol * P.ihx * P.ihx;
     K.gc_eps_vol_y = P.Gc * P.eps * P.vol * P.ihy * P.ihy;
     const long long ntx = (cv.o1[0] - cv.o0[0] + 1 + O2 - 1) / O2, nty = (cv.o1[1] - cv.o0[1] + 1 + O2 - 1) / O2;
-    hipLaunchKernelGGL(k_cart2d_cells, dim3((unsigned)(ntx * nty)), dim3(64), 0, s, v, cv, P, K, vals, res_pde, res_tot, residual_only,
-                       total_via_update);
+    const bool one_launch = getenv("PFM_CART2D_ONE_LAUNCH") != nullptr; // A/B runs, tests
+    if (one_launch)
+      hipLaunchKernelGGL(k_cart2d_cells<2>, dim3(xcd_grid((unsigned)(ntx * nty))), dim3(64), 0, s, v, cv, P, K, vals, res_pde, res_tot, residual_only,
+                         total_via_update, (int)nty);
+    else
+      {
+        hipLaunchKernelGGL(k_cart2d_cells<0>, dim3(xcd_grid((unsigned)(ntx * nty))), dim3(64), 0, s, v, cv, P, K, vals, res_pde, res_tot, residual_only,
+                           total_via_update, (int)nty);
+        hipLaunchKernelGGL(k_cart2d_cells<1>, dim3(xcd_grid((unsigned)(ntx * nty))), dim3(64), 0, s_phi, v, cv, P, K, vals, res_pde, res_tot, residual_only,
+                           total_via_update, (int)nty);
+      }
     return hipGetLastError() == hipSuccess ? PFM_OK : PFM_ERR_HIP;
   }
 } // namespace pfm

@@ -94,6 +94,8 @@ namespace pfm
                                  // sorted behind the owned ones): CSR slot of the r-th existing offset =
                                  // row_perm[nadj_ptr[row] + r]; nullptr when no row needs it
     const double *cell_lam, *cell_mu; // per-cell Lame coefficients (cracks.cc:2207-2216) in lattice cell order
+    double *cell_avg;                 // 2-D boxes: [(NX-1)*(NY-1)] scratch, mean |diagonal| of the element matrices of the blocks with
+                                      // constrained rows -- from the first launch of k_cart2d_cells to the second
                                       // ci + (NX-1) (cj + (NY-1) ck); nullptr: the scalars of pfm_params
     // pfm_assemble_overlapped, phase 2: compact launches over the tiles that read ghost nodes (lists built on first use:
     // an early-exit launch over the full grid costs ~3 ns per skipped workgroup, 0.4 ms at 1.5e5 tiles)
@@ -199,7 +201,7 @@ namespace pfm
   bool cart_matrix_supported(int dim);
   // 2-D boxes: row-owner Jacobian + residual of runs WITHOUT the stress split (pfm_cart2d.hip; PFM_ERR_UNSUPPORTED otherwise)
   int launch_cart2d(const DevView &v, const CartView &cv, const pfm_params &p, int residual_only, double *const *d_values,
-                    double *res_pde, double *res_tot, hipStream_t s);
+                    double *res_pde, double *res_tot, hipStream_t s, hipStream_t s_phi);
   // z-chunk length of a marching kernel: `tiles` columns, `planes` node planes, one redundant cell layer per chunk,
   // `per_cu` resident workgroups per CU.  Maximises (fill of the last dispatch round) x (useful layers per chunk).
   int choose_zchunk(long long tiles, int planes, int zc_min, int zc_max, int per_cu);
