@@ -539,8 +539,10 @@ namespace pfm
         if (staged)
           {
             flush(vals.b[0], 4, 0);
+            // (u,phi): structurally zero (cracks.cc:2333-2337).  CartView::up_block_cleared: a fill in front of the launch
+            // has written the block (18 of the 81 doubles of a node, at the rate of a plain stream of stores)
 #pragma unroll 1
-            for (int r = 0; r < O2; ++r) // (u,phi): structurally zero (cracks.cc:2333-2337)
+            for (int r = 0; r < (cv.up_block_cleared ? 0 : O2); ++r)
               {
                 const long long o_f = __shfl(off_first, (r + 1) * B2 + 1);
                 const int len = 2 * (int)__shfl(row_len, (r + 1) * B2 + 1);

@@ -3842,6 +3842,19 @@ extern "C"
         c->scal_dirty = false;
       }
     pfm::CartView cv_launch = c->cv;
+    cv_launch.up_block_cleared = 0;
+    // 2-D box, blocked layout: the structurally zero (u,phi) block (cracks.cc:2333-2337) by a fill in front of the kernels
+    // (PFM_CART2D_NO_FILL: the kernel writes the zeros with the rows, A/B runs)
+    if (cart && c->v.dim == 2 && !residual_only && phase <= 1 && c->v.layout == PFM_LAYOUT_BLOCKED && c->n_blocks == 4 && d_values[1] &&
+        getenv("PFM_CART2D_NO_FILL") == nullptr && getenv("PFM_CART2D_ONE_LAUNCH") == nullptr)
+      {
+        if (hipMemsetAsync(d_values[1], 0, sizeof(double) * (size_t)c->block_nnz(1), c->stream) != hipSuccess)
+          return fail(c, PFM_ERR_HIP, "clear the (u,phi) block");
+        cv_launch.up_block_cleared = 1;
+      }
+    if (cart && c->v.dim == 2 && phase == 2 && c->v.layout == PFM_LAYOUT_BLOCKED && getenv("PFM_CART2D_NO_FILL") == nullptr &&
+        getenv("PFM_CART2D_ONE_LAUNCH") == nullptr && !residual_only)
+      cv_launch.up_block_cleared = 1; // cleared in phase 1 of this overlapped assembly
     // (round 6, measured and removed: clearing the structurally zero (u,phi) block with a fill on a third stream instead of
     // by 21 of the 49 store instructions of every copy-out of k_cart_phi4 -- 10.95 -> 11.35 ms per assembly at 216^3,
     // profiles/r06/ab_up_fill.txt: the fill takes bandwidth in a burst and dispatch slots from the pair)

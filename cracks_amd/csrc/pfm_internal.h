@@ -114,6 +114,7 @@ namespace pfm
     // launch -- hanging, parent, mixed-level or ghost nodes stay with the general family).  nullptr: every owned node of
     // the box is a row (uniform boxes).
     const int32_t *row_of_box;
+    int up_block_cleared;             // 2-D boxes, blocked layout: the caller has cleared the structurally zero (u,phi) block with a fill
     int tile_sel;                     // 0: every tile; 1: only tiles that read no ghost node ("interior"); 2: only the
                                       // others -- the two launches of pfm_assemble_overlapped, between which the ghost
                                       // import lands (cracks.cc:2147-2154 next to the cell loop instead of in front of it)
