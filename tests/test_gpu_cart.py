@@ -503,8 +503,9 @@ def test_assemble_nl_residual_device_reads_the_solution_itself(dim, n, blocked):
     assert linf_scaled(A.data, A_ref.data) < TOL and linf_scaled(bufs[0].cpu().numpy(), r.residual_pde) < TOL
 
 
-@pytest.mark.parametrize("n", [(15, 15, 2), (16, 31, 5), (14, 29, 3), (33, 16, 26), (45, 46, 7)])
-def test_residual_kernels_with_planes_by_transfer_agree(n, monkeypatch):
+@pytest.mark.parametrize("n,het", [((15, 15, 2), False), ((16, 31, 5), False), ((14, 29, 3), False), ((33, 16, 26), False),
+                                   ((45, 46, 7), False), ((17, 30, 6), True)])
+def test_residual_kernels_with_planes_by_transfer_agree(n, het, monkeypatch):
     """k_cart_residual3x (blocked solution vector read in place, 16-byte global -> LDS transfers two planes ahead),
     k_cart_residual3d (dword transfers, any layout) and k_cart_residual3 <true> (planes through registers) form the same
     sums in the same order: same bits, on boxes whose last tile holds 1, 2 or 15 nodes, with one or several z-chunks, and in
@@ -513,6 +514,8 @@ def test_residual_kernels_with_planes_by_transfer_agree(n, monkeypatch):
     import torch
 
     c = box_case(3, n, -10.0, 10.0, True)
+    if het:  # per-cell Lame coefficients: the <HET> instances of the two transfer kernels
+        c = heterogeneous(c)
     ctx = make_context(c)
     ctx.assemble_host(c.sol, c.old, c.oldold, True)
     rng = np.random.default_rng(11)
@@ -541,6 +544,39 @@ def test_residual_kernels_with_planes_by_transfer_agree(n, monkeypatch):
     c.sol = sol2
     r, _, _ = oracle(c, True)
     assert linf_scaled(rx, r.residual_pde) < TOL and linf_scaled(tx, r.residual_total) < TOL
+
+
+@pytest.mark.parametrize("blocked", [True, False])
+def test_cart2d_launch_variants_agree(blocked, monkeypatch):
+    """k_cart2d_cells: one launch per row group (default; the mean |diagonal| of a block with constrained rows goes from
+    the first launch to the second through CartView::cell_avg, the structurally zero (u,phi) block is cleared by a fill
+    in front of them), the same without the fill, and the single launch of round 5 write the same bits -- on a box with
+    Dirichlet lines, an active set and dead zones where diagonal entries vanish (the placeholder needs the mean)."""
+    c = box_case(2, (45, 31), -10.0, 10.0, blocked, monolithic=True)
+    c.params.constant_k = 0.0
+    node, comp = c.layout.node_comp_of_dof()
+    is_phi = comp == 2
+    dead = c.mesh.coords[node[is_phi]][:, 0] < 0.0
+    o = c.old.copy()
+    o[np.nonzero(is_phi)[0][dead]] = 0.0
+    c.old, c.oldold = o, o.copy()
+    phi_dofs = np.nonzero(is_phi)[0]
+    c.cu = M.update_constraints(c.mesh, c.layout, M.sneddon_dirichlet_dofs(c.mesh, c.layout), phi_dofs[::5])
+    ctx = make_context(c)
+    assert ctx.kernel_path == 1
+
+    def run():
+        vals, rp, _ = ctx.assemble_host(c.sol, c.old, c.oldold, False)
+        return [np.array(v, copy=True) for v in vals], rp.copy()
+
+    v0, p0 = run()
+    for key in ("PFM_CART2D_NO_FILL", "PFM_CART2D_ONE_LAUNCH"):
+        monkeypatch.setenv(key, "1")
+        v1, p1 = run()
+        assert all(np.array_equal(a, b) for a, b in zip(v0, v1)) and np.array_equal(p0, p1), key
+    monkeypatch.delenv("PFM_CART2D_NO_FILL")
+    monkeypatch.delenv("PFM_CART2D_ONE_LAUNCH")
+    _full(c, path=1)
 
 
 def test_bench_reports_the_config5_standin():
