@@ -87,9 +87,9 @@ HASH = "$HASH"
 def per_kernel(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
+        m = re.search(r"(k_[a-z0-9_]+)(<[0-9]+>)?", r["Kernel_Name"])  # (k_cart2d_cells<0> and <1>: two launches per assembly)
         if m and "pfm" in r["Kernel_Name"]:
-            acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[m.group(1) + (m.group(2) or "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
     # the 3-D residual kernels: the run's set-up (all three vectors through the state) launches another variant once --
     # not a part of the assemblies the record describes
